@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the radix-partitioned hash join on MI355X.
+
+A "step" = one full pass of the hot path over one batch of synthetic input already resident in HBM:
+radix-partition R, radix-partition S, build+probe (count-only), read the count back
+(the reference's timed region, src/hash_join_clustered_probe.cu:881-933 / 953-980).
+Workload at N=1: BASELINE.json configs[2] — 2^30 ⋈ 2^30 unique uniform int32 keys, payload = 1.
+For N>1 each rank holds 2^30 tuples of R and of S (weak scaling, config 5 shape): level-0 shard
+split → all-to-all over xGMI (RCCL) → local partition + build/probe → all-reduce of the count.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(log2n, seconds_budget=25.0):
+    """The oracle's OpenMP radix join ("port") on a bounded sample of the same workload shape, on
+    this box's host cores.  Only this leg touches oracle/."""
+    import numpy as np
+    from oracle import pyoracle as o
+    threads = o.max_threads()
+    n = 1 << log2n
+    rng = np.random.default_rng(7)
+    R = rng.permutation(n).astype(np.int32)
+    S = rng.permutation(n).astype(np.int32)
+    bits = max(0, log2n - 12)
+    b2 = bits // 2
+    t0 = time.perf_counter()
+    m, _ = o.radix_join_omp(R, None, S, None, bits - b2, b2, threads)
+    dt = time.perf_counter() - t0
+    assert m == n, (m, n)
+    return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port",
+            "sample": "2^%d ⋈ 2^%d unique uniform int32 (same shape as the GPU workload, smaller), oracle "
+                      "o_radix_join_omp two-pass radix + chained build/probe, %d OpenMP threads, %.1f s" %
+                      (log2n, log2n, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
+    ap.add_argument("--cpu-log2n", type=int, default=26)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-materialize", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    pkg = graft.load_package()
+    n = 1 << a.log2n
+    total_n = n * world
+
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
+    # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
+    domain = min(total_n, 1 << 32)
+    Rk = torch.empty(n, dtype=torch.int32, device=dev)
+    Sk = torch.empty(n, dtype=torch.int32, device=dev)
+    Rp = torch.empty(n, dtype=torch.int32, device=dev)
+    Sp = torch.empty(n, dtype=torch.int32, device=dev)
+    hj.gen_unique(Rk, n, rank * n, domain, 1)
+    hj.gen_unique(Sk, n, rank * n, domain, 2)
+    hj.fill_payload(Rp, n, "ones")
+    hj.fill_payload(Sp, n, "ones")
+    hj.sync()
+    dup = max(1, total_n // domain)
+    expect = total_n * dup  # every key occurs dup times in R and in S
+
+    if world > 1:
+        from importlib import import_module
+        dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev)
+
+    def step():
+        if world == 1:
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            return hj.join()[0]
+        return dj.join(Rk, Rp, Sk, Sp)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        got = step()
+        assert got == expect, (got, expect)
+    hj.timings_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert got == expect, (got, expect)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kt = hj.timings()
+    ms_per_step = dt / a.steps * 1e3
+    value = 2.0 * total_n * a.steps / dt / 1e9
+
+    # roofline of the dominant kernel: the radix scatter (4 launches per step at N=1: 2 passes x 2
+    # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
+    sc = kt.get("k_scatter", {"launches": 0, "total_ms": 0.0})
+    roof = None
+    if sc["launches"]:
+        launches_per_step = sc["launches"] / a.steps
+        tuples_per_launch = 2.0 * n * (launches_per_step / 2.0) / launches_per_step if world == 1 else float(n)
+        tuples_per_launch = float(n)  # every scatter launch moves one whole local relation
+        avg_ms = sc["total_ms"] / sc["launches"]
+        achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_scatter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch}
+    kernels = {k: {"launches_per_step": v["launches"] / a.steps, "ms_per_step": round(v["total_ms"] / a.steps, 4)}
+               for k, v in kt.items() if v["launches"]}
+    jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
+    probe = None
+    if jc["launches"] and world == 1:
+        avg = jc["total_ms"] / jc["launches"]
+        probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
+                 "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1),
+                 "frac_of_8TBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # secondary: the materialising variant (count + scan + write of (key,payR,payS)), N=1 only
+    mat = None
+    if world == 1 and not a.no_materialize:
+        cap = expect
+        ok, opr, ops = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
+        hj.timings_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = max(1, a.steps // 2)
+        for _ in range(reps):
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            hj.partition(pkg.REL_R)
+            hj.partition(pkg.REL_S)
+            nout = hj.join_materialize_into(ok, opr, ops, cap)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / reps
+        assert nout == expect
+        km = hj.timings()
+        mk = km.get("k_join_materialize", {"launches": 0, "total_ms": 0.0})
+        mat = {"value": round(2.0 * n / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3),
+               "output_tuples": int(nout)}
+        if mk["launches"]:
+            avg = mk["total_ms"] / mk["launches"]
+            mat["k_join_materialize_ms"] = round(avg, 4)
+            mat["k_join_materialize_GBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9, 1)
+        del ok, opr, ops
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_log2n)
+
+    if rank == 0:
+        cfg = hj.config()
+        line = {
+            "metric": "billion tuples/sec (build+probe), 2^30⋈2^30 int32 uniform, 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "2^%d ⋈ 2^%d unique uniform int32 keys per GPU, payload=1, count-only "
+                                   "build+probe after %d-pass radix partition (%d+%d bits)%s" %
+                                   (a.log2n, a.log2n, 2 if cfg["bits2"] else 1, cfg["bits1"], cfg["bits2"],
+                                    "" if world == 1 else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
+                       "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
+                       "matches": int(got)},
+            "roofline": roof, "probe_phase": probe, "kernels": kernels, "materialize": mat, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

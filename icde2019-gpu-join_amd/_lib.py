@@ -1,0 +1,99 @@
+"""ctypes binding of libhj.so (include/hj.h).  No fallback: if the library is missing it is built
+with hipcc, and if that fails the import fails."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhj.so")
+BENCH_PATH = os.path.join(_HERE, "bench")
+
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class Config(C.Structure):
+    _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
+                ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
+                ("probe_chunk", C.c_uint32), ("reserved", C.c_uint32 * 9)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float),
+                ("last_ms", C.c_float)]
+
+
+class Args(C.Structure):  # include/hj_reference_abi.h  (src/common-host.h:39-52)
+    _fields_ = [("S", i32p), ("S_els", C.c_size_t), ("S_filename", C.c_char * 50),
+                ("R", i32p), ("R_els", C.c_size_t), ("R_filename", C.c_char * 50),
+                ("threadsNum", C.c_int), ("sharedMem", C.c_uint), ("pivotsNum", C.c_uint)]
+
+
+class LastResult(C.Structure):
+    _fields_ = [("matches", C.c_ulonglong), ("agg", C.c_ulonglong), ("materialized", C.c_ulonglong),
+                ("partition_ms", C.c_double * 2), ("join_ms", C.c_double * 2), ("status", C.c_int)]
+
+
+# every symbol include/hj.h and include/hj_reference_abi.h declare: (restype, argtypes)
+SIGNATURES = {
+    "hj_version": (C.c_char_p, []),
+    "hj_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "hj_destroy": (C.c_int, [vp]),
+    "hj_error": (C.c_char_p, [vp]),
+    "hj_set_stream": (C.c_int, [vp, vp]),
+    "hj_configure": (C.c_int, [vp, C.POINTER(Config)]),
+    "hj_get_config": (C.c_int, [vp, C.POINTER(Config)]),
+    "hj_sync": (C.c_int, [vp]),
+    "hj_load_host": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64, C.c_int]),
+    "hj_bind_device": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64]),
+    "hj_partition": (C.c_int, [vp, C.c_int]),
+    "hj_join_count": (C.c_int, [vp, u64p, u64p]),
+    "hj_join_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
+    "hj_join": (C.c_int, [vp, u64p, u64p]),
+    "hj_device_malloc": (C.c_int, [vp, C.POINTER(vp), C.c_uint64]),
+    "hj_device_free": (C.c_int, [vp, vp]),
+    "hj_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "hj_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "hj_get_partitions": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]),
+    "hj_timings_reset": (C.c_int, [vp]),
+    "hj_timings": (C.c_int, [vp, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "hj_shard_split": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u64p]),
+    "hj_shard_of": (C.c_uint32, [C.c_int32, C.c_uint32]),
+    "hj_gen_unique": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hj_fill_payload": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64]),
+    "hj_digest_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, u64p]),
+    "hj_digest_triples": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
+    "hj_verify_partitions": (C.c_int, [vp, C.c_int, u64p, vp]),
+    "hj_gen_set_seed": (None, [C.c_uint64]),
+    "hj_create_relation_unique": (C.c_int, [C.c_char_p, vp, C.c_uint64, C.c_int64]),
+    "hj_create_relation_nonunique": (C.c_int, [C.c_char_p, vp, C.c_uint64, C.c_int64]),
+    "hj_create_relation_zipf": (C.c_int, [C.c_char_p, vp, C.c_uint64, C.c_int64, C.c_double]),
+    "hj_create_relation_fk_from_pk": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_uint64]),
+    "hj_create_relation_n": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64]),
+    "hj_read_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
+    "hj_write_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
+    "hashJoinClusteredProbe": (C.c_uint, [C.POINTER(Args), vp]),
+    "hj_reference_last_result": (None, [C.POINTER(LastResult)]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libhj.so and bench for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not (os.path.exists(LIB_PATH) and os.path.exists(BENCH_PATH)):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "all"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, argt) in SIGNATURES.items():
+            f = getattr(_lib, name)  # AttributeError if the header and the library disagree
+            f.restype = res
+            f.argtypes = argt
+    return _lib

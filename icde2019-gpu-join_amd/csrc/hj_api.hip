@@ -1,0 +1,664 @@
+// hj_api.hip — host side of libhj.so: context, HBM buffers, pass orchestration, the C ABI of
+// include/hj.h.  Replaces the host steps of outOfGPU_Join1_payload (hjcp.cu:802-994) and
+// prepare_Relation_payload (jp.cu:1582-1613).  Everything between hj_partition and the final
+// result copy is enqueued on one HIP stream with no host read of device data (same discipline as
+// the reference's timed region, hjcp.cu:881-933: *buckets_used is only dereferenced on device).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "hj.h"
+#include "hj_internal.h"
+
+using namespace hj;
+
+namespace {
+
+constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-byte tail loads)
+constexpr uint32_t TARGET_SPANS = 2048;
+constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 8192;
+constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
+
+struct KStat { std::string name; uint32_t launches = 0; float total_ms = 0, last_ms = 0; };
+struct Stamp { int kid; hipEvent_t a, b; };
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Rel {
+    const int32_t *in_k = nullptr, *in_p = nullptr; // input columns (caller's or own_*)
+    uint64_t n = 0;
+    bool bound = false;
+    Buf own_k, own_p;         // hj_load_host copies
+    Buf a_k, a_p, b_k, b_p;   // pass-1 / final partitioned columns
+    Buf off1, off2, root;     // partition offsets (uint64)
+    const int32_t *part_k = nullptr, *part_p = nullptr;
+    const uint64_t *part_off = nullptr;
+    uint32_t nparts = 0;
+    bool partitioned = false;
+};
+
+} // namespace
+
+struct hj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    hj_config cfg{};
+    uint32_t bits1 = 0, bits2 = 0, cap = 0, nh = 0, chunk = 0; // effective
+    int build = HJ_REL_R;
+    std::string err;
+    Rel rel[2];
+    // workspace
+    Buf span_start, hist, chunk_sums, chunk_prefix;
+    Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
+    Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
+    uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64)
+    bool join_planned = false;
+    uint32_t max_items = 0;
+    size_t lds_limit = 0;
+    // timing
+    bool events = true;
+    std::vector<KStat> kstats;
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+int fail(hj_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return fail(c, e__ == hipErrorOutOfMemory ? HJ_ENOMEM : HJ_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+                        hipGetErrorString(e__));                                                      \
+    } while (0)
+
+#define RET(x)                                                                                        \
+    do {                                                                                              \
+        int r__ = (x);                                                                                \
+        if (r__) return r__;                                                                          \
+    } while (0)
+
+int ensure(hj_ctx *c, Buf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    if (b.p) {
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    if (bytes == 0) bytes = 256;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+void release(Buf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int kid_of(hj_ctx *c, const char *name) {
+    for (size_t i = 0; i < c->kstats.size(); i++)
+        if (c->kstats[i].name == name) return (int)i;
+    KStat k;
+    k.name = name;
+    c->kstats.push_back(k);
+    return (int)c->kstats.size() - 1;
+}
+
+hipEvent_t get_event(hj_ctx *c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RAII: HIP events on the context stream around one kernel launch
+struct Timed {
+    hj_ctx *c;
+    Stamp s;
+    bool on;
+    Timed(hj_ctx *ctx, const char *name) : c(ctx), on(ctx->events) {
+        if (!on) return;
+        s.kid = kid_of(c, name);
+        s.a = get_event(c);
+        s.b = get_event(c);
+        (void)hipEventRecord(s.a, c->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(s.b, c->stream);
+        c->stamps.push_back(s);
+    }
+};
+
+void resolve_stamps(hj_ctx *c) {
+    for (auto &s : c->stamps) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            KStat &k = c->kstats[s.kid];
+            k.launches++;
+            k.total_ms += ms;
+            k.last_ms = ms;
+        }
+        c->pool.push_back(s.a);
+        c->pool.push_back(s.b);
+    }
+    c->stamps.clear();
+}
+
+uint32_t ceil_log2(uint64_t x) {
+    uint32_t k = 0;
+    while (((uint64_t)1 << k) < x) k++;
+    return k;
+}
+
+// radix bits from the relation sizes (replaces the constants of common.h:51-52)
+void choose_bits(hj_ctx *c) {
+    const hj_config &g = c->cfg;
+    uint64_t nR = c->rel[0].n, nS = c->rel[1].n;
+    if (g.build_side == 1) c->build = HJ_REL_R;
+    else if (g.build_side == 2) c->build = HJ_REL_S;
+    else c->build = (nS < nR) ? HJ_REL_S : HJ_REL_R;
+    c->cap = g.lds_capacity ? g.lds_capacity : DEFAULT_CAP;
+    if (c->cap > 65535) c->cap = 65535;
+    c->nh = g.lds_heads ? g.lds_heads : DEFAULT_HEADS;
+    while (c->nh & (c->nh - 1)) c->nh &= c->nh - 1; // round down to a power of two
+    if (!c->nh) c->nh = 1;
+    c->chunk = g.probe_chunk ? g.probe_chunk : DEFAULT_CHUNK;
+    if (g.force_bits || g.bits1) {
+        c->bits1 = g.bits1 > 9 ? 9 : g.bits1;
+        c->bits2 = g.bits2 > 9 ? 9 : g.bits2;
+        if (!c->bits1) { c->bits1 = c->bits2; c->bits2 = 0; }
+        return;
+    }
+    uint64_t nb = c->rel[c->build].n;
+    uint32_t total = nb > TARGET_PART ? ceil_log2((nb + TARGET_PART - 1) / TARGET_PART) : 0;
+    if (total > 18) total = 18;
+    if (total <= 9) { c->bits1 = total; c->bits2 = 0; }
+    else { c->bits2 = total / 2; c->bits1 = total - c->bits2; }
+}
+
+// one radix pass: in(keys,pays) partitioned by parents → out, child offsets → coff
+int run_pass(hj_ctx *c, int mode, const int32_t *in_k, const int32_t *in_p, uint64_t n, const uint64_t *poff,
+             uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
+             uint64_t *coff) {
+    if (nparents > (uint32_t)MAX_PARENTS || P > (uint32_t)MAX_PARTS || P == 0) return fail(c, HJ_EINVAL, "pass fan-out out of range");
+    if (n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU pass (n < 2^32 required)");
+    uint64_t span64 = (n + TARGET_SPANS - 1) / TARGET_SPANS;
+    span64 = ((span64 + TILE - 1) / TILE) * TILE;
+    if (span64 < (uint64_t)TILE) span64 = TILE;
+    PassArgs pa{};
+    pa.keys = in_k; pa.pays = in_p; pa.nalloc = n; pa.poff = poff; pa.nparents = nparents;
+    pa.span = (uint32_t)span64;
+    pa.max_spans = (uint32_t)((n + span64 - 1) / span64) + nparents;
+    pa.shift = shift; pa.P = P; pa.mask_or_n = mask_or_n;
+    uint64_t max_len = (uint64_t)pa.max_spans * P;
+    uint64_t nchunks = (max_len + SCAN_CHUNK - 1) / SCAN_CHUNK + 2;
+    RET(ensure(c, c->span_start, (size_t)(nparents + 1) * 4));
+    RET(ensure(c, c->hist, (size_t)max_len * 4));
+    RET(ensure(c, c->chunk_sums, (size_t)nchunks * 8));
+    RET(ensure(c, c->chunk_prefix, (size_t)nchunks * 8));
+    pa.span_start = (uint32_t *)c->span_start.p;
+    pa.hist = (uint32_t *)c->hist.p;
+    pa.chunk_sums = (uint64_t *)c->chunk_sums.p;
+    pa.chunk_prefix = (uint64_t *)c->chunk_prefix.p;
+    pa.out_keys = out_k; pa.out_pays = out_p;
+    hipStream_t st = c->stream;
+    { Timed t(c, "k_plan"); HIPCHK(c, launch_plan(st, poff, nparents, pa.span, pa.span_start)); }
+    { Timed t(c, "k_hist"); HIPCHK(c, launch_hist(st, mode, pa)); }
+    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + nparents, P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr)); }
+    { Timed t(c, "k_offsets"); HIPCHK(c, launch_offsets(st, pa, n, coff)); }
+    { Timed t(c, "k_scatter"); HIPCHK(c, launch_scatter(st, mode, pa)); }
+    return 0;
+}
+
+int check_rel(hj_ctx *c, int rel) {
+    if (!c) return HJ_EINVAL;
+    if (rel != HJ_REL_R && rel != HJ_REL_S) return fail(c, HJ_EINVAL, "rel must be HJ_REL_R or HJ_REL_S");
+    return 0;
+}
+
+void invalidate(hj_ctx *c) {
+    c->rel[0].partitioned = c->rel[1].partitioned = false;
+    c->join_planned = false;
+}
+
+int partition_rel(hj_ctx *c, int r) {
+    Rel &R = c->rel[r];
+    if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
+    choose_bits(c);
+    hipStream_t st = c->stream;
+    RET(ensure(c, R.root, 2 * 8));
+    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n)); }
+    const uint32_t b1 = c->bits1, b2 = c->bits2;
+    if (b1 == 0) { // nothing to partition: one partition = the input itself
+        R.part_k = R.in_k; R.part_p = R.in_p; R.part_off = (const uint64_t *)R.root.p; R.nparts = 1;
+        R.partitioned = true;
+        c->join_planned = false;
+        return 0;
+    }
+    const size_t colbytes = (size_t)(R.n + PAD) * 4;
+    RET(ensure(c, R.b_k, colbytes));
+    RET(ensure(c, R.b_p, colbytes));
+    const uint32_t P1 = 1u << b1, P2 = 1u << b2;
+    if (b2 == 0) {
+        RET(ensure(c, R.off2, (size_t)(P1 + 1) * 8));
+        RET(run_pass(c, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, 0, P1, P1 - 1, (int32_t *)R.b_k.p,
+                     (int32_t *)R.b_p.p, (uint64_t *)R.off2.p));
+        R.nparts = P1;
+    } else {
+        RET(ensure(c, R.a_k, colbytes));
+        RET(ensure(c, R.a_p, colbytes));
+        RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
+        RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
+        // pass 1 on key bits [b2, b2+b1), pass 2 on bits [0, b2): final partition id = low b1+b2 key
+        // bits, pass-1 digit major — the order of jp.cu:402 ((pid << log_parts2) + j)
+        RET(run_pass(c, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, (int32_t *)R.a_k.p,
+                     (int32_t *)R.a_p.p, (uint64_t *)R.off1.p));
+        RET(run_pass(c, 0, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
+                     P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, (uint64_t *)R.off2.p));
+        R.nparts = P1 * P2;
+    }
+    R.part_k = (const int32_t *)R.b_k.p;
+    R.part_p = (const int32_t *)R.b_p.p;
+    R.part_off = (const uint64_t *)R.off2.p;
+    R.partitioned = true;
+    c->join_planned = false;
+    return 0;
+}
+
+// work-item list + per-wave counts; leaves scanned wave counts in place for the materialising kernel
+int run_count(hj_ctx *c, JoinArgs &a, bool &tag16) {
+    Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
+    if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
+    if (B.nparts != Pb.nparts) return fail(c, HJ_EINVAL, "relations partitioned with different fan-out");
+    hipStream_t st = c->stream;
+    const uint32_t nparts = B.nparts;
+    const uint32_t rbits = c->bits1 + c->bits2;
+    tag16 = (32 - rbits) <= 16; // the tag shortcut of jp.cu:1029 is exact only then (D2)
+    const uint64_t max_items64 = (uint64_t)nparts + Pb.n / c->chunk + 1;
+    if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
+    c->max_items = (uint32_t)max_items64;
+    RET(ensure(c, c->items_cnt, (size_t)nparts * 4));
+    RET(ensure(c, c->items, (size_t)c->max_items * 8));
+    const uint64_t nwave = (uint64_t)c->max_items * JOIN_WAVES;
+    RET(ensure(c, c->wave_counts, (size_t)nwave * 8));
+    RET(ensure(c, c->wave_agg, (size_t)nwave * 8));
+    uint64_t nch = (nwave + SCAN_CHUNK - 1) / SCAN_CHUNK + 2;
+    uint64_t nch2 = ((uint64_t)nparts + SCAN_CHUNK - 1) / SCAN_CHUNK + 2;
+    if (nch2 > nch) nch = nch2;
+    RET(ensure(c, c->jchunk_sums, (size_t)nch * 8));
+    RET(ensure(c, c->jchunk_prefix, (size_t)nch * 8));
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    const size_t lds = join_lds_bytes(c->nh, c->cap, tag16);
+    if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
+    if (lds > c->lds_limit) {
+        HIPCHK(c, join_set_lds_limit(lds));
+        c->lds_limit = lds;
+    }
+    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, B.part_off, Pb.part_off, nparts, c->chunk, (uint32_t *)c->items_cnt.p)); }
+    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
+                                                      (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
+    { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, B.part_off, Pb.part_off, nparts, c->chunk, (const uint32_t *)c->items_cnt.p,
+                                                                (const uint64_t *)c->jchunk_prefix.p, (uint2 *)c->items.p)); }
+    a = JoinArgs{};
+    a.bk = B.part_k; a.bp = B.part_p; a.boff = B.part_off; a.b_nalloc = B.n;
+    a.pk = Pb.part_k; a.pp = Pb.part_p; a.poff = Pb.part_off; a.p_nalloc = Pb.n;
+    a.items = (const uint2 *)c->items.p;
+    a.n_items = sc + 0;
+    a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
+    a.wave_counts = (uint64_t *)c->wave_counts.p;
+    a.wave_agg = (uint64_t *)c->wave_agg.p;
+    { Timed t(c, "k_join_count"); HIPCHK(c, launch_join(st, a, c->max_items, tag16, false)); }
+    HIPCHK(c, hipMemsetAsync(sc + 2, 0, 8, st));
+    // n_items is a uint64 on the device; the scans take its low word as their length (little endian)
+    const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
+    { Timed t(c, "k_reduce"); HIPCHK(c, launch_reduce64(st, a.wave_agg, len, JOIN_WAVES, sc + 2)); }
+    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u64(st, a.wave_counts, len, JOIN_WAVES, nwave, (uint64_t *)c->jchunk_sums.p,
+                                                      (uint64_t *)c->jchunk_prefix.p, sc + 1)); }
+    return 0;
+}
+
+int fetch_scalars(hj_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *hj_version(void) { return "hj-mi355x 0.1 (gfx950)"; }
+
+int hj_create(hj_ctx **out, int device) {
+    if (!out) return HJ_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return HJ_EHIP; // no GPU: fail loudly, there is no CPU fallback
+    if (device < 0 || device >= ndev) return HJ_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return HJ_EHIP;
+    hj_ctx *c = new hj_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_EHIP; }
+    c->stream = c->own_stream;
+    if (hipMalloc(&c->scalars.p, 64) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    c->scalars.cap = 64;
+    if (hipHostMalloc((void **)&c->h_scalars, 64, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    memset(c->h_scalars, 0, 64);
+    const char *ev = getenv("HJ_NO_KERNEL_EVENTS");
+    c->events = !(ev && ev[0] == '1');
+    *out = c;
+    return HJ_OK;
+}
+
+int hj_destroy(hj_ctx *c) {
+    if (!c) return HJ_EINVAL;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto &e : c->pool) (void)hipEventDestroy(e);
+    for (int r = 0; r < 2; r++) {
+        Rel &R = c->rel[r];
+        release(R.own_k); release(R.own_p); release(R.a_k); release(R.a_p); release(R.b_k); release(R.b_p);
+        release(R.off1); release(R.off2); release(R.root);
+    }
+    release(c->span_start); release(c->hist); release(c->chunk_sums); release(c->chunk_prefix);
+    release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
+    release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return HJ_OK;
+}
+
+const char *hj_error(const hj_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int hj_set_stream(hj_ctx *c, void *s) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_stamps(c);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return HJ_OK;
+}
+
+int hj_configure(hj_ctx *c, const hj_config *cfg) {
+    if (!c || !cfg) return HJ_EINVAL;
+    if (cfg->bits1 > 9 || cfg->bits2 > 9) return fail(c, HJ_EINVAL, "at most 9 radix bits per pass");
+    if (cfg->lds_capacity > 65535) return fail(c, HJ_EINVAL, "lds_capacity must be <= 65535 (16-bit chain links)");
+    if (cfg->lds_heads & (cfg->lds_heads - 1)) return fail(c, HJ_EINVAL, "lds_heads must be a power of two");
+    c->cfg = *cfg;
+    invalidate(c);
+    return HJ_OK;
+}
+
+int hj_get_config(const hj_ctx *c, hj_config *cfg) {
+    if (!c || !cfg) return HJ_EINVAL;
+    hj_ctx *m = const_cast<hj_ctx *>(c);
+    choose_bits(m);
+    memset(cfg, 0, sizeof *cfg);
+    cfg->bits1 = c->bits1; cfg->bits2 = c->bits2; cfg->force_bits = c->cfg.force_bits;
+    cfg->build_side = c->build == HJ_REL_R ? 1 : 2;
+    cfg->lds_capacity = c->cap; cfg->lds_heads = c->nh; cfg->probe_chunk = c->chunk;
+    return HJ_OK;
+}
+
+int hj_sync(hj_ctx *c) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, uint64_t n, int mode) {
+    RET(check_rel(c, rel));
+    if (n && !keys) return fail(c, HJ_EINVAL, "keys == NULL");
+    if (mode == HJ_PAYLOAD_GIVEN && n && !pays) return fail(c, HJ_EINVAL, "payload_mode GIVEN needs a payload column");
+    if (mode < HJ_PAYLOAD_ONES || mode > HJ_PAYLOAD_GIVEN) return fail(c, HJ_EINVAL, "bad payload_mode");
+    HIPCHK(c, hipSetDevice(c->device));
+    Rel &R = c->rel[rel];
+    RET(ensure(c, R.own_k, (size_t)(n + PAD) * 4));
+    RET(ensure(c, R.own_p, (size_t)(n + PAD) * 4));
+    if (n) HIPCHK(c, hipMemcpyAsync(R.own_k.p, keys, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (mode == HJ_PAYLOAD_GIVEN) {
+        if (n) HIPCHK(c, hipMemcpyAsync(R.own_p.p, pays, n * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, launch_fill(c->stream, (int32_t *)R.own_p.p, n, mode, 0));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.in_k = (const int32_t *)R.own_k.p;
+    R.in_p = (const int32_t *)R.own_p.p;
+    R.n = n;
+    R.bound = true;
+    invalidate(c);
+    return HJ_OK;
+}
+
+int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_pays, uint64_t n) {
+    RET(check_rel(c, rel));
+    if (n && (!d_keys || !d_pays)) return fail(c, HJ_EINVAL, "device columns == NULL");
+    if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
+    Rel &R = c->rel[rel];
+    R.in_k = d_keys; R.in_p = d_pays; R.n = n; R.bound = true;
+    invalidate(c);
+    return HJ_OK;
+}
+
+int hj_partition(hj_ctx *c, int rel) {
+    RET(check_rel(c, rel));
+    HIPCHK(c, hipSetDevice(c->device));
+    return partition_rel(c, rel);
+}
+
+int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    JoinArgs a;
+    bool tag16;
+    RET(run_count(c, a, tag16));
+    RET(fetch_scalars(c));
+    if (matches) *matches = c->h_scalars[1];
+    if (agg) *agg = c->h_scalars[2];
+    return HJ_OK;
+}
+
+int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+    if (!c) return HJ_EINVAL;
+    if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    JoinArgs a;
+    bool tag16;
+    RET(run_count(c, a, tag16));
+    a.wave_scanned = (const uint64_t *)c->wave_counts.p;
+    a.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
+    a.out_key = d_key;
+    a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
+    a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
+    a.out_cap = cap;
+    { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, true)); }
+    RET(fetch_scalars(c));
+    if (n_out) *n_out = c->h_scalars[1];
+    if (c->h_scalars[1] > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu",
+                                           (unsigned long long)c->h_scalars[1], (unsigned long long)cap);
+    return HJ_OK;
+}
+
+int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    RET(hj_partition(c, HJ_REL_R));
+    RET(hj_partition(c, HJ_REL_S));
+    return hj_join_count(c, matches, agg);
+}
+
+int hj_device_malloc(hj_ctx *c, void **d_ptr, uint64_t bytes) {
+    if (!c || !d_ptr) return HJ_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_ptr, bytes ? bytes : 256));
+    return HJ_OK;
+}
+
+int hj_device_free(hj_ctx *c, void *d_ptr) {
+    if (!c) return HJ_EINVAL;
+    if (d_ptr) HIPCHK(c, hipFree(d_ptr));
+    return HJ_OK;
+}
+
+int hj_memcpy_d2h(hj_ctx *c, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!c) return HJ_EINVAL;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_memcpy_h2d(hj_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!c) return HJ_EINVAL;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_get_partitions(hj_ctx *c, int rel, const int32_t **d_keys, const int32_t **d_pays, const uint64_t **d_offsets,
+                      uint64_t *nparts) {
+    RET(check_rel(c, rel));
+    Rel &R = c->rel[rel];
+    if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
+    if (d_keys) *d_keys = R.part_k;
+    if (d_pays) *d_pays = R.part_p;
+    if (d_offsets) *d_offsets = R.part_off;
+    if (nparts) *nparts = R.nparts;
+    return HJ_OK;
+}
+
+int hj_timings_reset(hj_ctx *c) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_stamps(c);
+    for (auto &k : c->kstats) { k.launches = 0; k.total_ms = 0; k.last_ms = 0; }
+    return HJ_OK;
+}
+
+int hj_timings(hj_ctx *c, hj_kernel_time *out, uint32_t cap, uint32_t *n) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_stamps(c);
+    uint32_t k = 0;
+    for (auto &s : c->kstats) {
+        if (out && k < cap) {
+            memset(&out[k], 0, sizeof out[k]);
+            strncpy(out[k].name, s.name.c_str(), sizeof(out[k].name) - 1);
+            out[k].launches = s.launches; out[k].total_ms = s.total_ms; out[k].last_ms = s.last_ms;
+        }
+        k++;
+    }
+    if (n) *n = k;
+    return HJ_OK;
+}
+
+int hj_shard_split(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint32_t nshards,
+                   int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts) {
+    if (!c) return HJ_EINVAL;
+    if (nshards == 0 || nshards > (uint32_t)MAX_PARTS) return fail(c, HJ_EINVAL, "nshards out of range");
+    if (n && (!d_keys || !d_pays || !d_out_keys || !d_out_pays)) return fail(c, HJ_EINVAL, "null column");
+    if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    Buf root, coff;
+    int rc = ensure(c, root, 16);
+    if (!rc) rc = ensure(c, coff, (size_t)(nshards + 1) * 8);
+    if (!rc) {
+        hipError_t e = launch_set_root(c->stream, (uint64_t *)root.p, n);
+        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "set_root: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = run_pass(c, 1, d_keys, d_pays, n, (const uint64_t *)root.p, 1, 0, nshards, nshards, d_out_keys, d_out_pays,
+                           (uint64_t *)coff.p);
+    std::vector<uint64_t> off(nshards + 1);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(off.data(), coff.p, (size_t)(nshards + 1) * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "shard offsets: %s", hipGetErrorString(e));
+    }
+    release(root);
+    release(coff);
+    if (rc) return rc;
+    if (h_counts) for (uint32_t i = 0; i < nshards; i++) h_counts[i] = off[i + 1] - off[i];
+    return HJ_OK;
+}
+
+uint32_t hj_shard_of(int32_t key, uint32_t nshards) { return host_shard_of(key, nshards); }
+
+int hj_gen_unique(hj_ctx *c, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed) {
+    if (!c) return HJ_EINVAL;
+    if (domain == 0 || domain > ((uint64_t)1 << 32)) return fail(c, HJ_EINVAL, "domain must be in [1, 2^32]");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_gen_unique(c->stream, d_keys, n, first, domain, seed));
+    return HJ_OK;
+}
+
+int hj_fill_payload(hj_ctx *c, int32_t *d_pays, uint64_t n, int mode, uint64_t first_rowid) {
+    if (!c) return HJ_EINVAL;
+    if (mode != HJ_PAYLOAD_ONES && mode != HJ_PAYLOAD_ROWID) return fail(c, HJ_EINVAL, "bad payload_mode");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_fill(c->stream, d_pays, n, mode, first_rowid));
+    return HJ_OK;
+}
+
+static int digest_common(hj_ctx *c, const int32_t *a, const int32_t *b, const int32_t *d, uint64_t n, uint64_t *out) {
+    if (!c || !out) return HJ_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    HIPCHK(c, hipMemsetAsync(sc + 3, 0, 8, c->stream));
+    HIPCHK(c, launch_digest(c->stream, a, b, d, n, sc + 3));
+    RET(fetch_scalars(c));
+    *out = c->h_scalars[3];
+    return HJ_OK;
+}
+
+int hj_digest_pairs(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint64_t *digest) {
+    return digest_common(c, d_keys, d_pays, nullptr, n, digest);
+}
+
+int hj_digest_triples(hj_ctx *c, const int32_t *d_key, const int32_t *d_payR, const int32_t *d_payS, uint64_t n,
+                      uint64_t *digest) {
+    return digest_common(c, d_key, d_payR, d_payS, n, digest);
+}
+
+int hj_verify_partitions(hj_ctx *c, int rel, uint64_t *misplaced, uint64_t *d_digests) {
+    RET(check_rel(c, rel));
+    Rel &R = c->rel[rel];
+    if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    HIPCHK(c, hipMemsetAsync(sc + 4, 0, 8, c->stream));
+    HIPCHK(c, launch_verify_partitions(c->stream, R.part_k, R.part_p, R.part_off, R.nparts, sc + 4, d_digests));
+    RET(fetch_scalars(c));
+    if (misplaced) *misplaced = c->h_scalars[4];
+    return HJ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+// hj_internal.h — shared between the kernels (hj_kernels.hip) and the host side (hj_api.hip).
+#ifndef HJ_INTERNAL_H_
+#define HJ_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hj {
+
+// partition kernels: 512-thread workgroups (8 wave64), 4 x 16-byte loads per thread per tile
+constexpr int PART_THREADS = 512;
+constexpr int TILE_U = 4;
+constexpr int TILE = PART_THREADS * 4 * TILE_U; // 8192 tuples: 32 KiB LDS reorder buffer
+constexpr int MAX_PARTS = 512;                  // fan-out limit of one pass (9 bits)
+constexpr int MAX_PARENTS = 1024;               // k_plan is a single workgroup
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER = 16;
+constexpr int SCAN_CHUNK_LOG = 12;
+constexpr int SCAN_CHUNK = 1 << SCAN_CHUNK_LOG; // = SCAN_THREADS * SCAN_PER
+
+constexpr int JOIN_THREADS = 512;
+constexpr int JOIN_WAVES = JOIN_THREADS / 64;
+
+struct PassArgs {
+    const int32_t *keys, *pays; // input columns
+    uint64_t nalloc;            // true length of the input arrays
+    const uint64_t *poff;       // parent offsets [nparents+1]
+    uint32_t nparents;
+    uint32_t *span_start;       // [nparents+1]
+    uint32_t span;              // tuples per span
+    uint32_t max_spans;         // launch bound
+    uint32_t shift, P, mask_or_n;
+    uint32_t *hist;             // [max_spans * P]
+    uint64_t *chunk_sums, *chunk_prefix;
+    int32_t *out_keys, *out_pays;
+};
+
+struct JoinArgs {
+    const int32_t *bk, *bp;  // build side, partitioned
+    const uint64_t *boff;
+    uint64_t b_nalloc;
+    const int32_t *pk, *pp;  // probe side, partitioned
+    const uint64_t *poff;
+    uint64_t p_nalloc;
+    const uint2 *items;      // (partition, probe chunk)
+    const uint64_t *n_items;
+    uint32_t radix_bits, cap, nh, chunk;
+    uint64_t *wave_counts, *wave_agg;                     // count kernel outputs [items * JOIN_WAVES]
+    const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
+    int32_t *out_key, *out_bpay, *out_ppay;
+    uint64_t out_cap;
+};
+
+hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n);
+hipError_t launch_plan(hipStream_t st, const uint64_t *poff, uint32_t nparents, uint32_t span, uint32_t *span_start);
+hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa);
+hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
+hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
+hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
+hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
+hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
+                            uint32_t *items_cnt);
+hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
+                              const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items);
+size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
+hipError_t join_set_lds_limit(size_t bytes);
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, bool mat);
+hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out);
+hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first);
+hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
+hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, const int32_t *c, uint64_t n, uint64_t *out);
+hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *off,
+                                    uint32_t nparts, uint64_t *misplaced, uint64_t *digests);
+uint32_t host_shard_of(int32_t key, uint32_t nshards);
+
+} // namespace hj
+#endif

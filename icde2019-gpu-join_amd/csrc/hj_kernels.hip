@@ -1,0 +1,732 @@
+// hj_kernels.hip — gfx950 (MI355X, CDNA4) device code of the radix-partitioned hash join.
+//
+// What the reference does on this path (all GPU kernels live in src/join-primitives.cu):
+//   partition_pass_one/two   jp.cu:58-283, 338-535   fused histogram + slot reservation + LDS tile
+//                                                    reorder + key/payload scatter into chained
+//                                                    4096-tuple buckets (atomic bump allocation)
+//   compute_bucket_info      jp.cu:294-312           chain walk between the passes
+//   decompose_chains         jp.cu:843-874           probe-side work decomposition (<= 8192 tuples)
+//   join_partitioned_aggregate / _results  jp.cu:885-1095, 1107-1416   LDS chained hash build+probe
+//
+// What this file does instead (MI355X-first):
+//   * partitions are CONTIGUOUS (64-bit offsets), not bucket chains: a keys-only histogram kernel,
+//     a device-side scan, and a scatter kernel whose workgroups own long contiguous spans, so each
+//     (span, digit) output run is a private, contiguous HBM region that the workgroup fills tile by
+//     tile through an LDS reorder buffer (wave64, 512-thread workgroups, 8192-tuple tiles).
+//     Nothing is read back to the host between kernels; grids are launched at their upper bound.
+//   * the join kernel builds a chained hash table in LDS per build partition (16-bit tags when the
+//     radix bits leave <= 16 key bits, full keys otherwise) and probes it with coalesced 16-byte
+//     loads; work items split the probe side (<= probe_chunk tuples); counts are kept per wave so
+//     that the materialising kernel writes (key,payR,payS) at exact, contention-free positions
+//     (no global output cursor, no FOLD ring: jp.cu:1097-1101 D6).
+//   All arithmetic is integer; there is no MFMA-shaped work on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hj_internal.h"
+
+namespace hj {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint64_t fmix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t mix_pair(int32_t key, int32_t pay) {
+    return fmix64(((uint64_t)(uint32_t)key << 32) | (uint32_t)pay);
+}
+__device__ __forceinline__ uint64_t mix_triple(int32_t key, int32_t pr, int32_t ps) {
+    return fmix64(mix_pair(key, pr) ^ ((uint64_t)(uint32_t)ps * 0x9E3779B97F4A7C15ULL));
+}
+
+// Partition function.  MODE 0: the reference's (hasht(key) >> first_bit) & (parts-1) with hasht =
+// identity (common.h:45-47, jp.cu:126).  MODE 1: shard id for the multi-GPU level-0 split, a
+// multiplicative range reduction of a murmur-finalised key (independent of the low radix bits).
+template <int MODE>
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t shift, uint32_t mask_or_n) {
+    if (MODE == 0) return (key >> shift) & mask_or_n;
+    return (uint32_t)(((uint64_t)fmix32(key) * mask_or_n) >> 32);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if ((int)lane_id() >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = __shfl_up(v, o, 64);
+        if ((int)lane_id() >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Exclusive scan of one value per thread over the workgroup (blockDim.x multiple of 64, <= 1024).
+// scratch: >= 17 T's of LDS.  Returns the exclusive prefix; *total = sum over the workgroup.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *scratch, T *total) {
+    const uint32_t w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    T incl = (sizeof(T) == 8) ? (T)wave_incl_scan64((uint64_t)v) : (T)wave_incl_scan((uint32_t)v);
+    if (lane_id() == 63) scratch[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+        for (uint32_t i = 0; i < nw; i++) { T t = scratch[i]; scratch[i] = run; run += t; }
+        scratch[16] = run;
+    }
+    __syncthreads();
+    T res = incl - v + scratch[w];
+    if (total) *total = scratch[16];
+    __syncthreads();
+    return res;
+}
+
+// 16-byte load of 4 consecutive int32 at element index i (i % 4 == 0, base 16-B aligned); elements
+// at or beyond nalloc (the true length of the array) are not touched.
+__device__ __forceinline__ int4 load4(const int32_t *__restrict__ base, uint64_t i, uint64_t nalloc) {
+    if (i + 4 <= nalloc) return *reinterpret_cast<const int4 *>(base + i);
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < nalloc) v.x = base[i];
+    if (i + 1 < nalloc) v.y = base[i + 1];
+    if (i + 2 < nalloc) v.z = base[i + 2];
+    return v;
+}
+__device__ __forceinline__ int32_t elem(const int4 &v, int e) {
+    return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// partition pass: plan → histogram → scan → offsets → scatter
+// ------------------------------------------------------------------------------------------------
+
+// One thread per parent partition: number of spans (<= span tuples each) it is cut into, and the
+// exclusive prefix of that.  span_start has nparents+1 entries.  Single workgroup, nparents <= 1024.
+__global__ __launch_bounds__(1024) void k_plan(const uint64_t *__restrict__ poff, uint32_t nparents,
+                                               uint32_t span, uint32_t *__restrict__ span_start) {
+    __shared__ uint32_t scratch[17];
+    uint32_t c = 0;
+    if (threadIdx.x < nparents) {
+        uint64_t cnt = poff[threadIdx.x + 1] - poff[threadIdx.x];
+        c = (uint32_t)((cnt + span - 1) / span);
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &total);
+    if (threadIdx.x < nparents) span_start[threadIdx.x] = ex;
+    if (threadIdx.x == 0) span_start[nparents] = total;
+}
+
+struct SpanInfo {
+    uint32_t parent, s, nsp, first; // parent id, span index inside it, spans of the parent, span_start[parent]
+    uint64_t lo, hi;                // tuple range of this span
+};
+
+// Decode blockIdx.x into a span.  Every thread runs the same search (wave-uniform scalar loads).
+__device__ __forceinline__ bool decode_span(const uint64_t *__restrict__ poff, uint32_t nparents,
+                                            const uint32_t *__restrict__ span_start, uint32_t span,
+                                            SpanInfo &si) {
+    const uint32_t b = blockIdx.x;
+    if (b >= span_start[nparents]) return false;
+    uint32_t lo = 0, hi = nparents;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (span_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    // parents with zero spans share span_start with their successor: take the last one <= b
+    si.parent = lo;
+    si.first = span_start[lo];
+    si.nsp = span_start[lo + 1] - si.first;
+    si.s = b - si.first;
+    uint64_t p0 = poff[lo], p1 = poff[lo + 1];
+    si.lo = p0 + (uint64_t)si.s * span;
+    si.hi = si.lo + span < p1 ? si.lo + span : p1;
+    return true;
+}
+
+// Histogram of one span: hist[(first*P) + d*nsp + s].  4 B/tuple read, nothing else.
+template <int MODE>
+__global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict__ keys, uint64_t nalloc,
+                                                       const uint64_t *__restrict__ poff, uint32_t nparents,
+                                                       const uint32_t *__restrict__ span_start, uint32_t span,
+                                                       uint32_t shift, uint32_t P, uint32_t mask_or_n,
+                                                       uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[MAX_PARTS];
+    SpanInfo si;
+    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    for (uint32_t d = threadIdx.x; d < P; d += PART_THREADS) h[d] = 0;
+    __syncthreads();
+    const uint64_t a0 = si.lo & ~(uint64_t)3;
+    for (uint64_t i = a0 + (uint64_t)threadIdx.x * 4; i < si.hi; i += (uint64_t)PART_THREADS * 4) {
+        int4 v = load4(keys, i, nalloc);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint64_t idx = i + e;
+            if (idx >= si.lo && idx < si.hi) atomicAdd(&h[digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < P; d += PART_THREADS)
+        hist[(uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s] = h[d];
+}
+
+// ---- scan over a device-sized array: data[i] becomes the exclusive prefix inside its 4096-entry
+// chunk, chunk_sums[c] the chunk total; k_scan_top turns the sums into exclusive chunk prefixes.
+// The value of entry i is then data[i] + chunk_prefix[i >> 12].  L = (*len_ptr) * mul, or mul. ----
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ data, const uint32_t *__restrict__ len_ptr,
+                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums) {
+    __shared__ T scratch[17];
+    const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
+    const uint64_t start = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    if (start >= L) return;
+    const uint64_t i0 = start + (uint64_t)threadIdx.x * SCAN_PER;
+    T v[SCAN_PER];
+    T sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) {
+        v[j] = (i0 + j < L) ? data[i0 + j] : (T)0;
+        sum += v[j];
+    }
+    T total;
+    T ex = block_excl_scan<T>(sum, scratch, &total);
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) {
+        if (i0 + j < L) data[i0 + j] = ex;
+        ex += v[j];
+    }
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = (uint64_t)total;
+}
+
+// Single workgroup: exclusive scan of the chunk sums; chunk_prefix[nchunks] and *total_out = total.
+__global__ __launch_bounds__(1024) void k_scan_top(const uint64_t *__restrict__ chunk_sums, const uint32_t *__restrict__ len_ptr,
+                                                   uint64_t mul, uint64_t *__restrict__ chunk_prefix,
+                                                   uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t scratch[17];
+    const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
+    const uint64_t nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nchunks; base += 1024) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < nchunks ? chunk_sums[i] : 0;
+        uint64_t total;
+        uint64_t ex = block_excl_scan<uint64_t>(v, scratch, &total);
+        if (i < nchunks) chunk_prefix[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        chunk_prefix[nchunks] = carry;
+        if (total_out) *total_out = carry;
+    }
+}
+
+// Child partition offsets: coff[parent*P + d] = output position of (parent, d, span 0); coff[last] = n.
+__global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__restrict__ chunk_prefix,
+                          const uint32_t *__restrict__ span_start, uint32_t nparents, uint32_t P,
+                          uint64_t n, uint64_t *__restrict__ coff) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nchild = (uint64_t)nparents * P;
+    if (t > nchild) return;
+    if (t == nchild) { coff[t] = n; return; }
+    const uint32_t parent = (uint32_t)(t / P), d = (uint32_t)(t % P);
+    const uint64_t total = (uint64_t)span_start[nparents] * P;
+    const uint32_t first = span_start[parent], nsp = span_start[parent + 1] - first;
+    const uint64_t idx = (uint64_t)first * P + (uint64_t)d * nsp;
+    coff[t] = idx < total ? (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG] : n;
+}
+
+// Scatter one span.  Per 8192-tuple tile: LDS histogram with ranks (one returning LDS atomic per
+// tuple), workgroup scan, reorder keys through a 32 KiB LDS buffer so that each digit's tuples are
+// consecutive, then consecutive lanes store consecutive positions of the span's private output run
+// of that digit; payloads reuse the same LDS slots (the two-phase idea of jp.cu:203-278, with
+// contiguous per-span output regions instead of bucket chains, so consecutive tiles extend the same
+// cache lines from the same CU).  Algorithmic traffic: 8 B read + 8 B written per tuple.
+template <int MODE>
+__global__ __launch_bounds__(PART_THREADS) void k_scatter(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                          uint64_t nalloc, const uint64_t *__restrict__ poff,
+                                                          uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                          uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
+                                                          const uint32_t *__restrict__ hist,
+                                                          const uint64_t *__restrict__ chunk_prefix,
+                                                          int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+    __shared__ int32_t buf[TILE];
+    __shared__ uint32_t h[MAX_PARTS];      // per-tile count of each digit
+    __shared__ uint32_t start[MAX_PARTS];  // per-tile exclusive prefix
+    __shared__ uint32_t gbase[MAX_PARTS];  // next output position of each digit for this span (n < 2^32 per pass)
+    __shared__ uint32_t scratch[17];
+    SpanInfo si;
+    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t d = tid; d < P; d += PART_THREADS) {
+        uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
+        gbase[d] = (uint32_t)((uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG]);
+        h[d] = 0;
+    }
+    __syncthreads();
+    const uint64_t a0 = si.lo & ~(uint64_t)3;
+    for (uint64_t t0 = a0; t0 < si.hi; t0 += TILE) {
+        // ---- A: load keys, rank inside digit ----
+        int4 kv[TILE_U];
+        uint32_t dr[TILE_U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
+#pragma unroll
+        for (int u = 0; u < TILE_U; u++) {
+            uint64_t i = t0 + ((uint64_t)u * PART_THREADS + tid) * 4;
+            kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint64_t idx = i + e;
+                uint32_t code = 0xFFFFFFFFu;
+                if (idx >= si.lo && idx < si.hi) {
+                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
+                    code = (d << 16) | atomicAdd(&h[d], 1u);
+                }
+                dr[u * 4 + e] = code;
+            }
+        }
+        __syncthreads();
+        // ---- B: exclusive scan of the tile histogram (P <= 512 = one value per thread) ----
+        uint32_t cnt = tid < P ? h[tid] : 0;
+        uint32_t tile_cnt;
+        uint32_t ex = block_excl_scan<uint32_t>(cnt, scratch, &tile_cnt);
+        if (tid < P) start[tid] = ex;
+        __syncthreads();
+        // ---- C: keys into digit order ----
+#pragma unroll
+        for (int u = 0; u < TILE_U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t code = dr[u * 4 + e];
+                if (code != 0xFFFFFFFFu) buf[start[code >> 16] + (code & 0xFFFFu)] = elem(kv[u], e);
+            }
+        __syncthreads();
+        // ---- D: keys out; remember each slot's destination for the payload ----
+        uint32_t dst[TILE_U * 4];
+#pragma unroll
+        for (int j = 0; j < TILE_U * 4; j++) {
+            uint32_t i = j * PART_THREADS + tid;
+            dst[j] = 0;
+            if (i < tile_cnt) {
+                int32_t key = buf[i];
+                uint32_t d = digit_of<MODE>((uint32_t)key, shift, mask_or_n);
+                dst[j] = gbase[d] + (i - start[d]);
+                out_keys[dst[j]] = key;
+            }
+        }
+        __syncthreads();
+        // ---- E: payloads through the same slots ----
+#pragma unroll
+        for (int u = 0; u < TILE_U; u++) {
+            uint64_t i = t0 + ((uint64_t)u * PART_THREADS + tid) * 4;
+            int4 pv = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t code = dr[u * 4 + e];
+                if (code != 0xFFFFFFFFu) buf[start[code >> 16] + (code & 0xFFFFu)] = elem(pv, e);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TILE_U * 4; j++) {
+            uint32_t i = j * PART_THREADS + tid;
+            if (i < tile_cnt) out_pays[dst[j]] = buf[i];
+        }
+        __syncthreads();
+        // ---- F: advance the span's output cursors ----
+        if (tid < P) { gbase[tid] += h[tid]; h[tid] = 0; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// join: plan → (count) → scan → (materialise)
+// ------------------------------------------------------------------------------------------------
+
+// items per partition: probe partition cut into chunks of <= chunk tuples (decompose_chains,
+// jp.cu:843-874, threshold = 2*bucket_size at hjcp.cu:904); no item when either side is empty.
+__global__ void k_join_plan(const uint64_t *__restrict__ boff, const uint64_t *__restrict__ poff,
+                            uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparts) return;
+    uint64_t nb = boff[p + 1] - boff[p], np = poff[p + 1] - poff[p];
+    items_cnt[p] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
+}
+
+// items_cnt has been scanned (local + chunk prefix): write the item list and the item count.
+__global__ void k_join_expand(const uint64_t *__restrict__ boff, const uint64_t *__restrict__ poff,
+                              uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
+                              const uint64_t *__restrict__ chunk_prefix, uint2 *__restrict__ items) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparts) return;
+    uint64_t nb = boff[p + 1] - boff[p], np = poff[p + 1] - poff[p];
+    uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
+    uint64_t at = (uint64_t)items_scanned[p] + chunk_prefix[p >> SCAN_CHUNK_LOG];
+    for (uint32_t j = 0; j < c; j++) items[at + j] = make_uint2(p, j);
+}
+
+// LDS layout (dynamic): head[nh] u32 | pay[cap] i32 | key[cap] (u16 tag or u32 key) | next[cap] u16
+// The reference's table: elem int16 tag, payload int32, next int16, head int32[1024] (jp.cu:899-902).
+template <bool TAG16, bool MAT>
+__global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t item = blockIdx.x;
+    if (item >= *a.n_items) return;
+    uint32_t *head = reinterpret_cast<uint32_t *>(smem);
+    int32_t *lpay = reinterpret_cast<int32_t *>(smem + (size_t)a.nh * 4);
+    unsigned char *kbase = smem + (size_t)a.nh * 4 + (size_t)a.cap * 4;
+    uint16_t *ltag = reinterpret_cast<uint16_t *>(kbase);
+    uint32_t *lkey = reinterpret_cast<uint32_t *>(kbase);
+    uint16_t *lnext = reinterpret_cast<uint16_t *>(kbase + (size_t)a.cap * (TAG16 ? 2 : 4));
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint2 it = a.items[item];
+    const uint32_t p = it.x;
+    const uint64_t b0 = a.boff[p], nb = a.boff[p + 1] - b0;
+    const uint64_t q0 = a.poff[p] + (uint64_t)it.y * a.chunk;
+    const uint64_t pend = a.poff[p + 1];
+    const uint64_t q1 = q0 + a.chunk < pend ? q0 + a.chunk : pend;
+    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+
+    uint64_t my_matches = 0, my_agg = 0;
+    uint64_t cur = 0; // MAT: next output slot of this wave
+    if (MAT) {
+        uint64_t idx = (uint64_t)item * JOIN_WAVES + wave;
+        cur = a.wave_scanned[idx] + a.wave_chunk_prefix[idx >> SCAN_CHUNK_LOG];
+    }
+    const uint64_t lt_mask = ((uint64_t)1 << lane_id()) - 1;
+
+    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
+        const uint64_t gb = b0 + bc;
+        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+        for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        // ---- build: tuple j of the chunk lives in slot j; LIFO chain insert by atomic exchange on
+        // the bucket head (jp.cu:1021-1048) ----
+        for (uint64_t i = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i < gb + nbc; i += (uint64_t)JOIN_THREADS * 4) {
+            int4 kv = load4(a.bk, i, a.b_nalloc), pv = load4(a.bp, i, a.b_nalloc);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint64_t idx = i + e;
+                if (idx >= gb && idx < gb + nbc) {
+                    uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(kv, e);
+                    if (TAG16) ltag[slot] = (uint16_t)(key >> bits); else lkey[slot] = key;
+                    lpay[slot] = elem(pv, e);
+                    uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                    lnext[slot] = (uint16_t)old;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- probe ----
+        // the loop bound is wave-uniform (w0), so every lane of a wave stays in the loop together:
+        // the ballot ranks and the wave's output cursor depend on it
+        for (uint64_t w0 = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256; w0 < q1; w0 += (uint64_t)JOIN_THREADS * 4) {
+            const uint64_t i = w0 + (uint64_t)lane_id() * 4;
+            int4 kv = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
+            if (i < q1) { kv = load4(a.pk, i, a.p_nalloc); pv = load4(a.pp, i, a.p_nalloc); }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint64_t idx = i + e;
+                const bool valid = idx >= q0 && idx < q1;
+                const uint32_t key = (uint32_t)elem(kv, e);
+                const int32_t ppay = elem(pv, e);
+                uint32_t pos = valid ? head[(key >> bits) & nhm] : 0xFFFFFFFFu;
+                pos &= 0xFFFFu; // chain links are 16 bit; 0xFFFF = end
+                if (!MAT) {
+                    while (pos != 0xFFFFu) {
+                        bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                        if (eq) {
+                            my_matches++;
+                            my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)ppay);
+                        }
+                        pos = lnext[pos];
+                    }
+                } else {
+                    // every step of the wave: each lane advances to its next matching entry, the
+                    // matching lanes are ranked by a 64-bit ballot and write one coalesced run
+                    for (;;) {
+                        while (pos != 0xFFFFu) {
+                            bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                            if (eq) break;
+                            pos = lnext[pos];
+                        }
+                        const bool m = pos != 0xFFFFu;
+                        const uint64_t mask = __ballot(m);
+                        if (!mask) break;
+                        if (m) {
+                            uint64_t o = cur + __popcll(mask & lt_mask);
+                            if (o < a.out_cap) {
+                                a.out_key[o] = (int32_t)key;
+                                a.out_bpay[o] = lpay[pos];
+                                a.out_ppay[o] = ppay;
+                            }
+                            pos = lnext[pos];
+                        }
+                        cur += __popcll(mask);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!MAT) {
+        my_matches = wave_sum64(my_matches);
+        my_agg = wave_sum64(my_agg);
+        if (lane_id() == 0) {
+            a.wave_counts[(uint64_t)item * JOIN_WAVES + wave] = my_matches;
+            a.wave_agg[(uint64_t)item * JOIN_WAVES + wave] = my_agg;
+        }
+    }
+}
+
+// sum of a device-sized uint64 array (per-wave aggregates) into *out (zeroed by the caller)
+__global__ __launch_bounds__(256) void k_reduce64(const uint64_t *__restrict__ data, const uint32_t *__restrict__ len_ptr,
+                                                  uint64_t mul, unsigned long long *__restrict__ out) {
+    const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
+    uint64_t s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (uint64_t)gridDim.x * blockDim.x) s += data[i];
+    s = wave_sum64(s);
+    if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// utilities: payload fill (init_payload jp.cu:30-33), input synthesis, digests, partition check
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill(int32_t *__restrict__ p, uint64_t n, int mode, uint64_t first) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = mode == 1 ? (int32_t)(uint32_t)(first + i) : 1;
+}
+
+__global__ void k_set_root(uint64_t *poff, uint64_t n) { poff[0] = 0; poff[1] = n; }
+
+// bijection on [0, 2^k): odd multiply, xorshift, add — four rounds keyed by the seed; cycle-walked
+// down to [0, domain).
+__device__ __forceinline__ uint64_t perm_round(uint64_t x, uint64_t mask, uint32_t k, uint64_t m, uint64_t c) {
+    x = (x * (m | 1)) & mask;
+    x ^= x >> ((k >> 1) + 1);
+    x = (x + c) & mask;
+    return x;
+}
+__global__ void k_gen_unique(int32_t *__restrict__ keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed) {
+    uint32_t k = 1;
+    while (((uint64_t)1 << k) < domain) k++;
+    const uint64_t mask = (((uint64_t)1 << k) - 1);
+    const uint64_t s0 = fmix64(seed ^ 0x1234567ULL), s1 = fmix64(s0 + 1), s2 = fmix64(s1 + 2), s3 = fmix64(s2 + 3);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (first + i) % domain;
+        do {
+            x = perm_round(x, mask, k, s0, s1 >> 7);
+            x = perm_round(x, mask, k, s1, s2 >> 9);
+            x = perm_round(x, mask, k, s2, s3 >> 11);
+            x = perm_round(x, mask, k, s3, s0 >> 13);
+        } while (x >= domain);
+        keys[i] = (int32_t)(uint32_t)x;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_digest(const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+                                                const int32_t *__restrict__ c, uint64_t n,
+                                                unsigned long long *__restrict__ out) {
+    uint64_t s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        s += c ? mix_triple(a[i], b[i], c[i]) : mix_pair(a[i], b[i]);
+    s = wave_sum64(s);
+    if (lane_id() == 0) atomicAdd(out, (unsigned long long)s);
+}
+
+// one workgroup per partition: tuples whose low radix bits differ from the partition id, and the
+// partition's (key,pay) digest
+__global__ __launch_bounds__(256) void k_verify_partitions(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                           const uint64_t *__restrict__ off, uint32_t nparts,
+                                                           unsigned long long *__restrict__ misplaced,
+                                                           uint64_t *__restrict__ digests) {
+    __shared__ uint64_t red[4];
+    for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        uint64_t bad = 0, dg = 0;
+        for (uint64_t i = off[p] + threadIdx.x; i < off[p + 1]; i += blockDim.x) {
+            if ((((uint32_t)keys[i]) & (nparts - 1)) != p) bad++;
+            dg += mix_pair(keys[i], pays[i]);
+        }
+        bad = wave_sum64(bad);
+        dg = wave_sum64(dg);
+        if (lane_id() == 0 && bad) atomicAdd(misplaced, (unsigned long long)bad);
+        if (digests) {
+            if (lane_id() == 0) red[threadIdx.x >> 6] = dg;
+            __syncthreads();
+            if (threadIdx.x == 0) digests[p] = red[0] + red[1] + red[2] + red[3];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (host)
+// ------------------------------------------------------------------------------------------------
+#define HJ_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n) {
+    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, st, poff, n);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_plan(hipStream_t st, const uint64_t *poff, uint32_t nparents, uint32_t span, uint32_t *span_start) {
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, poff, nparents, span, span_start);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa) {
+    dim3 g(pa.max_spans), b(PART_THREADS);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+    else
+        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
+    uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if (nchunks == 0) nchunks = 1;
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    HJ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
+    uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if (nchunks == 0) nchunks = 1;
+    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    HJ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff) {
+    uint64_t nthreads = (uint64_t)pa.nparents * pa.P + 1;
+    hipLaunchKernelGGL(k_offsets, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, st, pa.hist, pa.chunk_prefix,
+                       pa.span_start, pa.nparents, pa.P, n, coff);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
+    dim3 g(pa.max_spans), b(PART_THREADS);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_scatter<0>, g, b, 0, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span,
+                           pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    else
+        hipLaunchKernelGGL(k_scatter<1>, g, b, 0, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span,
+                           pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
+                            uint32_t *items_cnt) {
+    hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, boff, poff, nparts, chunk, items_cnt);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
+                              const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items) {
+    hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, boff, poff, nparts, chunk, items_scanned,
+                       chunk_prefix, items);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16) {
+    size_t b = (size_t)nh * 4 + (size_t)cap * 4 + (size_t)cap * (tag16 ? 2 : 4) + (size_t)cap * 2;
+    return (b + 15) & ~(size_t)15;
+}
+
+hipError_t join_set_lds_limit(size_t bytes) {
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, bool mat) {
+    size_t lds = join_lds_bytes(a.nh, a.cap, tag16);
+    dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
+    if (tag16 && !mat) hipLaunchKernelGGL((k_join<true, false>), g, b, lds, st, a);
+    else if (tag16 && mat) hipLaunchKernelGGL((k_join<true, true>), g, b, lds, st, a);
+    else if (!tag16 && !mat) hipLaunchKernelGGL((k_join<false, false>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_join<false, true>), g, b, lds, st, a);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out) {
+    hipLaunchKernelGGL(k_reduce64, dim3(512), dim3(256), 0, st, data, len_ptr, mul, reinterpret_cast<unsigned long long *>(out));
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fill, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, p, n, mode, first);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_gen_unique, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, keys, n, first, domain, seed);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, const int32_t *c, uint64_t n, uint64_t *out) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_digest, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, a, b, c, n,
+                       reinterpret_cast<unsigned long long *>(out));
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *off,
+                                    uint32_t nparts, uint64_t *misplaced, uint64_t *digests) {
+    hipLaunchKernelGGL(k_verify_partitions, dim3(nparts < 4096 ? nparts : 4096), dim3(256), 0, st, keys, pays, off, nparts,
+                       reinterpret_cast<unsigned long long *>(misplaced), digests);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+uint32_t host_shard_of(int32_t key, uint32_t nshards) {
+    uint32_t h = (uint32_t)key;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return (uint32_t)(((uint64_t)h * nshards) >> 32);
+}
+
+} // namespace hj

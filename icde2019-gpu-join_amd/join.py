@@ -1,0 +1,248 @@
+"""Host-side mirror of the reference's join interface on top of the C ABI (include/hj.h).
+
+    HashJoin            one context per GPU; the steps of outOfGPU_Join1_payload
+                        (src/hash_join_clustered_probe.cu:802-994) as methods
+    hashJoinClusteredProbe(R, S)   the reference entry point itself (hjcp.cu:2062-2073), called
+                        through the same `args` block main.cu fills (src/common-host.h:39-52)
+
+numpy arrays are host columns; anything with .data_ptr() (torch tensors) is taken as an HBM-resident
+column.  There is no CPU fallback: without libhj.so + a GPU every call raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+REL_R, REL_S = 0, 1
+PAYLOAD_ONES, PAYLOAD_ROWID, PAYLOAD_GIVEN = 0, 1, 2
+_PAYLOAD = {"ones": PAYLOAD_ONES, "rowid": PAYLOAD_ROWID, "given": PAYLOAD_GIVEN}
+
+
+class HJError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libhj error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _dev_ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    raise TypeError("expected a device tensor or a raw device pointer, got %r" % type(x))
+
+
+def _host_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class HashJoin:
+    """One join context on one GPU (src/main.cu:93: one device per process)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.hj_create(C.byref(h), device)
+        if rc:
+            raise HJError(rc, "hj_create(device=%d) failed: no usable GPU (the HIP path has no CPU fallback)" % device)
+        self._h = h
+        self._keep = {}
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise HJError(rc, (self._L.hj_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hj_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        self._ck(self._L.hj_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def configure(self, bits1=0, bits2=0, force_bits=False, build_side=0, lds_capacity=0, lds_heads=0,
+                  probe_chunk=0):
+        cfg = _lib.Config(bits1=bits1, bits2=bits2, force_bits=int(force_bits), build_side=build_side,
+                          lds_capacity=lds_capacity, lds_heads=lds_heads, probe_chunk=probe_chunk)
+        self._ck(self._L.hj_configure(self._h, C.byref(cfg)))
+
+    def config(self):
+        cfg = _lib.Config()
+        self._ck(self._L.hj_get_config(self._h, C.byref(cfg)))
+        return {k: getattr(cfg, k) for k, _ in _lib.Config._fields_ if k != "reserved"}
+
+    def sync(self):
+        self._ck(self._L.hj_sync(self._h))
+
+    # -- relations --------------------------------------------------------------------------------
+    def load_host(self, rel, keys, pays=None, payload="ones"):
+        keys, kp = _host_i32(keys)
+        mode = _PAYLOAD[payload] if pays is None else PAYLOAD_GIVEN
+        pp = None
+        if pays is not None:
+            pays, pp = _host_i32(pays)
+            assert len(pays) == len(keys)
+        self._ck(self._L.hj_load_host(self._h, rel, kp, pp, len(keys), mode))
+
+    def bind_device(self, rel, keys, pays, n=None):
+        n = int(keys.numel()) if n is None else n
+        self._keep[rel] = (keys, pays)  # keep the caller's tensors alive while bound
+        self._ck(self._L.hj_bind_device(self._h, rel, _dev_ptr(keys), _dev_ptr(pays), n))
+
+    # -- the path ---------------------------------------------------------------------------------
+    def partition(self, rel):
+        self._ck(self._L.hj_partition(self._h, rel))
+
+    def join_count(self):
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_count(self._h, C.byref(m), C.byref(a)))
+        return m.value, a.value
+
+    def join(self):
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join(self._h, C.byref(m), C.byref(a)))
+        return m.value, a.value
+
+    def join_materialize_into(self, d_key, d_payR, d_payS, cap):
+        n = C.c_uint64()
+        self._ck(self._L.hj_join_materialize(self._h, _dev_ptr(d_key), _dev_ptr(d_payR), _dev_ptr(d_payS), cap,
+                                             C.byref(n)))
+        return n.value
+
+    def join_materialize(self, cap=None):
+        """Returns host numpy columns (key, payR, payS); sizes the output with a count run if cap is None."""
+        if cap is None:
+            cap = self.join_count()[0]
+        bufs = [self.device_malloc(max(cap, 1) * 4) for _ in range(3)]
+        try:
+            n = self.join_materialize_into(bufs[0], bufs[1], bufs[2], cap)
+            return tuple(self.to_host(b, n, np.int32) for b in bufs)
+        finally:
+            for b in bufs:
+                self.device_free(b)
+
+    # -- memory helpers ---------------------------------------------------------------------------
+    def device_malloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(self._L.hj_device_malloc(self._h, C.byref(p), nbytes))
+        return p.value
+
+    def device_free(self, ptr):
+        self._ck(self._L.hj_device_free(self._h, C.c_void_p(ptr)))
+
+    def to_host(self, dptr, count, dtype):
+        out = np.empty(count, dtype=dtype)
+        p = dptr.value if isinstance(dptr, C.c_void_p) else (dptr.data_ptr() if hasattr(dptr, "data_ptr") else dptr)
+        self._ck(self._L.hj_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes))
+        return out
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.device_malloc(max(arr.nbytes, 16))
+        self._ck(self._L.hj_memcpy_h2d(self._h, C.c_void_p(p), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return p
+
+    # -- introspection ----------------------------------------------------------------------------
+    def partition_pointers(self, rel):
+        k, p, o, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._ck(self._L.hj_get_partitions(self._h, rel, C.byref(k), C.byref(p), C.byref(o), C.byref(n)))
+        return k.value, p.value, o.value, n.value
+
+    def partitions(self, rel, n):
+        """Host copies (keys, pays, offsets) of the partitioned relation of n tuples."""
+        k, p, o, nparts = self.partition_pointers(rel)
+        off = self.to_host(o, nparts + 1, np.uint64)
+        return self.to_host(k, n, np.int32), self.to_host(p, n, np.int32), off
+
+    def verify_partitions(self, rel, with_digests=False):
+        bad = C.c_uint64()
+        dg = None
+        _, _, _, nparts = self.partition_pointers(rel)
+        if with_digests:
+            dg = self.device_malloc(nparts * 8)
+        try:
+            self._ck(self._L.hj_verify_partitions(self._h, rel, C.byref(bad), C.c_void_p(dg) if dg else None))
+            digests = self.to_host(dg, nparts, np.uint64) if dg else None
+        finally:
+            if dg:
+                self.device_free(dg)
+        return bad.value, digests
+
+    def timings_reset(self):
+        self._ck(self._L.hj_timings_reset(self._h))
+
+    def timings(self):
+        arr = (_lib.KernelTime * 32)()
+        n = C.c_uint32()
+        self._ck(self._L.hj_timings(self._h, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "total_ms": arr[i].total_ms,
+                                        "last_ms": arr[i].last_ms} for i in range(min(n.value, 32))}
+
+    # -- multi-GPU level-0 split / synthesis / digests ------------------------------------------------
+    def shard_split(self, keys, pays, n, nshards, out_keys, out_pays):
+        counts = (C.c_uint64 * nshards)()
+        self._ck(self._L.hj_shard_split(self._h, _dev_ptr(keys), _dev_ptr(pays), n, nshards, _dev_ptr(out_keys),
+                                        _dev_ptr(out_pays), counts))
+        return [int(c) for c in counts]
+
+    def gen_unique(self, d_keys, n, first, domain, seed):
+        self._ck(self._L.hj_gen_unique(self._h, _dev_ptr(d_keys), n, first, domain, seed))
+
+    def fill_payload(self, d_pays, n, payload="ones", first_rowid=0):
+        self._ck(self._L.hj_fill_payload(self._h, _dev_ptr(d_pays), n, _PAYLOAD[payload], first_rowid))
+
+    def digest_pairs(self, d_keys, d_pays, n):
+        d = C.c_uint64()
+        self._ck(self._L.hj_digest_pairs(self._h, _dev_ptr(d_keys), _dev_ptr(d_pays), n, C.byref(d)))
+        return d.value
+
+    def digest_triples(self, d_key, d_pr, d_ps, n):
+        d = C.c_uint64()
+        self._ck(self._L.hj_digest_triples(self._h, _dev_ptr(d_key), _dev_ptr(d_pr), _dev_ptr(d_ps), n, C.byref(d)))
+        return d.value
+
+
+def shard_of(key, nshards):
+    return _lib.lib().hj_shard_of(int(np.int32(key)), nshards)
+
+
+def hashJoinClusteredProbe(R, S):
+    """The reference's entry point (src/main.cu:291 `input.alg.joinAlg(&joinArgs,&time)`), called the
+    way main.cu calls it: host key columns in an `args` block.  Returns hj_last_result as a dict."""
+    L = _lib.lib()
+    R = np.ascontiguousarray(R, np.int32)
+    S = np.ascontiguousarray(S, np.int32)
+    a = _lib.Args()
+    a.R = R.ctypes.data_as(_lib.i32p)
+    a.R_els = len(R)
+    a.S = S.ctypes.data_as(_lib.i32p)
+    a.S_els = len(S)
+    a.threadsNum, a.sharedMem, a.pivotsNum = 32, 30 << 10, 1
+    ret = L.hashJoinClusteredProbe(C.byref(a), None)
+    res = _lib.LastResult()
+    L.hj_reference_last_result(C.byref(res))
+    out = {k: getattr(res, k) for k in ("matches", "agg", "materialized", "status")}
+    out["partition_ms"] = list(res.partition_ms)
+    out["join_ms"] = list(res.join_ms)
+    out["return"] = ret
+    return out

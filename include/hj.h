@@ -1,0 +1,155 @@
+/*
+ * hj.h — C ABI of libhj.so: the MI355X-native radix-partitioned hash-join path.
+ *
+ * This is the drop-in boundary for the in-GPU join path of psiul/ICDE2019-GPU-Join.  The reference
+ * has no FFI layer: the join sits behind one C function pointer selected by `-a HJC`
+ *     unsigned int hashJoinClusteredProbe(args*, timingInfo*)       src/main.cu:31,33-36,64-66,291
+ * which this library exports with the same POD argument block (hj_reference_abi.h).  Underneath it
+ * the explicit entry points below replace, one for one, the host-side steps of
+ * outOfGPU_Join1_payload (src/hash_join_clustered_probe.cu:802-994).  Plain pointers and sizes
+ * only; every function returns 0 on success or a negative HJ_E* code (the library never exit()s —
+ * the reference's CHK_ERROR print-and-exit, src/common.h:132-141, is left to the `bench` wrapper).
+ *
+ * Threading: one caller thread per context, one context per GPU (src/main.cu:93 cudaSetDevice).
+ * All work is enqueued on the context's HIP stream; only the functions marked [sync] wait for it.
+ */
+#ifndef HJ_H_
+#define HJ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hj_ctx hj_ctx;
+
+enum { HJ_REL_R = 0, HJ_REL_S = 1 };
+
+/* payload columns: the reference synthesises all-ones payloads (hjcp.cu:1994-1999); row ids are
+ * what its init_payload kernel writes (jp.cu:30-33). */
+enum { HJ_PAYLOAD_ONES = 0, HJ_PAYLOAD_ROWID = 1, HJ_PAYLOAD_GIVEN = 2 };
+
+enum {
+    HJ_OK = 0,
+    HJ_EINVAL = -1,    /* bad argument / call order */
+    HJ_EHIP = -2,      /* a HIP runtime call failed (message in hj_error) */
+    HJ_ENOMEM = -3,    /* device or host allocation failed */
+    HJ_ECAPACITY = -4, /* materialised output does not fit the caller's buffers */
+    HJ_EIO = -5        /* relation file missing / short */
+};
+
+/* Tunables.  Zero-initialise for the defaults (radix bits derived from the relation sizes so that
+ * a build partition fits the LDS hash table; replaces the compile-time log_parts1/log_parts2 of
+ * src/common.h:51-52). */
+typedef struct hj_config {
+    uint32_t bits1;        /* radix bits of pass 1 (key bits [bits2, bits2+bits1)); 0 = auto */
+    uint32_t bits2;        /* radix bits of pass 2 (key bits [0, bits2)); 0 with bits1!=0 = single pass */
+    uint32_t force_bits;   /* 1: take bits1/bits2 literally (bits1=bits2=0 → no partitioning) */
+    uint32_t build_side;   /* 0 auto (smaller relation, ties → R), 1 = R, 2 = S */
+    uint32_t lds_capacity; /* build tuples per LDS hash table; 0 = default */
+    uint32_t lds_heads;    /* hash-table heads (power of two); 0 = default */
+    uint32_t probe_chunk;  /* probe tuples per work item (decompose_chains threshold, hjcp.cu:904); 0 = default */
+    uint32_t reserved[9];
+} hj_config;
+
+/* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream). */
+typedef struct hj_kernel_time {
+    char name[32];
+    uint32_t launches; /* launches since hj_timings_reset */
+    float total_ms;    /* summed over those launches */
+    float last_ms;
+} hj_kernel_time;
+
+/* ---- context ---- */
+int hj_create(hj_ctx **out, int device);            /* hipSetDevice(device), stream, small workspace */
+int hj_destroy(hj_ctx *ctx);                        /* frees every buffer the library allocated */
+const char *hj_error(const hj_ctx *ctx);            /* message of the last failing call */
+int hj_set_stream(hj_ctx *ctx, void *hip_stream);   /* run on a caller-owned hipStream_t (NULL = own stream) */
+int hj_configure(hj_ctx *ctx, const hj_config *cfg);
+int hj_get_config(const hj_ctx *ctx, hj_config *cfg); /* the effective values after defaults/auto */
+int hj_sync(hj_ctx *ctx);                           /* [sync] */
+
+/* ---- relations (replaces hjcp.cu:815-879: device buffers + cudaMemcpy H2D) ---- */
+/* Copy host columns into library-owned HBM.  pays may be NULL unless payload_mode == HJ_PAYLOAD_GIVEN.
+ * The caller's columns are never modified or freed (hjcp.cu:874-877). [sync] */
+int hj_load_host(hj_ctx *ctx, int rel, const int32_t *keys, const int32_t *pays, uint64_t n,
+                 int payload_mode);
+/* Use columns already resident in HBM (caller-owned, e.g. torch tensors); not modified. */
+int hj_bind_device(hj_ctx *ctx, int rel, const int32_t *d_keys, const int32_t *d_pays, uint64_t n);
+
+/* ---- the path (replaces prepare_Relation_payload jp.cu:1582-1613 + decompose_chains/join launches
+ *      hjcp.cu:904-913,972-974) ---- */
+/* Radix-partition one relation into contiguous partitions on the low key bits (async). */
+int hj_partition(hj_ctx *ctx, int rel);
+/* Build+probe every partition pair, count only (join_partitioned_aggregate jp.cu:885-1095).
+ * matches = |R ⋈ S|; agg = sum payR*payS mod 2^64 (low 32 bits = the reference's int32 aggregate,
+ * jp.cu:1073,1092).  Either pointer may be NULL.  [sync] */
+int hj_join_count(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
+/* Build+probe and write every (key,payR,payS) output tuple to the caller's HBM columns
+ * (join_partitioned_results jp.cu:1107-1416, without its 2^24 FOLD ring: every tuple is kept).
+ * cap = capacity of each output column in tuples; *n_out = tuples produced.  HJ_ECAPACITY if
+ * n_out > cap (nothing beyond cap is written).  [sync] */
+int hj_join_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap,
+                        uint64_t *n_out);
+/* One call = hj_partition(R) + hj_partition(S) + hj_join_count (the timed region hjcp.cu:881-933). [sync] */
+int hj_join(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
+
+/* ---- plain device-memory helpers for callers without a HIP runtime binding of their own ---- */
+int hj_device_malloc(hj_ctx *ctx, void **d_ptr, uint64_t bytes);
+int hj_device_free(hj_ctx *ctx, void *d_ptr);
+int hj_memcpy_d2h(hj_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes); /* [sync] */
+int hj_memcpy_h2d(hj_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes); /* [sync] */
+
+/* ---- introspection for parity tests ---- */
+/* Device pointers of the partitioned columns and of the nparts+1 partition offsets (uint64). */
+int hj_get_partitions(hj_ctx *ctx, int rel, const int32_t **d_keys, const int32_t **d_pays,
+                      const uint64_t **d_offsets, uint64_t *nparts);
+int hj_timings_reset(hj_ctx *ctx);
+/* [sync] fills up to cap entries, returns the number of kernels known in *n. */
+int hj_timings(hj_ctx *ctx, hj_kernel_time *out, uint32_t cap, uint32_t *n);
+
+/* ---- multi-GPU: level-0 shard split (the role of the 16-way host partition of the co-processing
+ *      path, hjcp.cu:1256-1266,1380-1382, moved onto the GPU).  Splits (d_keys,d_pays) into nshards
+ *      contiguous runs by a hash of the key; h_counts[nshards] receives the run lengths.  The runs
+ *      are what an all-to-all over xGMI exchanges.  [sync] ---- */
+int hj_shard_split(hj_ctx *ctx, const int32_t *d_keys, const int32_t *d_pays, uint64_t n,
+                   uint32_t nshards, int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts);
+/* destination shard of a key (host-side mirror of the device function, for tests/oracles) */
+uint32_t hj_shard_of(int32_t key, uint32_t nshards);
+
+/* ---- device-side input synthesis and checks (perf-run inputs too large to shuffle on the host) ---- */
+/* keys[i] = pi_seed(first + i) where pi_seed is a bijection on [0, domain): a duplicate-free slice
+ * of a pseudo-random permutation of 0..domain-1 when first+n <= domain; beyond the domain it wraps
+ * (first + i) mod domain. (async) */
+int hj_gen_unique(hj_ctx *ctx, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
+int hj_fill_payload(hj_ctx *ctx, int32_t *d_pays, uint64_t n, int payload_mode, uint64_t first_rowid);
+/* order-independent 64-bit digests: sum of mix(key,pay) / mix(key,payR,payS) mod 2^64.  [sync] */
+int hj_digest_pairs(hj_ctx *ctx, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint64_t *digest);
+int hj_digest_triples(hj_ctx *ctx, const int32_t *d_key, const int32_t *d_payR, const int32_t *d_payS,
+                      uint64_t n, uint64_t *digest);
+/* number of tuples of the partitioned relation that sit in a partition other than
+ * (key >> 0) & (nparts-1), plus per-partition (key,pay) digests into d_digests[nparts] if non-NULL.  [sync] */
+int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_digests);
+
+/* ---- generator_ETHZ drop-in (host side; src/generator_ETHZ.cuh:11-23) ----
+ * Same generators, same raw-int32 .bin cache format; the time(NULL)/rand() global state of the
+ * reference is replaced by an explicit seed (0 = take time(NULL) like the reference). */
+void hj_gen_set_seed(uint64_t seed);
+int hj_create_relation_unique(const char *filename, int32_t *relation, uint64_t num_tuples, int64_t maxid);
+int hj_create_relation_nonunique(const char *filename, int32_t *relation, uint64_t num_tuples, int64_t maxid);
+int hj_create_relation_zipf(const char *filename, int32_t *relation, uint64_t num_tuples, int64_t maxid,
+                            double zipf_param);
+int hj_create_relation_fk_from_pk(const char *filename, int32_t *fkrel, uint64_t fk_tuples,
+                                  const int32_t *pkrel, uint64_t pk_tuples);
+int hj_create_relation_n(const int32_t *in_relation, int32_t *out_relation, uint64_t num_tuples, uint64_t n);
+int hj_read_relation(const char *filename, int32_t *relation, uint64_t num_tuples);
+int hj_write_relation(const char *filename, const int32_t *relation, uint64_t num_tuples);
+
+const char *hj_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJ_H_ */

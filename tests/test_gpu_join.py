@@ -1,0 +1,261 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Bit-exact bar: match count, sum(payR*payS) mod 2^64, the multiset of (key,payR,payS) output tuples,
+and the (key,payload) multiset of every radix partition."""
+import os
+
+import numpy as np
+import pytest
+
+from hjtest import pkg, sorted_triples
+from oracle import pyoracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    return pkg()
+
+
+def _load(golden_dir, name):
+    return np.fromfile(os.path.join(golden_dir, name), dtype=np.int32)
+
+
+def _check_join(P, R, Pr, S, Ps, cfg=None, materialize=True):
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=materialize)
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, S, Ps)
+        m, agg = hj.join()
+        assert (m, agg) == (em, eagg), ("count/agg", (m, agg), (em, eagg), hj.config())
+        if materialize:
+            k, pr, ps = hj.join_materialize()
+            assert len(k) == em
+            assert o.triples_checksum(k, pr, ps) == echk
+            if em <= 2_000_000:
+                ek, epr, eps = o.join_materialize(R, Pr, S, Ps)
+                got, exp = sorted_triples(k, pr, ps), sorted_triples(ek, epr, eps)
+                for a, b in zip(got, exp):
+                    assert np.array_equal(a, b)
+        return hj.config()
+
+
+def _check_partitions(P, keys, pays, cfg):
+    with P.HashJoin(0) as hj:
+        hj.configure(**cfg)
+        hj.load_host(P.REL_R, keys, pays)
+        hj.load_host(P.REL_S, keys[:1], pays[:1])
+        hj.partition(P.REL_R)
+        c = hj.config()
+        bits = c["bits1"] + c["bits2"]
+        gk, gp, goff = hj.partitions(P.REL_R, len(keys))
+        bad, dg = hj.verify_partitions(P.REL_R, with_digests=True)
+    assert bad == 0
+    ok, op, ooff = o.radix_partition(keys, pays, 0, bits)
+    assert np.array_equal(goff, ooff)                                   # identical partition boundaries
+    assert np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+    assert np.array_equal(dg, o.partition_digest(ok, op, ooff))         # device-side digest kernel agrees
+    d = gk.view(np.uint32) & ((1 << bits) - 1)
+    assert np.all(np.diff(d.astype(np.int64)) >= 0)                     # every tuple sits in its partition
+
+
+# ---- golden fixtures (outputs of the reference generator) --------------------------------------------
+@pytest.mark.parametrize("cfg", [None, dict(bits1=3), dict(bits1=4, bits2=3), dict(force_bits=True)])
+def test_golden_unique_self_join(P, golden_dir, cfg):
+    R = _load(golden_dir, "unique_4096.bin")        # bench -R 4096 -S 4096: S ≡ R → 4096 matches
+    Pr = np.arange(len(R), dtype=np.int32)
+    _check_join(P, R, Pr, R, Pr, cfg)
+
+
+@pytest.mark.parametrize("cfg", [None, dict(bits1=5, bits2=4)])
+def test_golden_unique_fk(P, golden_dir, cfg):
+    R = _load(golden_dir, "unique_4096.bin")
+    S = _load(golden_dir, "unique_fk10000_max4096.bin")
+    _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R)
+        hj.load_host(P.REL_S, S)
+        assert hj.join() == (10000 - (10000 - 1) // 4096,) * 2   # closed form, payloads = 1
+
+
+@pytest.mark.parametrize("cfg", [None, dict(bits1=2, bits2=2), dict(bits1=6, bits2=5, lds_capacity=64, lds_heads=16, probe_chunk=100)])
+def test_golden_zipf_nonunique_fullrange(P, golden_dir, cfg):
+    R = _load(golden_dir, "unique_4096.bin")
+    Z = _load(golden_dir, "zipf_S20000_a4096_t1.0_seed42.bin")
+    _check_join(P, R, np.arange(len(R), dtype=np.int32), Z, np.arange(len(Z), dtype=np.int32), cfg)
+    A = _load(golden_dir, "nonuniq_R6000_seed7.bin")
+    B = _load(golden_dir, "nonuniq_S9000_seed8.bin")
+    _check_join(P, A, np.arange(len(A), dtype=np.int32), B, -np.arange(len(B), dtype=np.int32), cfg)
+    K = _load(golden_dir, "pk_R3000_seed11.bin")
+    F = _load(golden_dir, "fk_S7000_pk_R3000_seed11.bin")
+    _check_join(P, K, np.arange(len(K), dtype=np.int32), F, np.arange(len(F), dtype=np.int32), cfg)
+
+
+# ---- edge cases ----------------------------------------------------------------------------------------
+def test_empty_and_tiny(P):
+    e = np.empty(0, np.int32)
+    one = np.array([7], np.int32)
+    for R, S in [(e, e), (one, e), (e, one), (one, one), (one, np.array([8], np.int32))]:
+        for cfg in (None, dict(bits1=3, bits2=2)):
+            _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 511, 512, 513, 4095, 4097, 8191, 8192, 8193, 20001])
+def test_ragged_sizes(P, n):
+    rng = np.random.default_rng(n)
+    R = rng.permutation(n).astype(np.int32)
+    S = rng.integers(0, n + 3, 2 * n + 1).astype(np.int32)
+    _check_join(P, R, np.arange(n, dtype=np.int32), S, np.arange(len(S), dtype=np.int32), dict(bits1=3, bits2=2))
+
+
+def test_extreme_keys_and_payload_overflow(P):
+    rng = np.random.default_rng(9)
+    keys = np.array([-2**31, 2**31 - 1, 0, -1, 1, 0x7FFF0000, -0x7FFF0000], np.int32)
+    R = np.concatenate([keys, rng.integers(-2**31, 2**31 - 1, 5000).astype(np.int32)])
+    S = np.concatenate([keys[::-1], R[::3], rng.integers(-2**31, 2**31 - 1, 5000).astype(np.int32)])
+    Pr = rng.integers(-2**31, 2**31 - 1, len(R)).astype(np.int32)   # payR*payS overflows int32: agg is mod 2^64
+    Ps = rng.integers(-2**31, 2**31 - 1, len(S)).astype(np.int32)
+    for cfg in (None, dict(bits1=9, bits2=9), dict(bits1=8, bits2=8), dict(bits1=5)):
+        _check_join(P, R, Pr, S, Ps, cfg)
+
+
+def test_all_duplicates_overflow_lds_table(P):
+    """One key everywhere: a single partition far larger than the LDS table (the reference's
+    'S partition doesn't fit' branch, jp.cu:929-1003) and a quadratic output."""
+    R = np.full(3000, 42, np.int32)
+    S = np.full(1500, 42, np.int32)
+    cfg = dict(bits1=4, bits2=4, lds_capacity=256, lds_heads=64, probe_chunk=512)
+    _check_join(P, R, np.arange(3000, dtype=np.int32), S, np.arange(1500, dtype=np.int32), cfg)
+    with P.HashJoin(0) as hj:
+        hj.configure(**cfg)
+        hj.load_host(P.REL_R, R)
+        hj.load_host(P.REL_S, S)
+        assert hj.join() == (4_500_000, 4_500_000)
+
+
+def test_skew_heavy_hitters(P):
+    rng = np.random.default_rng(4)
+    n = 1 << 14
+    R = rng.permutation(n).astype(np.int32)
+    hot = rng.integers(0, n, 8)
+    S = np.where(rng.random(1 << 18) < 0.6, hot[rng.integers(0, 8, 1 << 18)], rng.integers(0, n, 1 << 18)).astype(np.int32)
+    for cfg in (None, dict(bits1=5, bits2=5, probe_chunk=1000), dict(build_side=2, lds_capacity=2048, lds_heads=512)):
+        _check_join(P, R, np.arange(n, dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
+
+
+def test_tag16_vs_full_key_paths(P):
+    # 16+ radix bits → 16-bit tags (the reference's compression, jp.cu:1029); fewer → full keys.
+    rng = np.random.default_rng(11)
+    R = rng.integers(-2**31, 2**31 - 1, 1 << 16).astype(np.int32)
+    S = np.concatenate([R[: 1 << 15], rng.integers(-2**31, 2**31 - 1, 1 << 15).astype(np.int32)])
+    # keys that agree in the low bits and in the hash slot bits but differ above must not match
+    R[:4] = [0x00010000, 0x10010000, 0x20010000, 0x30010000]
+    S[:2] = [0x40010000, 0x10010000]
+    for cfg in (dict(bits1=8, bits2=8), dict(bits1=9, bits2=9), dict(bits1=8, bits2=7), dict(bits1=2)):
+        _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
+
+
+# ---- partition parity --------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(bits1=1), dict(bits1=9), dict(bits1=4, bits2=4), dict(bits1=9, bits2=9), dict(bits1=7, bits2=2)])
+def test_partition_parity(P, cfg):
+    rng = np.random.default_rng(21)
+    n = 300_001
+    keys = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    keys[: n // 4] = rng.integers(0, 50, n // 4)            # a skewed quarter
+    _check_partitions(P, keys, np.arange(n, dtype=np.int32), cfg)
+
+
+def test_partition_repeatable_and_input_untouched(P):
+    rng = np.random.default_rng(2)
+    keys = rng.integers(0, 1 << 20, 100_000).astype(np.int32)
+    pays = np.arange(100_000, dtype=np.int32)
+    k0, p0 = keys.copy(), pays.copy()
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=6, bits2=5)
+        hj.load_host(P.REL_R, keys, pays)
+        hj.load_host(P.REL_S, keys, pays)
+        first = hj.join()
+        for _ in range(3):                                   # atomics decide in-partition order: results must not move
+            assert hj.join() == first
+    assert np.array_equal(keys, k0) and np.array_equal(pays, p0)
+
+
+# ---- medium sizes: oracle still finishes in seconds ------------------------------------------------------
+@pytest.mark.parametrize("logn", [20, 22])
+def test_config1_and_up_unique(P, logn):
+    n = 1 << logn
+    P.generator.seed_generator(12345)
+    R = P.generator.create_relation_unique(None, n, n)
+    assert np.array_equal(R, o.random_unique_gen(n, n, 12345))
+    rng = np.random.default_rng(logn)
+    S = R[rng.permutation(n)]
+    Pr = np.arange(n, dtype=np.int32)
+    c = _check_join(P, R, Pr, S, Pr, None, materialize=(logn <= 20))
+    assert c["bits1"] + c["bits2"] == logn - 12
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R)
+        hj.load_host(P.REL_S, S)
+        assert hj.join() == (n, n)
+
+
+def test_reference_entry_point(P, golden_dir, capfd):
+    """hashJoinClusteredProbe(args*, timingInfo*) as main.cu calls it (src/main.cu:291)."""
+    R = _load(golden_dir, "unique_4096.bin")
+    S = _load(golden_dir, "unique_fk10000_max4096.bin")
+    r = P.hashJoinClusteredProbe(R, S)
+    out = capfd.readouterr().out
+    assert r["status"] == 0 and r["return"] == 0
+    assert r["matches"] == r["agg"] == r["materialized"] == 9998
+    for line in ("With materialization", "Partition Throughput ", "Joins Throughput ", "Total Throughput  ",
+                 "9998 results", "Without materialization", "Total Throughput "):
+        assert line in out, line
+
+
+def test_bench_cli_join(P, tmp_path):
+    import subprocess
+    r = subprocess.run([P._lib.BENCH_PATH, "-b", "7", "-a", "HJC", "-R", "65536", "-S", "200000", "--seed", "3"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "HJC : shareMemory = 30720\t#threads = 32" in r.stdout
+    assert "%d results" % (200000 - (200000 - 1) // 65536) in r.stdout
+
+
+# ---- BASELINE sizes through size-independent properties --------------------------------------------------
+@pytest.mark.parametrize("logn", [27])
+def test_large_unique_properties(P, logn):
+    """2^27 ⋈ 2^27 unique keys generated on the device (two independent pseudo-random permutations):
+    matches = N; partitioning preserves the (key,payload) multiset and places every tuple; the
+    materialised output has N tuples whose digest equals the digest of (R[i], i, pos_S(R[i]))."""
+    import torch
+    n = 1 << logn
+    dev = torch.device("cuda:0")
+    Rk, Sk = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    Rp, Sp = torch.empty_like(Rk), torch.empty_like(Sk)
+    with P.HashJoin(0) as hj:
+        hj.gen_unique(Rk, n, 0, n, 1)
+        hj.gen_unique(Sk, n, 0, n, 2)
+        hj.fill_payload(Rp, n, "rowid")
+        hj.fill_payload(Sp, n, "rowid")
+        hj.sync()
+        assert int(torch.unique(Rk).numel()) == n and int(Rk.min()) == 0 and int(Rk.max()) == n - 1
+        hj.bind_device(P.REL_R, Rk, Rp)
+        hj.bind_device(P.REL_S, Sk, Sp)
+        before = hj.digest_pairs(Rk, Rp, n)
+        m, agg = hj.join()
+        assert m == n
+        # sum_i rowidR(i) * rowidS(match) mod 2^64, from torch (independent of the join path)
+        inv = torch.empty(n, dtype=torch.int64, device=dev)
+        inv[Sk.long()] = torch.arange(n, device=dev)
+        exp_agg = int((torch.arange(n, device=dev) * inv[Rk.long()]).sum().item()) % (1 << 64)
+        assert agg == exp_agg
+        bad, _ = hj.verify_partitions(P.REL_R)
+        assert bad == 0
+        k, p, off, nparts = hj.partition_pointers(P.REL_R)
+        assert hj.digest_pairs(k, p, n) == before
+        ok, opr, ops = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+        assert hj.join_materialize_into(ok, opr, ops, n) == n
+        exp_digest = hj.digest_triples(Rk, Rp, inv[Rk.long()].int(), n)
+        assert hj.digest_triples(ok, opr, ops, n) == exp_digest
+        assert torch.equal(Rk[opr.long()], ok) and torch.equal(Sk[ops.long()], ok)   # key == R[payR] == S[payS]
