@@ -1,0 +1,68 @@
+"""Multi-GPU join: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-GPU; its structural analogue is the co-processing path, which radix-splits
+both relations 16 ways on the host and joins each level-0 partition independently
+(src/hash_join_clustered_probe.cu:1256-1266, 1503-1618).  Here the level-0 split runs on each GPU
+(hj_shard_split: hash of the key → owner GPU), the shards are exchanged with ONE all-to-all-v per
+column — xGMI is point-to-point, every ordered GPU pair has its own link, so nothing is relayed —
+and each GPU then runs the unchanged local path (partition + build/probe) on what it received.
+Only the 64-bit match count / aggregate is all-reduced.
+
+`engine` is a HashJoin (HIP).  Tests drive the same exchange logic over gloo with a stand-in engine.
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardedJoin:
+    def __init__(self, engine, pkg, device, group=None):
+        self.e = engine
+        self.pkg = pkg
+        self.dev = device
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._buf = {}
+
+    def _get(self, name, n):
+        """Reusable int32 column of at least n elements (HBM is plentiful: keep, do not re-allocate)."""
+        t = self._buf.get(name)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(int(n * 1.02) + 1024, 1024), dtype=torch.int32, device=self.dev)
+            self._buf[name] = t
+        return t
+
+    def exchange(self, cols, send_counts):
+        """All-to-all-v of several columns that share one split: cols = {name: tensor[sum(send_counts)]}.
+        Returns ({name: tensor}, n_received)."""
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.tolist()]
+        total = sum(recv_counts)
+        out = {}
+        for name, t in cols.items():
+            r = self._get("recv_" + name, total)
+            dist.all_to_all_single(r[:total], t[:sum(send_counts)], recv_counts, list(send_counts), group=self.group)
+            out[name] = r
+        return out, total
+
+    def join(self, Rk, Rp, Sk, Sp):
+        """Local slices of R and S (int32 device columns) → (global matches, global sum payR*payS mod 2^64)."""
+        e, w = self.e, self.world
+        recv = {}
+        for tag, k, p in (("R", Rk, Rp), ("S", Sk, Sp)):
+            n = int(k.numel())
+            ok, op = self._get("split_k" + tag, n), self._get("split_p" + tag, n)
+            counts = e.shard_split(k, p, n, w, ok, op)           # level-0 radix split, contiguous per owner
+            got, total = self.exchange({"k" + tag: ok, "p" + tag: op}, counts)
+            recv[tag] = (got["k" + tag], got["p" + tag], total)
+        e.bind_device(self.pkg.REL_R, recv["R"][0], recv["R"][1], recv["R"][2])
+        e.bind_device(self.pkg.REL_S, recv["S"][0], recv["S"][1], recv["S"][2])
+        m, agg = e.join()                                         # unchanged single-GPU path
+        # 64-bit results as 32-bit halves so the SUM all-reduce cannot overflow int64
+        t = torch.tensor([m & 0xFFFFFFFF, m >> 32, agg & 0xFFFFFFFF, agg >> 32], dtype=torch.int64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        v = [int(x) for x in t.tolist()]
+        mask = (1 << 64) - 1
+        return (v[0] + (v[1] << 32)) & mask, (v[2] + (v[3] << 32)) & mask

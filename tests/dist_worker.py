@@ -1,0 +1,87 @@
+"""Worker for tests/test_dist.py: runs ShardedJoin over gloo (CPU) with a stand-in engine whose
+shard_split / join are numpy + the oracle, so the exchange logic of the multi-GPU path is exercised
+end to end at world_size 2 without a GPU.  With HJ_DIST_GPU=1 the engine is the real HashJoin."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+from oracle import pyoracle as o  # noqa: E402
+
+
+class OracleEngine:
+    """Same interface as HashJoin for the three calls ShardedJoin makes (CPU tensors)."""
+
+    def __init__(self, pkg):
+        self.pkg = pkg
+        self.rel = {}
+
+    def shard_split(self, keys, pays, n, nshards, out_keys, out_pays):
+        k, p = keys[:n].numpy(), pays[:n].numpy()
+        owner = np.array([self.pkg.shard_of(int(x), nshards) for x in k], dtype=np.int64) if n else np.empty(0, np.int64)
+        order = np.argsort(owner, kind="stable")
+        out_keys[:n] = torch.from_numpy(k[order])
+        out_pays[:n] = torch.from_numpy(p[order])
+        return [int((owner == s).sum()) for s in range(nshards)]
+
+    def bind_device(self, rel, keys, pays, n):
+        self.rel[rel] = (keys[:n].numpy().copy(), pays[:n].numpy().copy())
+
+    def join(self):
+        (rk, rp), (sk, sp) = self.rel[0], self.rel[1]
+        m, agg, _ = o.join_count(rk, rp, sk, sp, checksum=False)
+        return m, agg
+
+
+def main():
+    gpu = os.environ.get("HJ_DIST_GPU") == "1"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    pkg = graft.load_package()
+    if gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=dev)
+        engine = pkg.HashJoin(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo")
+        engine = OracleEngine(pkg)
+    from importlib import import_module
+    dj = import_module(pkg.__name__ + ".dist").ShardedJoin(engine, pkg, dev)
+
+    # every rank generates the same global relations and keeps its own slice
+    rng = np.random.default_rng(123)
+    nR, nS = 20_000, 50_001
+    R = rng.integers(-5000, 5000, nR).astype(np.int32)
+    S = rng.integers(-5000, 5000, nS).astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = np.arange(nS, dtype=np.int32)
+
+    def sl(a, n):
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        return torch.from_numpy(a[lo:hi].copy()).to(dev)
+
+    res = []
+    for _ in range(2):  # twice: buffers are reused across steps
+        res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS)))
+    # an empty local slice on one rank must work too
+    e = torch.empty(0, dtype=torch.int32, device=dev)
+    if rank == 0:
+        res.append(dj.join(e, e, sl(S, nS), sl(Ps, nS)))
+    else:
+        res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS)))
+    if rank == 0:
+        em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+        lo = nR // world
+        em3, eagg3, _ = o.join_count(R[lo:], Pr[lo:], S, Ps, checksum=False)
+        print("RESULT " + json.dumps({"got": res, "expect": [[em, eagg], [em, eagg], [em3, eagg3]]}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

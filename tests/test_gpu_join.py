@@ -233,7 +233,8 @@ def test_large_unique_properties(P, logn):
     dev = torch.device("cuda:0")
     Rk, Sk = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
     Rp, Sp = torch.empty_like(Rk), torch.empty_like(Sk)
-    with P.HashJoin(0) as hj:
+    # run on torch's current stream so that torch ops and libhj kernels are ordered with each other
+    with P.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream) as hj:
         hj.gen_unique(Rk, n, 0, n, 1)
         hj.gen_unique(Sk, n, 0, n, 2)
         hj.fill_payload(Rp, n, "rowid")
