@@ -64,6 +64,7 @@ struct hj_ctx {
     bool join_planned = false;
     uint32_t max_items = 0;
     size_t lds_limit = 0;
+    int scatter_variant = -1;
     // timing
     bool events = true;
     std::vector<KStat> kstats;
@@ -232,7 +233,10 @@ int run_pass(hj_ctx *c, int mode, const int32_t *in_k, const int32_t *in_p, uint
     { Timed t(c, "k_hist"); HIPCHK(c, launch_hist(st, mode, pa)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + nparents, P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr)); }
     { Timed t(c, "k_offsets"); HIPCHK(c, launch_offsets(st, pa, n, coff)); }
-    { Timed t(c, "k_scatter"); HIPCHK(c, launch_scatter(st, mode, pa)); }
+        // wide fan-out: LDS write-combining lines (aligned 128-B stores); narrow fan-out (shard split, small
+    // inputs): the sorted-tile kernel, whose runs are long anyway.  HJ_SCATTER_VARIANT overrides (experiments).
+    const int variant = c->scatter_variant >= 0 ? c->scatter_variant : (P >= 64 ? 4 : 1);
+    { Timed t(c, "k_scatter"); HIPCHK(c, launch_scatter(st, mode, variant, pa)); }
     return 0;
 }
 
@@ -376,6 +380,8 @@ int hj_create(hj_ctx **out, int device) {
     memset(c->h_scalars, 0, 64);
     const char *ev = getenv("HJ_NO_KERNEL_EVENTS");
     c->events = !(ev && ev[0] == '1');
+    const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
+    if (sv) c->scatter_variant = atoi(sv);
     *out = c;
     return HJ_OK;
 }
@@ -406,7 +412,7 @@ int hj_set_stream(hj_ctx *c, void *s) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_stamps(c);
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (s == HJ_OWN_STREAM) ? c->own_stream : (hipStream_t)s;
     return HJ_OK;
 }
 

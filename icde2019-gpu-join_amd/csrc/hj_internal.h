@@ -10,7 +10,7 @@ namespace hj {
 // partition kernels: 512-thread workgroups (8 wave64), 4 x 16-byte loads per thread per tile
 constexpr int PART_THREADS = 512;
 constexpr int TILE_U = 4;
-constexpr int TILE = PART_THREADS * 4 * TILE_U; // 8192 tuples: 32 KiB LDS reorder buffer
+constexpr int TILE = PART_THREADS * 4 * TILE_U; // default tile: 8192 tuples (span granularity)
 constexpr int MAX_PARTS = 512;                  // fan-out limit of one pass (9 bits)
 constexpr int MAX_PARENTS = 1024;               // k_plan is a single workgroup
 
@@ -60,7 +60,8 @@ hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_p
 hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
-hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
+hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa);
+size_t scatter_lds_bytes(int threads, int u);
 hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
                             uint32_t *items_cnt);
 hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,

@@ -250,43 +250,53 @@ __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__r
     coff[t] = idx < total ? (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG] : n;
 }
 
-// Scatter one span.  Per 8192-tuple tile: LDS histogram with ranks (one returning LDS atomic per
-// tuple), workgroup scan, reorder keys through a 32 KiB LDS buffer so that each digit's tuples are
-// consecutive, then consecutive lanes store consecutive positions of the span's private output run
-// of that digit; payloads reuse the same LDS slots (the two-phase idea of jp.cu:203-278, with
-// contiguous per-span output regions instead of bucket chains, so consecutive tiles extend the same
-// cache lines from the same CU).  Algorithmic traffic: 8 B read + 8 B written per tuple.
-template <int MODE>
-__global__ __launch_bounds__(PART_THREADS) void k_scatter(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                          uint64_t nalloc, const uint64_t *__restrict__ poff,
-                                                          uint32_t nparents, const uint32_t *__restrict__ span_start,
-                                                          uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                          const uint32_t *__restrict__ hist,
-                                                          const uint64_t *__restrict__ chunk_prefix,
-                                                          int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
-    __shared__ int32_t buf[TILE];
-    __shared__ uint32_t h[MAX_PARTS];      // per-tile count of each digit
-    __shared__ uint32_t start[MAX_PARTS];  // per-tile exclusive prefix
-    __shared__ uint32_t gbase[MAX_PARTS];  // next output position of each digit for this span (n < 2^32 per pass)
-    __shared__ uint32_t scratch[17];
+// Scatter one span.  Per tile (THREADS*4*U tuples): LDS histogram with ranks (one returning LDS
+// atomic per tuple), workgroup scan, keys AND payloads reordered together through two LDS buffers so
+// that each digit's tuples are consecutive, then ONE write-out pass in which consecutive lanes store
+// consecutive positions of the span's private output run of that digit (the tile-reorder idea of
+// jp.cu:203-278, with contiguous per-span output regions instead of bucket chains, so consecutive
+// tiles extend the same cache lines from the same CU).  The next tile's 16-byte loads are issued
+// before the write-out so HBM reads stay in flight across the barriers.  5 barriers per tile.
+// Algorithmic traffic: 8 B read + 8 B written per tuple.
+template <int MODE, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                     uint64_t nalloc, const uint64_t *__restrict__ poff,
+                                                     uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                     uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
+                                                     const uint32_t *__restrict__ hist,
+                                                     const uint64_t *__restrict__ chunk_prefix,
+                                                     int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+    constexpr uint32_t TILE_T = THREADS * 4 * U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t *bufK = reinterpret_cast<int32_t *>(smem);
+    int32_t *bufP = bufK + TILE_T;
+    uint32_t *h = reinterpret_cast<uint32_t *>(bufP + TILE_T); // per-tile count of each digit
+    uint32_t *delta = h + MAX_PARTS;                            // output position minus tile slot, per digit
+    uint32_t *gbase = delta + MAX_PARTS;                        // next output position of each digit (n < 2^32)
+    uint32_t *scratch = gbase + MAX_PARTS;                      // 32 words
     SpanInfo si;
     if (!decode_span(poff, nparents, span_start, span, si)) return;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t d = tid; d < P; d += PART_THREADS) {
+    const uint32_t tid = threadIdx.x, wv = tid >> 6;
+    for (uint32_t d = tid; d < P; d += THREADS) {
         uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
         gbase[d] = (uint32_t)((uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG]);
         h[d] = 0;
     }
-    __syncthreads();
     const uint64_t a0 = si.lo & ~(uint64_t)3;
-    for (uint64_t t0 = a0; t0 < si.hi; t0 += TILE) {
-        // ---- A: load keys, rank inside digit ----
-        int4 kv[TILE_U];
-        uint32_t dr[TILE_U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
+    int4 kv[U], pv[U];
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++) {
-            uint64_t i = t0 + ((uint64_t)u * PART_THREADS + tid) * 4;
-            kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
+    for (int u = 0; u < U; u++) {
+        uint64_t i = a0 + ((uint64_t)u * THREADS + tid) * 4;
+        kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
+        pv[u] = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (uint64_t t0 = a0; t0 < si.hi; t0 += TILE_T) {
+        // ---- A: rank of every tuple inside its digit ----
+        uint32_t dr[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t i = t0 + ((uint64_t)u * THREADS + tid) * 4;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 uint64_t idx = i + e;
@@ -299,56 +309,241 @@ __global__ __launch_bounds__(PART_THREADS) void k_scatter(const int32_t *__restr
             }
         }
         __syncthreads();
-        // ---- B: exclusive scan of the tile histogram (P <= 512 = one value per thread) ----
+        // ---- B: exclusive scan of the tile histogram (P <= 512 <= THREADS: one digit per thread);
+        //         the owner thread of a digit also advances its output cursor and clears its count ----
         uint32_t cnt = tid < P ? h[tid] : 0;
-        uint32_t tile_cnt;
-        uint32_t ex = block_excl_scan<uint32_t>(cnt, scratch, &tile_cnt);
-        if (tid < P) start[tid] = ex;
+        uint32_t incl = wave_incl_scan(cnt);
+        if (lane_id() == 63) scratch[wv] = incl;
         __syncthreads();
-        // ---- C: keys into digit order ----
+        uint32_t wpre = 0, tile_cnt = 0;
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++)
+        for (int w = 0; w < THREADS / 64; w++) {
+            uint32_t t = scratch[w];
+            if (w < (int)wv) wpre += t;
+            tile_cnt += t;
+        }
+        if (tid < P) {
+            uint32_t ex = wpre + incl - cnt;
+            uint32_t g = gbase[tid];
+            delta[tid] = g - ex;
+            h[tid] = ex;          // h becomes the tile-local start of the digit for step C
+            gbase[tid] = g + cnt;
+        }
+        __syncthreads();
+        // ---- C: keys and payloads into digit order ----
+#pragma unroll
+        for (int u = 0; u < U; u++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 uint32_t code = dr[u * 4 + e];
-                if (code != 0xFFFFFFFFu) buf[start[code >> 16] + (code & 0xFFFFu)] = elem(kv[u], e);
+                if (code != 0xFFFFFFFFu) {
+                    uint32_t slot = h[code >> 16] + (code & 0xFFFFu);
+                    bufK[slot] = elem(kv[u], e);
+                    bufP[slot] = elem(pv[u], e);
+                }
             }
-        __syncthreads();
-        // ---- D: keys out; remember each slot's destination for the payload ----
-        uint32_t dst[TILE_U * 4];
+        // ---- prefetch the next tile while this one is written out ----
+        {
+            const uint64_t t1 = t0 + TILE_T;
 #pragma unroll
-        for (int j = 0; j < TILE_U * 4; j++) {
-            uint32_t i = j * PART_THREADS + tid;
-            dst[j] = 0;
+            for (int u = 0; u < U; u++) {
+                uint64_t i = t1 + ((uint64_t)u * THREADS + tid) * 4;
+                kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
+                pv[u] = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // ---- D: one write-out pass: consecutive lanes → consecutive output positions ----
+#pragma unroll
+        for (int j = 0; j < U * 4; j++) {
+            uint32_t i = j * THREADS + tid;
             if (i < tile_cnt) {
-                int32_t key = buf[i];
-                uint32_t d = digit_of<MODE>((uint32_t)key, shift, mask_or_n);
-                dst[j] = gbase[d] + (i - start[d]);
-                out_keys[dst[j]] = key;
+                int32_t key = bufK[i], pay = bufP[i];
+                uint32_t o = delta[digit_of<MODE>((uint32_t)key, shift, mask_or_n)] + i;
+                out_keys[o] = key;
+                out_pays[o] = pay;
             }
         }
+        if (tid < P) h[tid] = 0;
         __syncthreads();
-        // ---- E: payloads through the same slots ----
+    }
+}
+
+// Scatter one span through per-digit LDS WRITE-COMBINING buffers (the software write-combining idea
+// of the reference's CPU partitioner, partition-primitives.cu:40-125, re-expressed in LDS): every
+// digit owns one 128-byte line of keys and one of payloads (32 tuples) in LDS; tuples are appended
+// to their digit's line, and a line leaves the CU only when it is full — as one aligned 128-B store
+// of 32 lanes.  On MI355X aligned full-line scatter stores run at ~5 TB/s while the same bytes in
+// unaligned runs run at 1-2.5 TB/s (scratch/ubench_store.hip), and that is the whole point.
+//
+// The span's private output run of digit d starts at g0 = hist-scan position (any alignment).  The
+// LDS line of d mirrors the 128-B line of the output that is currently being filled: slot s of the
+// line is output position line[d] + s, line[d] % 32 == 0.  Per round of 4096 tuples (1024 threads x
+// one 16-byte load): (1) rank every tuple inside its digit with one returning LDS atomic;
+// (2) tuples that fall into the current line are stored to LDS, tuples beyond the lines that fill up
+// this round are kept in registers, tuples in between (only when a digit receives more than a line
+// per round: skew) go straight to HBM; (3) every digit whose line filled up is flushed by one wave
+// (lanes 0-31 the key line, lanes 32-63 the payload line); (4) the kept tuples start the next line.
+// No retry loops: the cost of a round does not depend on the key distribution.
+// Algorithmic traffic: 8 B read + 8 B written per tuple.
+constexpr int WC_THREADS = 1024;
+constexpr int WC_LINE = 32; // tuples per 128-byte line
+
+template <int MODE, int U>
+__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                           uint64_t nalloc, const uint64_t *__restrict__ poff,
+                                                           uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                           uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
+                                                           const uint32_t *__restrict__ hist,
+                                                           const uint64_t *__restrict__ chunk_prefix,
+                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int32_t *bufK = reinterpret_cast<int32_t *>(smem);           // [MAX_PARTS][32]
+    int32_t *bufP = bufK + MAX_PARTS * WC_LINE;                  // [MAX_PARTS][32]
+    uint32_t *hh = reinterpret_cast<uint32_t *>(bufP + MAX_PARTS * WC_LINE); // [2][MAX_PARTS] arrivals, by round parity
+    uint32_t *cur = hh + 2 * MAX_PARTS;                          // occupied slots of the current line
+    uint32_t *line = cur + MAX_PARTS;                            // output position of slot 0 (multiple of 32)
+    uint32_t *lo = line + MAX_PARTS;                             // first valid slot (non-zero only for the first line)
+    SpanInfo si;
+    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+    for (uint32_t d = tid; d < P; d += WC_THREADS) {
+        uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
+        uint32_t g0 = (uint32_t)((uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG]);
+        line[d] = g0 & ~(uint32_t)(WC_LINE - 1);
+        cur[d] = lo[d] = g0 & (WC_LINE - 1);
+        hh[d] = hh[MAX_PARTS + d] = 0;
+    }
+    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
+    const uint64_t a0 = si.lo & ~(uint64_t)3;
+    // 32-bit positions relative to a0 (a span is < 2^32 tuples)
+    const uint32_t rlo = (uint32_t)(si.lo - a0), rhi = (uint32_t)(si.hi - a0);
+    const int32_t *kin = keys + a0, *pin = pays + a0;
+    const uint64_t navail = nalloc - a0;
+    int4 kv[U], pv[U];
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++) {
-            uint64_t i = t0 + ((uint64_t)u * PART_THREADS + tid) * 4;
-            int4 pv = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
+    for (int u = 0; u < U; u++) {
+        uint32_t r = (u * WC_THREADS + tid) * 4;
+        kv[u] = (r < rhi) ? load4(kin, r, navail) : make_int4(0, 0, 0, 0);
+        pv[u] = (r < rhi) ? load4(pin, r, navail) : make_int4(0, 0, 0, 0);
+    }
+    int4 kk[U], pp[U];     // the previous round's tuples: the kept ones are stored one phase later
+    uint32_t keep[U * 4];  // LDS word index (d*32 + slot) of a kept tuple, 0xFFFFFFFF = none
+#pragma unroll
+    for (int j = 0; j < U * 4; j++) keep[j] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
+    __syncthreads();
+    uint32_t par = 0;
+    for (uint32_t r0 = 0; r0 < rhi; r0 += ROUND, par ^= 1) {
+        uint32_t *h = hh + par * MAX_PARTS, *hprev = hh + (par ^ 1) * MAX_PARTS;
+        // ---- A: finish the previous round (kept tuples open the next line, digit owners advance
+        //         their state), and rank this round's tuples (arrival counters alternate by parity) ----
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
+                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
+                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
+                }
+        if (tid < P) {
+            const uint32_t total = cur[tid] + hprev[tid];
+            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
+            if (full) { line[tid] += full; lo[tid] = 0; }
+            cur[tid] = total - full;
+            hprev[tid] = 0;
+        }
+        uint32_t code[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t r = r0 + (u * WC_THREADS + tid) * 4;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                uint32_t code = dr[u * 4 + e];
-                if (code != 0xFFFFFFFFu) buf[start[code >> 16] + (code & 0xFFFFu)] = elem(pv, e);
+                code[u * 4 + e] = 0xFFFFFFFFu;
+                if (r + e >= rlo && r + e < rhi) {
+                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
+                    code[u * 4 + e] = (d << 16) | atomicAdd(&h[d], 1u);
+                }
             }
         }
         __syncthreads();
+        // ---- B: place: current line / straight to HBM / keep for the next line ----
 #pragma unroll
-        for (int j = 0; j < TILE_U * 4; j++) {
-            uint32_t i = j * PART_THREADS + tid;
-            if (i < tile_cnt) out_pays[dst[j]] = buf[i];
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t c = code[u * 4 + e];
+                keep[u * 4 + e] = 0xFFFFFFFFu;
+                if (c != 0xFFFFFFFFu) {
+                    const uint32_t d = c >> 16;
+                    const uint32_t cd = cur[d];
+                    const uint32_t q = cd + (c & 0xFFFFu);
+                    const uint32_t full = (cd + h[d]) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
+                    if (q < WC_LINE) {
+                        bufK[d * WC_LINE + q] = elem(kv[u], e);
+                        bufP[d * WC_LINE + q] = elem(pv[u], e);
+                    } else if (q >= full) {
+                        keep[u * 4 + e] = d * WC_LINE + (q - full);
+                    } else { // more than one line for this digit in one round (skew): bypass the buffer
+                        out_keys[line[d] + q] = elem(kv[u], e);
+                        out_pays[line[d] + q] = elem(pv[u], e);
+                    }
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            kk[u] = kv[u]; pp[u] = pv[u];
+            // next round's loads fly while the lines are flushed
+            const uint32_t r1 = r0 + ROUND + (u * WC_THREADS + tid) * 4;
+            const bool in = r1 < rhi && r1 >= ROUND; // r1 >= ROUND: no wrap of the 32-bit position
+            kv[u] = in ? load4(kin, r1, navail) : make_int4(0, 0, 0, 0);
+            pv[u] = in ? load4(pin, r1, navail) : make_int4(0, 0, 0, 0);
         }
         __syncthreads();
-        // ---- F: advance the span's output cursors ----
-        if (tid < P) { gbase[tid] += h[tid]; h[tid] = 0; }
+        // ---- C: flush every line that filled up: one aligned 128-B store per column.  Wave w owns
+        //         digits [32w, 32w+32): a ballot picks the full ones, the wave walks only those ----
+        for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
+            const uint32_t dl = dbase + (ln & 31u);
+            const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
+            uint64_t m = __ballot(fullq);
+            const uint32_t s = ln & (WC_LINE - 1);
+            while (m) {
+                const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (s >= lo[d]) {
+                    if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
+                    else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+                }
+            }
+        }
         __syncthreads();
+    }
+    // ---- epilogue: phase A of the last round, then the partially filled last line of every digit ----
+    {
+        uint32_t *hprev = hh + (par ^ 1) * MAX_PARTS;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
+                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
+                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
+                }
+        if (tid < P) {
+            const uint32_t total = cur[tid] + hprev[tid];
+            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
+            if (full) { line[tid] += full; lo[tid] = 0; }
+            cur[tid] = total - full;
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
+        const uint32_t s = ln & (WC_LINE - 1);
+        if (s >= lo[d] && s < cur[d]) {
+            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
+            else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+        }
     }
 }
 
@@ -630,16 +825,61 @@ hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64
     return hipSuccess;
 }
 
-hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
-    dim3 g(pa.max_spans), b(PART_THREADS);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_scatter<0>, g, b, 0, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span,
-                           pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
-    else
-        hipLaunchKernelGGL(k_scatter<1>, g, b, 0, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span,
-                           pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
-    HJ_LAUNCH_CHECK();
-    return hipSuccess;
+size_t scatter_lds_bytes(int threads, int u) {
+    return (size_t)threads * 4 * u * 4 * 2 + (size_t)MAX_PARTS * 4 * 3 + 32 * 4;
+}
+
+template <int MODE, int THREADS, int U>
+static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
+    static bool attr_set = false;
+    const size_t lds = scatter_lds_bytes(THREADS, U);
+    auto fn = k_scatter<MODE, THREADS, U>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
+                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    return hipGetLastError();
+}
+
+size_t scatter_wc_lds_bytes() { return (size_t)MAX_PARTS * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 5; }
+
+template <int MODE, int U>
+static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
+    static bool attr_set = false;
+    const size_t lds = scatter_wc_lds_bytes();
+    auto fn = k_scatter_wc<MODE, U>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
+                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    return hipGetLastError();
+}
+
+// variant: 0 = 512 threads x 8192-tuple sorted tiles (2 workgroups/CU), 1 = 1024 x 16384 (1/CU),
+//          2 = 512 x 4096, 3 = 1024 x 8192, 4/5 = LDS write-combining lines (k_scatter_wc, 8192/4096 per round)
+hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa) {
+    if (variant == 4) return mode == 0 ? launch_scatter_wc_t<0, 2>(st, pa) : launch_scatter_wc_t<1, 2>(st, pa);
+    if (variant == 5) return mode == 0 ? launch_scatter_wc_t<0, 1>(st, pa) : launch_scatter_wc_t<1, 1>(st, pa);
+    if (mode == 0) {
+        switch (variant) {
+        case 1: return launch_scatter_t<0, 1024, 4>(st, pa);
+        case 2: return launch_scatter_t<0, 512, 2>(st, pa);
+        case 3: return launch_scatter_t<0, 1024, 2>(st, pa);
+        default: return launch_scatter_t<0, 512, 4>(st, pa);
+        }
+    }
+    switch (variant) {
+    case 1: return launch_scatter_t<1, 1024, 4>(st, pa);
+    case 2: return launch_scatter_t<1, 512, 2>(st, pa);
+    case 3: return launch_scatter_t<1, 1024, 2>(st, pa);
+    default: return launch_scatter_t<1, 512, 4>(st, pa);
+    }
 }
 
 hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,

@@ -77,8 +77,10 @@ class HashJoin:
         self.close()
 
     def set_stream(self, stream):
-        """stream: a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        self._ck(self._L.hj_set_stream(self._h, C.c_void_p(stream) if stream else None))
+        """stream: a raw hipStream_t value, e.g. torch.cuda.current_stream().cuda_stream (0 = HIP's
+        default stream); None = back to the context's private stream."""
+        own = C.c_void_p(-1 & (2 ** 64 - 1))  # HJ_OWN_STREAM
+        self._ck(self._L.hj_set_stream(self._h, own if stream is None else C.c_void_p(int(stream))))
 
     def configure(self, bits1=0, bits2=0, force_bits=False, build_side=0, lds_capacity=0, lds_heads=0,
                   probe_chunk=0):

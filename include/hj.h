@@ -66,7 +66,11 @@ typedef struct hj_kernel_time {
 int hj_create(hj_ctx **out, int device);            /* hipSetDevice(device), stream, small workspace */
 int hj_destroy(hj_ctx *ctx);                        /* frees every buffer the library allocated */
 const char *hj_error(const hj_ctx *ctx);            /* message of the last failing call */
-int hj_set_stream(hj_ctx *ctx, void *hip_stream);   /* run on a caller-owned hipStream_t (NULL = own stream) */
+/* Run on a caller-owned hipStream_t.  NULL is HIP's default (null) stream — what
+ * torch.cuda.current_stream().cuda_stream is unless the caller made its own; HJ_OWN_STREAM goes back
+ * to the context's private stream. */
+#define HJ_OWN_STREAM ((void *)(intptr_t)-1)
+int hj_set_stream(hj_ctx *ctx, void *hip_stream);
 int hj_configure(hj_ctx *ctx, const hj_config *cfg);
 int hj_get_config(const hj_ctx *ctx, hj_config *cfg); /* the effective values after defaults/auto */
 int hj_sync(hj_ctx *ctx);                           /* [sync] */
