@@ -24,26 +24,51 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(log2n, seconds_budget=25.0):
+def cpu_baseline(pkg, hj, torch, dev, max_log2n, budget_s=20.0):
     """The oracle's OpenMP radix join ("port") on a bounded sample of the same workload shape, on
-    this box's host cores.  Only this leg touches oracle/."""
-    import numpy as np
+    this box's host cores.  Only this leg touches oracle/.  The sample size is calibrated so that the
+    join takes about budget_s seconds (at most the full 2^max_log2n workload)."""
+    import psutil
     from oracle import pyoracle as o
     threads = o.max_threads()
+
+    def sample(log2n):
+        n = 1 << log2n
+        k = torch.empty(n, dtype=torch.int32, device=dev)
+        hj.gen_unique(k, n, 0, n, 1)
+        hj.sync()
+        R = k.cpu().numpy()
+        hj.gen_unique(k, n, 0, n, 2)
+        hj.sync()
+        S = k.cpu().numpy()
+        del k
+        return R, S
+
+    def run(log2n):
+        R, S = sample(log2n)
+        bits = max(0, log2n - 12)
+        b2 = bits // 2
+        t0 = time.perf_counter()
+        m, _ = o.radix_join_omp(R, None, S, None, bits - b2, b2, threads)
+        dt = time.perf_counter() - t0
+        assert m == (1 << log2n), (m, log2n)
+        return dt
+
+    dt = run(24)                                   # calibration
+    rate = 2 * (1 << 24) / dt
+    log2n = 24
+    while log2n < max_log2n and 2 * (1 << (log2n + 1)) / rate <= budget_s * 1.5:
+        log2n += 1
+    while log2n > 24 and 48 * (1 << log2n) > psutil.virtual_memory().available:  # oracle peak ~ 48 B/tuple
+        log2n -= 1
+    if log2n > 24:
+        dt = run(log2n)
     n = 1 << log2n
-    rng = np.random.default_rng(7)
-    R = rng.permutation(n).astype(np.int32)
-    S = rng.permutation(n).astype(np.int32)
-    bits = max(0, log2n - 12)
-    b2 = bits // 2
-    t0 = time.perf_counter()
-    m, _ = o.radix_join_omp(R, None, S, None, bits - b2, b2, threads)
-    dt = time.perf_counter() - t0
-    assert m == n, (m, n)
     return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port",
-            "sample": "2^%d ⋈ 2^%d unique uniform int32 (same shape as the GPU workload, smaller), oracle "
-                      "o_radix_join_omp two-pass radix + chained build/probe, %d OpenMP threads, %.1f s" %
-                      (log2n, log2n, threads, dt)}
+            "sample": "2^%d x 2^%d unique uniform int32 (the GPU workload's generator and shape%s), oracle "
+                      "o_radix_join_omp: two-pass OpenMP radix partition + per-partition chained build/probe, "
+                      "%d threads, %.1f s" % (log2n, log2n, ", full size" if log2n == max_log2n else ", bounded sample",
+                                               threads, dt)}
 
 
 def main():
@@ -52,7 +77,6 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
-    ap.add_argument("--cpu-log2n", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     a = ap.parse_args()
@@ -125,16 +149,27 @@ def main():
 
     # roofline of the dominant kernel: the radix scatter (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
-    sc = kt.get("k_scatter", {"launches": 0, "total_ms": 0.0})
+    dom = max(("k_scatter_wc", "k_scatter"), key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
+    sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
     roof = None
-    if sc["launches"]:
+    if sc["launches"] and world == 1:
         launches_per_step = sc["launches"] / a.steps
-        tuples_per_launch = 2.0 * n * (launches_per_step / 2.0) / launches_per_step if world == 1 else float(n)
-        tuples_per_launch = float(n)  # every scatter launch moves one whole local relation
+        tuples_per_launch = float(n)  # every scatter launch moves one whole relation (keys + payloads)
         avg_ms = sc["total_ms"] / sc["launches"]
         achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_scatter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/): separate
+        # --pmc runs for FETCH_SIZE and WRITE_SIZE, KB units, FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH §HBM)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_2p30.json")))["kernels"]
+            key = [k for k in pm if k.startswith("hj::" + dom + "<0")]
+            if key and a.log2n == 30:
+                traffic = pm[key[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r1_pmc_2p30.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch}
     kernels = {k: {"launches_per_step": v["launches"] / a.steps, "ms_per_step": round(v["total_ms"] / a.steps, 4)}
@@ -177,7 +212,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.cpu_log2n)
+        cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
 
     if rank == 0:
         cfg = hj.config()

@@ -236,7 +236,7 @@ int run_pass(hj_ctx *c, int mode, const int32_t *in_k, const int32_t *in_p, uint
         // wide fan-out: LDS write-combining lines (aligned 128-B stores); narrow fan-out (shard split, small
     // inputs): the sorted-tile kernel, whose runs are long anyway.  HJ_SCATTER_VARIANT overrides (experiments).
     const int variant = c->scatter_variant >= 0 ? c->scatter_variant : (P >= 64 ? 4 : 1);
-    { Timed t(c, "k_scatter"); HIPCHK(c, launch_scatter(st, mode, variant, pa)); }
+    { Timed t(c, variant >= 4 ? "k_scatter_wc" : "k_scatter"); HIPCHK(c, launch_scatter(st, mode, variant, pa)); }
     return 0;
 }
 
