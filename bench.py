@@ -71,12 +71,49 @@ def cpu_baseline(pkg, hj, torch, dev, max_log2n, budget_s=20.0):
                                                threads, dt)}
 
 
+def bench_zipf(a, pkg, torch, dev, local):
+    """BASELINE configs[3]: PK-FK 2^27 x 2^31, Zipf(1.0) foreign keys, one GPU.  Reported in DESIGN.md;
+    not the headline line."""
+    nR, nS = 1 << 27, 1 << 31
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
+    Sk, Sp = (torch.empty(nS, dtype=torch.int32, device=dev) for _ in range(2))
+    hj.gen_unique(Rk, nR, 0, nR, 3)
+    hj.gen_zipf(Sk, nS, 0, nR, 1.0, 4)
+    hj.fill_payload(Rp, nR, "ones")
+    hj.fill_payload(Sp, nS, "ones")
+    hj.sync()
+    expect = nS - int((Sk == nR).sum().item())
+    hj.bind_device(pkg.REL_R, Rk, Rp)
+    hj.bind_device(pkg.REL_S, Sk, Sp)
+    for _ in range(a.warmup):
+        assert hj.join()[0] == expect
+    hj.timings_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = hj.join()[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert got == expect
+    kt = hj.timings()
+    print(json.dumps({"metric": "billion tuples/sec (build+probe), PK-FK 2^27 x 2^31 Zipf theta=1.0, 1 GPU",
+                      "value": round((nR + nS) * a.steps / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                      "config": {"workload": "PK-FK 2^27 x 2^31, Zipf(1.0) foreign keys (device generator), payload=1, count-only",
+                                 "matches": int(got), "radix_bits": [hj.config()["bits1"], hj.config()["bits2"]]},
+                      "kernels": {k: {"launches_per_step": v["launches"] / a.steps, "ms_per_step": round(v["total_ms"] / a.steps, 4)}
+                                  for k, v in kt.items() if v["launches"]}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
+    ap.add_argument("--workload", choices=["uniform", "zipf"], default="uniform",
+                    help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     a = ap.parse_args()
@@ -95,6 +132,8 @@ def main():
     pkg = graft.load_package()
     n = 1 << a.log2n
     total_n = n * world
+    if a.workload == "zipf":
+        return bench_zipf(a, pkg, torch, dev, local)
 
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
     # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key

@@ -61,6 +61,7 @@ SIGNATURES = {
     "hj_shard_split": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u64p]),
     "hj_shard_of": (C.c_uint32, [C.c_int32, C.c_uint32]),
     "hj_gen_unique": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "hj_gen_zipf": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64]),
     "hj_fill_payload": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64]),
     "hj_digest_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, u64p]),
     "hj_digest_triples": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),

@@ -626,6 +626,15 @@ int hj_gen_unique(hj_ctx *c, int32_t *d_keys, uint64_t n, uint64_t first, uint64
     return HJ_OK;
 }
 
+int hj_gen_zipf(hj_ctx *c, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta, uint64_t seed) {
+    if (!c) return HJ_EINVAL;
+    if (alphabet == 0 || alphabet >= ((uint64_t)1 << 32) - 1) return fail(c, HJ_EINVAL, "alphabet must be in [1, 2^32-2]");
+    if (!(theta >= 0.0) || theta > 8.0) return fail(c, HJ_EINVAL, "theta out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_gen_zipf(c->stream, d_keys, n, first, alphabet, theta, seed));
+    return HJ_OK;
+}
+
 int hj_fill_payload(hj_ctx *c, int32_t *d_pays, uint64_t n, int mode, uint64_t first_rowid) {
     if (!c) return HJ_EINVAL;
     if (mode != HJ_PAYLOAD_ONES && mode != HJ_PAYLOAD_ROWID) return fail(c, HJ_EINVAL, "bad payload_mode");

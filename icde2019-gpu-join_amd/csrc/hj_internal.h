@@ -72,6 +72,7 @@ hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bo
 hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out);
 hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first);
 hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
+hipError_t launch_gen_zipf(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta, uint64_t seed);
 hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, const int32_t *c, uint64_t n, uint64_t *out);
 hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *off,
                                     uint32_t nparts, uint64_t *misplaced, uint64_t *digests);

@@ -733,6 +733,57 @@ __global__ void k_gen_unique(int32_t *__restrict__ keys, uint64_t n, uint64_t fi
     }
 }
 
+// Zipf(theta) ranks over an alphabet of N values, mapped through the k_gen_unique bijection and shifted
+// by +1 (the reference's gen_zipf draws from an alphabet 1..N permuted at random, gen.cu:236-258,
+// 299-348).  The reference builds a 2^27-entry cumulative table on the host and binary-searches it per
+// tuple; here the cumulative mass H(k) = sum_{i<=k} i^-theta is exact for k <= 64 (small table in
+// registers/LDS) and the Euler-Maclaurin closed form beyond, inverted by bisection — a synthetic skew
+// generator with the same head probabilities (rank 1 holds 1/H(N) of the draws), not the reference's
+// exact stream.
+__device__ __forceinline__ double zipf_H(double k, double theta, const double *__restrict__ head, double c_tail) {
+    // c_tail = head[63] - closed(64): makes the closed form continuous with the exact head at k = 64
+    if (k <= 64.0) return head[(int)k - 1];
+    double closed = (fabs(theta - 1.0) < 1e-9) ? log(k) : (pow(k, 1.0 - theta) - 1.0) / (1.0 - theta);
+    return closed + 0.5 * pow(k, -theta) + c_tail;
+}
+__global__ __launch_bounds__(256) void k_gen_zipf(int32_t *__restrict__ keys, uint64_t n, uint64_t first, uint64_t alphabet,
+                                                  double theta, uint64_t seed) {
+    __shared__ double head[64];
+    __shared__ double sh_c, sh_HN;
+    if (threadIdx.x == 0) {
+        double acc = 0;
+        for (int i = 1; i <= 64; i++) { acc += pow((double)i, -theta); head[i - 1] = acc; }
+        double closed64 = (fabs(theta - 1.0) < 1e-9) ? log(64.0) : (pow(64.0, 1.0 - theta) - 1.0) / (1.0 - theta);
+        sh_c = head[63] - (closed64 + 0.5 * pow(64.0, -theta));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_HN = zipf_H((double)alphabet, theta, head, sh_c);
+    __syncthreads();
+    const double c_tail = sh_c, HN = sh_HN;
+    uint32_t kb = 1;
+    while (((uint64_t)1 << kb) < alphabet) kb++;
+    const uint64_t mask = (((uint64_t)1 << kb) - 1);
+    const uint64_t s0 = fmix64(seed ^ 0xABCDEF01ULL), s1 = fmix64(s0 + 1), s2 = fmix64(s1 + 2), s3 = fmix64(s2 + 3);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = fmix64((first + i) * 0x9E3779B97F4A7C15ULL ^ seed);
+        const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0) * HN; // target cumulative mass
+        // smallest rank k with H(k) >= u
+        uint64_t lo = 1, hi = alphabet;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (zipf_H((double)mid, theta, head, c_tail) >= u) hi = mid; else lo = mid + 1;
+        }
+        uint64_t x = lo - 1; // rank-1 in [0, alphabet) -> pseudo-random value of the alphabet
+        do {
+            x = perm_round(x, mask, kb, s0, s1 >> 7);
+            x = perm_round(x, mask, kb, s1, s2 >> 9);
+            x = perm_round(x, mask, kb, s2, s3 >> 11);
+            x = perm_round(x, mask, kb, s3, s0 >> 13);
+        } while (x >= alphabet);
+        keys[i] = (int32_t)(uint32_t)(x + 1);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_digest(const int32_t *__restrict__ a, const int32_t *__restrict__ b,
                                                 const int32_t *__restrict__ c, uint64_t n,
                                                 unsigned long long *__restrict__ out) {
@@ -942,6 +993,14 @@ hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t
     if (!n) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_gen_unique, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, keys, n, first, domain, seed);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gen_zipf(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta, uint64_t seed) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_gen_zipf, dim3((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, keys, n, first, alphabet, theta, seed);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

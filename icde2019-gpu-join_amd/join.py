@@ -210,6 +210,9 @@ class HashJoin:
     def gen_unique(self, d_keys, n, first, domain, seed):
         self._ck(self._L.hj_gen_unique(self._h, _dev_ptr(d_keys), n, first, domain, seed))
 
+    def gen_zipf(self, d_keys, n, first, alphabet, theta, seed):
+        self._ck(self._L.hj_gen_zipf(self._h, _dev_ptr(d_keys), n, first, alphabet, theta, seed))
+
     def fill_payload(self, d_pays, n, payload="ones", first_rowid=0):
         self._ck(self._L.hj_fill_payload(self._h, _dev_ptr(d_pays), n, _PAYLOAD[payload], first_rowid))
 

@@ -128,6 +128,10 @@ uint32_t hj_shard_of(int32_t key, uint32_t nshards);
  * of a pseudo-random permutation of 0..domain-1 when first+n <= domain; beyond the domain it wraps
  * (first + i) mod domain. (async) */
 int hj_gen_unique(hj_ctx *ctx, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
+/* keys[i] = 1 + pi_seed(rank_i - 1), rank_i ~ Zipf(theta) over 1..alphabet (values 1..alphabet, like
+ * gen_zipf src/generator_ETHZ.cu:299-348; same head probabilities, not the same random stream). (async) */
+int hj_gen_zipf(hj_ctx *ctx, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta,
+                uint64_t seed);
 int hj_fill_payload(hj_ctx *ctx, int32_t *d_pays, uint64_t n, int payload_mode, uint64_t first_rowid);
 /* order-independent 64-bit digests: sum of mix(key,pay) / mix(key,payR,payS) mod 2^64.  [sync] */
 int hj_digest_pairs(hj_ctx *ctx, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint64_t *digest);

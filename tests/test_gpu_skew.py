@@ -1,0 +1,95 @@
+"""BASELINE config 4: PK-FK join with Zipf-skewed foreign keys (the skew-handling probe path).
+Reference semantics: R = perm(0..N-1), S in {1..N} by gen_zipf (src/generator_ETHZ.cu:299-348) →
+matches = M - #{S == N}; the count exceeds INT32_MAX at full size (D5)."""
+import math
+
+import numpy as np
+import pytest
+
+from hjtest import pkg, sorted_triples
+from oracle import pyoracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    return pkg()
+
+
+def test_device_zipf_generator_distribution(P):
+    import torch
+    n, alphabet, theta = 1 << 22, 1 << 16, 1.0
+    k = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    with P.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream) as hj:
+        hj.gen_zipf(k, n, 0, alphabet, theta, 5)
+        hj.sync()
+    v = k.cpu().numpy()
+    assert v.min() >= 1 and v.max() <= alphabet                 # alphabet 1..N, no zeros (gen.cu:245)
+    cnt = np.sort(np.bincount(v, minlength=alphabet + 1))[::-1].astype(np.float64)
+    HN = sum(1.0 / i for i in range(1, alphabet + 1))
+    for rank in range(1, 9):                                    # head of the distribution: p_k = 1/(k H_N)
+        p = 1.0 / (rank * HN)
+        assert abs(cnt[rank - 1] - n * p) < 6 * math.sqrt(n * p), (rank, cnt[rank - 1], n * p)
+    assert np.count_nonzero(cnt) > 0.6 * alphabet               # the tail is populated too
+
+
+@pytest.mark.parametrize("cfg", [None, dict(bits1=6, bits2=5, probe_chunk=2048), dict(build_side=2)])
+def test_config4_shape_reference_stream(P, cfg):
+    """R unique, S from the reference's own Zipf stream (product generator = reference generator)."""
+    g = P.generator
+    nR, nS = 1 << 18, 1 << 22
+    g.seed_generator(12345)
+    R = g.create_relation_unique(None, nR, nR)
+    S = g.create_relation_zipf(None, nS, nR, 1.0)
+    expect = nS - int((S == nR).sum())
+    em, eagg, echk = o.join_count(R, None, S, None, checksum=False)
+    assert em == expect
+    Pr, Ps = np.arange(nR, dtype=np.int32), np.arange(nS, dtype=np.int32)
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, S, Ps)
+        m, agg = hj.join()
+        assert m == expect
+        assert agg == o.join_count(R, Pr, S, Ps, checksum=False)[1]
+        bad, dg = hj.verify_partitions(P.REL_S, with_digests=True)
+        assert bad == 0
+        c = hj.config()
+        ok, op, ooff = o.radix_partition(S, Ps, 0, c["bits1"] + c["bits2"])
+        assert np.array_equal(dg, o.partition_digest(ok, op, ooff))    # skewed partitions hold the right multisets
+        k, pr, ps = hj.join_materialize()
+    assert len(k) == expect
+    assert np.array_equal(R[pr], k) and np.array_equal(S[ps], k)
+    assert len(np.unique(ps)) == expect                                  # every matching S tuple exactly once
+
+
+def test_config4_full_size_properties(P):
+    """2^27 ⋈ 2^31, Zipf theta = 1.0 generated on the device: 64-bit count, closed form, partition checks."""
+    import torch
+    nR, nS = 1 << 27, 1 << 31
+    dev = torch.device("cuda:0")
+    Rk = torch.empty(nR, dtype=torch.int32, device=dev)
+    Rp = torch.empty(nR, dtype=torch.int32, device=dev)
+    Sk = torch.empty(nS, dtype=torch.int32, device=dev)
+    Sp = torch.empty(nS, dtype=torch.int32, device=dev)
+    with P.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream) as hj:
+        hj.gen_unique(Rk, nR, 0, nR, 3)
+        hj.gen_zipf(Sk, nS, 0, nR, 1.0, 4)
+        hj.fill_payload(Rp, nR, "ones")
+        hj.fill_payload(Sp, nS, "ones")
+        hj.sync()
+        absent = int((Sk == nR).sum().item())          # the one alphabet value R does not hold
+        top = int(torch.bincount(Sk[: 1 << 26].long(), minlength=nR + 1).max().item())
+        assert top > 0.04 * (1 << 26)                  # heaviest key ~ 1/H_N = 5.2 % of S
+        hj.bind_device(P.REL_R, Rk, Rp)
+        hj.bind_device(P.REL_S, Sk, Sp)
+        before = hj.digest_pairs(Sk, Sp, nS)
+        m, agg = hj.join()
+        assert m == agg == nS - absent and m > 2**31 - 2**20 > 2**31 - 1 - 2**20
+        assert hj.config()["build_side"] == 1          # the PK side builds; the skewed side is split into chunks
+        bad, _ = hj.verify_partitions(P.REL_S)
+        assert bad == 0
+        k, p, off, nparts = hj.partition_pointers(P.REL_S)
+        assert hj.digest_pairs(k, p, nS) == before
