@@ -76,6 +76,8 @@ def bench_zipf(a, pkg, torch, dev, local):
     not the headline line."""
     nR, nS = 1 << 27, 1 << 31
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    if a.probe_chunk:
+        hj.configure(probe_chunk=a.probe_chunk)
     Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
     Sk, Sp = (torch.empty(nS, dtype=torch.int32, device=dev) for _ in range(2))
     hj.gen_unique(Rk, nR, 0, nR, 3)
@@ -114,6 +116,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
     ap.add_argument("--workload", choices=["uniform", "zipf"], default="uniform",
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
+    ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
+    ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     a = ap.parse_args()
@@ -136,6 +140,8 @@ def main():
         return bench_zipf(a, pkg, torch, dev, local)
 
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    if a.bits or a.probe_chunk:
+        hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk)
     # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
     # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
     domain = min(total_n, 1 << 32)

@@ -22,7 +22,7 @@ namespace {
 
 constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-byte tail loads)
 constexpr uint32_t TARGET_SPANS = 2048;
-constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 8192;
+constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 65536;
 constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
 
 struct KStat { std::string name; uint32_t launches = 0; float total_ms = 0, last_ms = 0; };

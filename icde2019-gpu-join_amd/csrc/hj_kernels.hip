@@ -112,6 +112,31 @@ __device__ __forceinline__ int32_t elem(const int4 &v, int e) {
     return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
 }
 
+// Returning "count me in" on an LDS counter, skew-aware: when at least 16 lanes of the wave carry the
+// same digit as the wave's first valid lane (a heavy hitter), those lanes are served by ONE atomic add
+// of their number and ranked by a ballot; everybody else adds 1 for itself.  Must be called by all 64
+// lanes of the wave (valid = this lane has a tuple).  Same-address LDS atomics serialise per lane.
+__device__ __forceinline__ uint32_t rank_in_digit(uint32_t *cnt, uint32_t d, bool valid) {
+    const uint64_t vmask = __ballot(valid);
+    uint32_t r = 0;
+    if (vmask) {
+        const int first = __builtin_ctzll(vmask);
+        const uint32_t lead = (uint32_t)__shfl((int)d, first, 64);
+        const bool same = valid && d == lead;
+        const uint64_t smask = __ballot(same);
+        if (__popcll(smask) >= 16) {
+            uint32_t base = 0;
+            if ((int)lane_id() == first) base = atomicAdd(&cnt[lead], (uint32_t)__popcll(smask));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (same) r = base + (uint32_t)__popcll(smask & (((uint64_t)1 << lane_id()) - 1));
+            else if (valid) r = atomicAdd(&cnt[d], 1u);
+        } else if (valid) {
+            r = atomicAdd(&cnt[d], 1u);
+        }
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // partition pass: plan → histogram → scan → offsets → scatter
 // ------------------------------------------------------------------------------------------------
@@ -172,12 +197,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
     for (uint32_t d = threadIdx.x; d < P; d += PART_THREADS) h[d] = 0;
     __syncthreads();
     const uint64_t a0 = si.lo & ~(uint64_t)3;
-    for (uint64_t i = a0 + (uint64_t)threadIdx.x * 4; i < si.hi; i += (uint64_t)PART_THREADS * 4) {
-        int4 v = load4(keys, i, nalloc);
+    // wave-uniform trip count (rank_in_digit needs the whole wave)
+    for (uint64_t w0 = a0 + (uint64_t)(threadIdx.x & ~63u) * 4; w0 < si.hi; w0 += (uint64_t)PART_THREADS * 4) {
+        const uint64_t i = w0 + (uint64_t)lane_id() * 4;
+        int4 v = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             uint64_t idx = i + e;
-            if (idx >= si.lo && idx < si.hi) atomicAdd(&h[digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n)], 1u);
+            const bool valid = idx >= si.lo && idx < si.hi;
+            (void)rank_in_digit(h, digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n), valid);
         }
     }
     __syncthreads();
@@ -371,49 +399,48 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
 
 // Scatter one span through per-digit LDS WRITE-COMBINING buffers (the software write-combining idea
 // of the reference's CPU partitioner, partition-primitives.cu:40-125, re-expressed in LDS): every
-// digit owns one 128-byte line of keys and one of payloads (32 tuples) in LDS; tuples are appended
-// to their digit's line, and a line leaves the CU only when it is full — as one aligned 128-B store
-// of 32 lanes.  On MI355X aligned full-line scatter stores run at ~5 TB/s while the same bytes in
+// digit owns 128-byte lines of keys and of payloads (32 tuples each) in LDS; tuples are appended to
+// their digit's line, and a line leaves the CU only when it is full — as one aligned 128-B store of
+// 32 lanes.  On MI355X aligned full-line scatter stores run at ~5 TB/s while the same bytes in
 // unaligned runs run at 1-2.5 TB/s (scratch/ubench_store.hip), and that is the whole point.
 //
 // The span's private output run of digit d starts at g0 = hist-scan position (any alignment).  The
-// LDS line of d mirrors the 128-B line of the output that is currently being filled: slot s of the
-// line is output position line[d] + s, line[d] % 32 == 0.  Per round of 4096 tuples (1024 threads x
-// one 16-byte load): (1) rank every tuple inside its digit with one returning LDS atomic;
-// (2) tuples that fall into the current line are stored to LDS, tuples beyond the lines that fill up
-// this round are kept in registers, tuples in between (only when a digit receives more than a line
-// per round: skew) go straight to HBM; (3) every digit whose line filled up is flushed by one wave
-// (lanes 0-31 the key line, lanes 32-63 the payload line); (4) the kept tuples start the next line.
-// No retry loops: the cost of a round does not depend on the key distribution.
+// LDS lines of d mirror the 128-B lines of the output that are currently being filled: slot s is
+// output position line[d] + s, line[d] % 32 == 0.  Per round of 8192 tuples (1024 threads x two
+// 16-byte loads): (A) rank every tuple inside its digit with one returning LDS atomic; (B) tuples
+// that fall into lines that fill up this round are stored to LDS, the remainder is kept in registers
+// and opens the next line one phase later; (C) every full line is flushed by one wave (lanes 0-31 the
+// key line, lanes 32-63 the payload line).  3 barriers per round, no retry loops.
+//
+// Lines per digit: K = 512 / fan-out, i.e. room for twice the expected arrivals of a round at any
+// fan-out.  Skew: the span's own histogram (already in HBM from k_hist) tells which digits expect
+// more than that; at span start up to WC_EXTRA spare lines are handed to them in proportion, and a
+// span dominated by one digit switches the rank atomic to its wave-aggregated form.  Such spans take
+// the general code path (SKEW=true); all others take a lean path with no per-digit line table, and
+// the 512-way case (K = 1) is additionally compiled with its constants folded — the kernel is
+// instruction-sensitive (1 workgroup per CU), measured +33 % when every span ran the general path.
+// What still exceeds a digit's lines goes straight to HBM (correct, just slower).
 // Algorithmic traffic: 8 B read + 8 B written per tuple.
 constexpr int WC_THREADS = 1024;
-constexpr int WC_LINE = 32; // tuples per 128-byte line
+constexpr int WC_LINE = 32;   // tuples per 128-byte line
+constexpr int WC_EXTRA = 64;  // spare lines for heavy digits
+constexpr int WC_LINES = MAX_PARTS + WC_EXTRA;
 
-template <int MODE, int U>
-__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                           uint64_t nalloc, const uint64_t *__restrict__ poff,
-                                                           uint32_t nparents, const uint32_t *__restrict__ span_start,
-                                                           uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                           const uint32_t *__restrict__ hist,
-                                                           const uint64_t *__restrict__ chunk_prefix,
-                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t *bufK = reinterpret_cast<int32_t *>(smem);           // [MAX_PARTS][32]
-    int32_t *bufP = bufK + MAX_PARTS * WC_LINE;                  // [MAX_PARTS][32]
-    uint32_t *hh = reinterpret_cast<uint32_t *>(bufP + MAX_PARTS * WC_LINE); // [2][MAX_PARTS] arrivals, by round parity
-    uint32_t *cur = hh + 2 * MAX_PARTS;                          // occupied slots of the current line
-    uint32_t *line = cur + MAX_PARTS;                            // output position of slot 0 (multiple of 32)
-    uint32_t *lo = line + MAX_PARTS;                             // first valid slot (non-zero only for the first line)
-    SpanInfo si;
-    if (!decode_span(poff, nparents, span_start, span, si)) return;
+struct WcLds {
+    int32_t *bufK, *bufP;                   // [WC_LINES][32] each
+    uint32_t *hh, *cur, *line, *lo, *capb;  // see k_scatter_wc
+};
+
+template <int MODE, int U, bool SKEW, int KFIX>
+__device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, const int32_t *__restrict__ keys,
+                                        const int32_t *__restrict__ pays, uint64_t nalloc, uint32_t shift, uint32_t P,
+                                        uint32_t mask_or_n, int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
+                                        bool heavy_span, uint32_t K_rt) {
+    int32_t *bufK = L_.bufK, *bufP = L_.bufP;
+    uint32_t *hh = L_.hh, *cur = L_.cur, *line = L_.line, *lo = L_.lo, *capb = L_.capb;
+    (void)capb; (void)heavy_span;
+    const uint32_t K = KFIX ? (uint32_t)KFIX : K_rt; // KFIX = 1: the 512-way case with constants folded
     const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
-    for (uint32_t d = tid; d < P; d += WC_THREADS) {
-        uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
-        uint32_t g0 = (uint32_t)((uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG]);
-        line[d] = g0 & ~(uint32_t)(WC_LINE - 1);
-        cur[d] = lo[d] = g0 & (WC_LINE - 1);
-        hh[d] = hh[MAX_PARTS + d] = 0;
-    }
     constexpr uint32_t ROUND = WC_THREADS * 4 * U;
     const uint64_t a0 = si.lo & ~(uint64_t)3;
     // 32-bit positions relative to a0 (a span is < 2^32 tuples)
@@ -428,12 +455,11 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
         pv[u] = (r < rhi) ? load4(pin, r, navail) : make_int4(0, 0, 0, 0);
     }
     int4 kk[U], pp[U];     // the previous round's tuples: the kept ones are stored one phase later
-    uint32_t keep[U * 4];  // LDS word index (d*32 + slot) of a kept tuple, 0xFFFFFFFF = none
+    uint32_t keep[U * 4];  // LDS word index of a kept tuple, 0xFFFFFFFF = none
 #pragma unroll
     for (int j = 0; j < U * 4; j++) keep[j] = 0xFFFFFFFFu;
 #pragma unroll
     for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
-    __syncthreads();
     uint32_t par = 0;
     for (uint32_t r0 = 0; r0 < rhi; r0 += ROUND, par ^= 1) {
         uint32_t *h = hh + par * MAX_PARTS, *hprev = hh + (par ^ 1) * MAX_PARTS;
@@ -460,15 +486,16 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
             const uint32_t r = r0 + (u * WC_THREADS + tid) * 4;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                code[u * 4 + e] = 0xFFFFFFFFu;
-                if (r + e >= rlo && r + e < rhi) {
-                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
-                    code[u * 4 + e] = (d << 16) | atomicAdd(&h[d], 1u);
-                }
+                const bool valid = r + e >= rlo && r + e < rhi;
+                const uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
+                uint32_t rk = 0;
+                if (SKEW && heavy_span) rk = rank_in_digit(h, d, valid); // workgroup-uniform branch
+                else if (valid) rk = atomicAdd(&h[d], 1u);
+                code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
             }
         }
         __syncthreads();
-        // ---- B: place: current line / straight to HBM / keep for the next line ----
+        // ---- B: place: lines that fill this round / keep for the next line / straight to HBM ----
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -480,12 +507,19 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
                     const uint32_t cd = cur[d];
                     const uint32_t q = cd + (c & 0xFFFFu);
                     const uint32_t full = (cd + h[d]) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
-                    if (q < WC_LINE) {
-                        bufK[d * WC_LINE + q] = elem(kv[u], e);
-                        bufP[d * WC_LINE + q] = elem(pv[u], e);
-                    } else if (q >= full) {
-                        keep[u * 4 + e] = d * WC_LINE + (q - full);
-                    } else { // more than one line for this digit in one round (skew): bypass the buffer
+                    uint32_t cap = K * WC_LINE, base = d * cap;                   // lean path: K lines per digit
+                    if (SKEW) { const uint32_t cb = capb[d]; cap = (cb >> 16) * WC_LINE; base = (cb & 0xFFFFu) * WC_LINE; }
+                    if (q >= full) {             // remainder: stays in LDS after this round's flush
+                        if (full == 0) {         // nothing is flushed: append in place
+                            bufK[base + q] = elem(kv[u], e);
+                            bufP[base + q] = elem(pv[u], e);
+                        } else {
+                            keep[u * 4 + e] = base + (q - full);
+                        }
+                    } else if (q < cap) {        // a line that fills up this round
+                        bufK[base + q] = elem(kv[u], e);
+                        bufP[base + q] = elem(pv[u], e);
+                    } else {                     // beyond the digit's lines (extreme skew): bypass the buffer
                         out_keys[line[d] + q] = elem(kv[u], e);
                         out_pays[line[d] + q] = elem(pv[u], e);
                     }
@@ -501,19 +535,48 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
             pv[u] = in ? load4(pin, r1, navail) : make_int4(0, 0, 0, 0);
         }
         __syncthreads();
-        // ---- C: flush every line that filled up: one aligned 128-B store per column.  Wave w owns
-        //         digits [32w, 32w+32): a ballot picks the full ones, the wave walks only those ----
-        for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
-            const uint32_t dl = dbase + (ln & 31u);
-            const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-            uint64_t m = __ballot(fullq);
-            const uint32_t s = ln & (WC_LINE - 1);
-            while (m) {
-                const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                if (s >= lo[d]) {
-                    if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
-                    else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+        // ---- C: flush every line that filled up: one aligned 128-B store per column.  A wave owns 32
+        //         digits: a ballot picks the ones with full lines, the wave walks only those ----
+        if (KFIX == 1 && !SKEW) {
+            for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
+                const uint32_t dl = dbase + (ln & 31u);
+                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
+                uint64_t m = __ballot(fullq);
+                const uint32_t s = ln & (WC_LINE - 1);
+                while (m) {
+                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if (s >= lo[d]) {
+                        if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
+                        else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+                    }
+                }
+            }
+        } else {
+            // At narrow fan-out (fewer than 16 groups of 32 digits) the lines of one digit are dealt to
+            // several waves (rep), so that all 16 waves flush.
+            const uint32_t groups = (P + 31) / 32;
+            const uint32_t nrep = groups >= (uint32_t)(WC_THREADS / 64) ? 1u : (uint32_t)(WC_THREADS / 64) / groups;
+            const uint32_t rep = wv / groups;
+            for (uint32_t dbase = (wv % groups) * 32; dbase < P && rep < nrep; dbase += (WC_THREADS / 64) * 32) {
+                const uint32_t dl = dbase + (ln & 31u);
+                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
+                uint64_t m = __ballot(fullq);
+                const uint32_t s = ln & (WC_LINE - 1);
+                while (m) {
+                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    uint32_t cap = K * WC_LINE, base = d * cap;
+                    if (SKEW) { const uint32_t cb = capb[d]; cap = (cb >> 16) * WC_LINE; base = (cb & 0xFFFFu) * WC_LINE; }
+                    uint32_t full = (cur[d] + h[d]) & ~(uint32_t)(WC_LINE - 1);
+                    if (full > cap) full = cap;
+                    const uint32_t first_valid = lo[d], g = line[d];
+                    for (uint32_t j = rep * WC_LINE; j < full; j += nrep * WC_LINE) {
+                        if (j + s >= first_valid) {
+                            if (ln < (uint32_t)WC_LINE) out_keys[g + j + s] = bufK[base + j + s];
+                            else out_pays[g + j + s] = bufP[base + j + s];
+                        }
+                    }
                 }
             }
         }
@@ -540,10 +603,69 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     __syncthreads();
     for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
         const uint32_t s = ln & (WC_LINE - 1);
+        const uint32_t base = SKEW ? (capb[d] & 0xFFFFu) * WC_LINE : d * K * WC_LINE;
         if (s >= lo[d] && s < cur[d]) {
-            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
-            else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[base + s];
+            else out_pays[line[d] + s] = bufP[base + s];
         }
+    }
+}
+
+template <int MODE, int U>
+__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                           uint64_t nalloc, const uint64_t *__restrict__ poff,
+                                                           uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                           uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
+                                                           const uint32_t *__restrict__ hist,
+                                                           const uint64_t *__restrict__ chunk_prefix,
+                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WcLds L_;
+    L_.bufK = reinterpret_cast<int32_t *>(smem);
+    L_.bufP = L_.bufK + WC_LINES * WC_LINE;
+    L_.hh = reinterpret_cast<uint32_t *>(L_.bufP + WC_LINES * WC_LINE); // [2][MAX_PARTS] arrivals, by round parity
+    L_.cur = L_.hh + 2 * MAX_PARTS;   // occupied slots of the digit's lines
+    L_.line = L_.cur + MAX_PARTS;     // output position of slot 0 (multiple of 32)
+    L_.lo = L_.line + MAX_PARTS;      // first valid slot (non-zero only for the first line)
+    L_.capb = L_.lo + MAX_PARTS;      // (number of lines << 16) | first line of the digit   (SKEW path)
+    SpanInfo si;
+    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
+    // ---- span start: output cursors, and spare lines for the digits this span's histogram marks heavy ----
+    uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
+    const uint32_t K = (uint32_t)MAX_PARTS / P; // lines per digit: 2x the expected arrivals of a round
+    const uint64_t L = (uint64_t)span_start[nparents] * P;
+    uint32_t extra = 0, cnt = 0;
+    if (tid < P) {
+        const uint64_t idx = (uint64_t)si.first * P + (uint64_t)tid * si.nsp + si.s;
+        const uint64_t g0 = (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG];
+        const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : poff[nparents];
+        cnt = (uint32_t)(g1 - g0);
+        L_.line[tid] = (uint32_t)g0 & ~(uint32_t)(WC_LINE - 1);
+        L_.cur[tid] = L_.lo[tid] = (uint32_t)g0 & (WC_LINE - 1);
+        // lines needed for the expected arrivals per round with 30 % headroom, beyond the K every digit has
+        const uint64_t len = si.hi - si.lo;
+        const uint32_t need = (uint32_t)(((uint64_t)cnt * ROUND * 13 / 10) / (len ? len : 1)) / WC_LINE + 1;
+        extra = need > K ? need - K : 0;
+    }
+    uint32_t total_extra, any_heavy, dummy;
+    (void)block_excl_scan<uint32_t>(extra, scratch, &total_extra);
+    if (total_extra > (uint32_t)WC_EXTRA) extra = extra * WC_EXTRA / total_extra;
+    const uint32_t ex = block_excl_scan<uint32_t>(extra, scratch, &dummy);
+    // a span whose tuples mostly share one digit: same-address LDS atomics would serialise per lane
+    const uint32_t heavy = (tid < P && (uint64_t)cnt * 4 > (si.hi - si.lo)) ? 1u : 0u;
+    (void)block_excl_scan<uint32_t>(heavy, scratch, &any_heavy);
+    if (tid < P) L_.capb[tid] = ((K + extra) << 16) | (tid * K + ex);
+    __syncthreads();                     // scratch (aliases hh) is no longer read
+    for (uint32_t d = tid; d < 2 * MAX_PARTS; d += WC_THREADS) L_.hh[d] = 0;
+    __syncthreads();
+    // block_excl_scan hands the workgroup totals to every thread: the branch is workgroup-uniform
+    if (total_extra == 0 && any_heavy == 0) {
+        if (K == 1) wc_span<MODE, U, false, 1>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, false, K);
+        else wc_span<MODE, U, false, 0>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, false, K);
+    } else {
+        wc_span<MODE, U, true, 0>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, any_heavy != 0, K);
     }
 }
 
@@ -895,7 +1017,7 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     return hipGetLastError();
 }
 
-size_t scatter_wc_lds_bytes() { return (size_t)MAX_PARTS * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 5; }
+size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 6; }
 
 template <int MODE, int U>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
