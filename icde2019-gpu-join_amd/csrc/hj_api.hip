@@ -199,8 +199,22 @@ void choose_bits(hj_ctx *c) {
     uint64_t nb = c->rel[c->build].n;
     uint32_t total = nb > TARGET_PART ? ceil_log2((nb + TARGET_PART - 1) / TARGET_PART) : 0;
     if (total > 18) total = 18;
-    if (total <= 9) { c->bits1 = total; c->bits2 = 0; }
-    else { c->bits2 = total / 2; c->bits1 = total - c->bits2; }
+    if (total <= 9) {
+        c->bits1 = total; c->bits2 = 0;
+    } else {
+        // two passes: the first is always 9 bits (512-way is the fan-out k_scatter_wc is fastest at: one
+        // LDS line per digit, fewest same-digit collisions in the rank atomics); a 7-bit second pass
+        // measured faster than 5-6 bits at 2^27 (bit-split sweep, profiles/r1_bits_sweep_2p27.txt)
+        c->bits1 = 9;
+        c->bits2 = total - 9;
+        if (c->bits2 < 7 && nb >= ((uint64_t)1 << 25)) c->bits2 = 7;
+    }
+    if (!g.lds_heads) { // hash-table heads ~ 2x the average build partition, power of two in [256, 4096]
+        uint64_t avg = nb >> (c->bits1 + c->bits2);
+        uint32_t nh = 256;
+        while (nh < 2 * avg && nh < DEFAULT_HEADS) nh <<= 1;
+        c->nh = nh;
+    }
 }
 
 // one radix pass: in(keys,pays) partitioned by parents → out, child offsets → coff

@@ -22,6 +22,9 @@ class ShardedJoin:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # a second communicator for the tiny control messages (split sizes, final all-reduce): its
+        # collectives are not queued behind the multi-GiB column exchanges of the data communicator
+        self.ctl = dist.new_group(ranks=list(range(self.world))) if group is None else group
         self._buf = {}
 
     def _get(self, name, n):
@@ -32,37 +35,54 @@ class ShardedJoin:
             self._buf[name] = t
         return t
 
-    def exchange(self, cols, send_counts):
+    def exchange_async(self, cols, send_counts):
         """All-to-all-v of several columns that share one split: cols = {name: tensor[sum(send_counts)]}.
-        Returns ({name: tensor}, n_received)."""
+        Returns ({name: tensor}, n_received, [work handles]); the columns are valid after work.wait()."""
         sc = torch.tensor(send_counts, dtype=torch.int64, device=self.dev)
         rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
+        dist.all_to_all_single(rc, sc, group=self.ctl)
         recv_counts = [int(x) for x in rc.tolist()]
         total = sum(recv_counts)
-        out = {}
+        out, works = {}, []
         for name, t in cols.items():
             r = self._get("recv_" + name, total)
-            dist.all_to_all_single(r[:total], t[:sum(send_counts)], recv_counts, list(send_counts), group=self.group)
+            works.append(dist.all_to_all_single(r[:total], t[:sum(send_counts)], recv_counts, list(send_counts),
+                                                group=self.group, async_op=True))
             out[name] = r
+        return out, total, works
+
+    def exchange(self, cols, send_counts):
+        out, total, works = self.exchange_async(cols, send_counts)
+        for w in works:
+            w.wait()
         return out, total
 
     def join(self, Rk, Rp, Sk, Sp):
-        """Local slices of R and S (int32 device columns) → (global matches, global sum payR*payS mod 2^64)."""
+        """Local slices of R and S (int32 device columns) → (global matches, global sum payR*payS mod 2^64).
+
+        Pipeline: split R | exchange R ‖ split S | exchange S ‖ partition R | partition S | build+probe.
+        The column exchanges are asynchronous on the data communicator; xGMI moves them while the CUs
+        run the next local step (an exchange needs ~150 GB/s per link, the local passes need HBM)."""
         e, w = self.e, self.world
-        recv = {}
-        for tag, k, p in (("R", Rk, Rp), ("S", Sk, Sp)):
-            n = int(k.numel())
-            ok, op = self._get("split_k" + tag, n), self._get("split_p" + tag, n)
-            counts = e.shard_split(k, p, n, w, ok, op)           # level-0 radix split, contiguous per owner
-            got, total = self.exchange({"k" + tag: ok, "p" + tag: op}, counts)
-            recv[tag] = (got["k" + tag], got["p" + tag], total)
-        e.bind_device(self.pkg.REL_R, recv["R"][0], recv["R"][1], recv["R"][2])
-        e.bind_device(self.pkg.REL_S, recv["S"][0], recv["S"][1], recv["S"][2])
-        m, agg = e.join()                                         # unchanged single-GPU path
+        nR, nS = int(Rk.numel()), int(Sk.numel())
+        okR, opR = self._get("split_kR", nR), self._get("split_pR", nR)
+        cR = e.shard_split(Rk, Rp, nR, w, okR, opR)              # level-0 radix split, contiguous per owner
+        gotR, totR, workR = self.exchange_async({"kR": okR, "pR": opR}, cR)
+        okS, opS = self._get("split_kS", nS), self._get("split_pS", nS)
+        cS = e.shard_split(Sk, Sp, nS, w, okS, opS)              # runs while R is on the links
+        gotS, totS, workS = self.exchange_async({"kS": okS, "pS": opS}, cS)
+        for wk in workR:
+            wk.wait()
+        e.bind_device(self.pkg.REL_R, gotR["kR"], gotR["pR"], totR)
+        e.bind_device(self.pkg.REL_S, gotS["kS"], gotS["pS"], totS)   # sizes fix the radix bits for both
+        e.partition(self.pkg.REL_R)                              # runs while S is on the links
+        for wk in workS:
+            wk.wait()
+        e.partition(self.pkg.REL_S)
+        m, agg = e.join_count()                                   # unchanged single-GPU build+probe
         # 64-bit results as 32-bit halves so the SUM all-reduce cannot overflow int64
         t = torch.tensor([m & 0xFFFFFFFF, m >> 32, agg & 0xFFFFFFFF, agg >> 32], dtype=torch.int64, device=self.dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
         v = [int(x) for x in t.tolist()]
         mask = (1 << 64) - 1
         return (v[0] + (v[1] << 32)) & mask, (v[2] + (v[3] << 32)) & mask

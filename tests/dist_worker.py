@@ -30,10 +30,17 @@ class OracleEngine:
         return [int((owner == s).sum()) for s in range(nshards)]
 
     def bind_device(self, rel, keys, pays, n):
-        self.rel[rel] = (keys[:n].numpy().copy(), pays[:n].numpy().copy())
+        self.rel[rel] = (keys, pays, n)      # like the real engine: the data is read at partition time
 
-    def join(self):
-        (rk, rp), (sk, sp) = self.rel[0], self.rel[1]
+    def _snap(self, rel):
+        k, p, n = self.rel[rel]
+        return k[:n].numpy().copy(), p[:n].numpy().copy()
+
+    def partition(self, rel):
+        self.rel[("part", rel)] = self._snap(rel)   # by now the exchange of this relation must be complete
+
+    def join_count(self):
+        (rk, rp), (sk, sp) = self.rel[("part", 0)], self.rel[("part", 1)]
         m, agg, _ = o.join_count(rk, rp, sk, sp, checksum=False)
         return m, agg
 
