@@ -92,8 +92,11 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        # HJ_LIB: load another build of the same ABI (A/B experiments only)
+        _lib = C.CDLL(os.environ.get("HJ_LIB", LIB_PATH), mode=C.RTLD_GLOBAL)
         for name, (res, argt) in SIGNATURES.items():
+            if "HJ_LIB" in os.environ and not hasattr(_lib, name):
+                continue  # an older build in an A/B run
             f = getattr(_lib, name)  # AttributeError if the header and the library disagree
             f.restype = res
             f.argtypes = argt
