@@ -62,6 +62,7 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
 hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa);
 size_t scatter_lds_bytes(int threads, int u);
+hipError_t set_wc_ablate(uint32_t v);
 hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
                             uint32_t *items_cnt);
 hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,

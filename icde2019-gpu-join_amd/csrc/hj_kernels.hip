@@ -421,6 +421,9 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
 // instruction-sensitive (1 workgroup per CU), measured +33 % when every span ran the general path.
 // What still exceeds a digit's lines goes straight to HBM (correct, just slower).
 // Algorithmic traffic: 8 B read + 8 B written per tuple.
+// timing-only ablation mask for experiments (HJ_WC_ABLATE; results are wrong when non-zero)
+__device__ uint32_t g_wc_ablate = 0;
+
 constexpr int WC_THREADS = 1024;
 constexpr int WC_LINE = 32;   // tuples per 128-byte line
 constexpr int WC_EXTRA = 64;  // spare lines for heavy digits
@@ -429,6 +432,7 @@ constexpr int WC_LINES = MAX_PARTS + WC_EXTRA;
 struct WcLds {
     int32_t *bufK, *bufP;                   // [WC_LINES][32] each
     uint32_t *hh, *cur, *line, *lo, *capb;  // see k_scatter_wc
+    uint32_t *wlist;                        // [16 waves][32]: full digits of each wave (flush work list)
 };
 
 template <int MODE, int U, bool SKEW, int KFIX>
@@ -440,6 +444,7 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
     uint32_t *hh = L_.hh, *cur = L_.cur, *line = L_.line, *lo = L_.lo, *capb = L_.capb;
     (void)capb; (void)heavy_span;
     const uint32_t K = KFIX ? (uint32_t)KFIX : K_rt; // KFIX = 1: the 512-way case with constants folded
+    const uint32_t abl = __builtin_amdgcn_readfirstlane(g_wc_ablate);
     const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
     constexpr uint32_t ROUND = WC_THREADS * 4 * U;
     const uint64_t a0 = si.lo & ~(uint64_t)3;
@@ -490,12 +495,13 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
                 const uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
                 uint32_t rk = 0;
                 if (SKEW && heavy_span) rk = rank_in_digit(h, d, valid); // workgroup-uniform branch
-                else if (valid) rk = atomicAdd(&h[d], 1u);
+                else if (valid) { if (abl & 8u) rk = 0; else rk = atomicAdd(&h[d], 1u); }
                 code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
             }
         }
         __syncthreads();
         // ---- B: place: lines that fill this round / keep for the next line / straight to HBM ----
+        if (!(abl & 4u))
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -530,27 +536,50 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
             kk[u] = kv[u]; pp[u] = pv[u];
             // next round's loads fly while the lines are flushed
             const uint32_t r1 = r0 + ROUND + (u * WC_THREADS + tid) * 4;
-            const bool in = r1 < rhi && r1 >= ROUND; // r1 >= ROUND: no wrap of the 32-bit position
+            const bool in = r1 < rhi && r1 >= ROUND && !(abl & 16u); // r1 >= ROUND: no wrap of the 32-bit position
             kv[u] = in ? load4(kin, r1, navail) : make_int4(0, 0, 0, 0);
             pv[u] = in ? load4(pin, r1, navail) : make_int4(0, 0, 0, 0);
         }
         __syncthreads();
         // ---- C: flush every line that filled up: one aligned 128-B store per column.  A wave owns 32
         //         digits: a ballot picks the ones with full lines, the wave walks only those ----
-        if (KFIX == 1 && !SKEW) {
+        if (abl & 2u) {
+        } else if (KFIX == 1 && !SKEW) {
+            // The wave's full digits are compacted into a small LDS list; then 8 lanes move one 128-B
+            // line with 16-byte LDS reads and 16-byte stores, i.e. one iteration flushes the key and the
+            // payload lines of EIGHT digits — no per-line chain of dependent LDS round trips.
+            uint32_t *wlist = L_.wlist + wv * 32;
             for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
                 const uint32_t dl = dbase + (ln & 31u);
                 const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-                uint64_t m = __ballot(fullq);
-                const uint32_t s = ln & (WC_LINE - 1);
-                while (m) {
-                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1;
-                    if (s >= lo[d]) {
-                        if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[d * WC_LINE + s];
-                        else out_pays[line[d] + s] = bufP[d * WC_LINE + s];
+                const uint64_t m = __ballot(fullq);
+                const uint32_t nfull = (uint32_t)__popcll(m);
+                if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = dl;
+                __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
+                const uint32_t c4 = (ln & 7u) * 4;
+                for (uint32_t t = 0; t < nfull; t += 8) {
+                    const uint32_t idx = t + (ln >> 3);
+                    if (idx < nfull) {
+                        const uint32_t d = wlist[idx];
+                        const uint32_t first_valid = lo[d], gpos = line[d] + c4;
+                        const int4 kq = *reinterpret_cast<const int4 *>(bufK + d * WC_LINE + c4);
+                        const int4 pq = *reinterpret_cast<const int4 *>(bufP + d * WC_LINE + c4);
+                        if (abl & 1u) {
+                            asm volatile("" ::"v"(kq.x), "v"(pq.x));
+                        } else if (first_valid == 0) {
+                            *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
+                            *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
+                        } else { // the span's first line of this digit starts mid-line: element-wise
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (c4 + e >= first_valid) {
+                                    out_keys[gpos + e] = elem(kq, e);
+                                    out_pays[gpos + e] = elem(pq, e);
+                                }
+                        }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
             // At narrow fan-out (fewer than 16 groups of 32 digits) the lines of one digit are dealt to
@@ -628,6 +657,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     L_.line = L_.cur + MAX_PARTS;     // output position of slot 0 (multiple of 32)
     L_.lo = L_.line + MAX_PARTS;      // first valid slot (non-zero only for the first line)
     L_.capb = L_.lo + MAX_PARTS;      // (number of lines << 16) | first line of the digit   (SKEW path)
+    L_.wlist = L_.capb + MAX_PARTS;
     SpanInfo si;
     if (!decode_span(poff, nparents, span_start, span, si)) return;
     const uint32_t tid = threadIdx.x;
@@ -1017,7 +1047,9 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     return hipGetLastError();
 }
 
-size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 6; }
+hipError_t set_wc_ablate(uint32_t v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wc_ablate), &v, sizeof v); }
+
+size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 6 + (WC_THREADS / 64) * 32 * 4; }
 
 template <int MODE, int U>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
