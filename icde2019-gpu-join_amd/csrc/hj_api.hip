@@ -43,6 +43,7 @@ struct Rel {
     const int32_t *part_k = nullptr, *part_p = nullptr;
     const uint64_t *part_off = nullptr;
     uint32_t nparts = 0;
+    uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
     bool partitioned = false;
 };
 
@@ -67,6 +68,10 @@ struct hj_ctx {
     uint32_t max_items = 0;
     size_t lds_limit = 0;
     int scatter_variant = -1;
+    bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
+    hipStream_t copy = nullptr;     // H2D of the next probe segment
+    Buf seg_k[2], seg_p[2];         // double-buffered probe segments
+    hipEvent_t seg_ready[2] = {};
     // timing
     bool events = true;
     std::vector<KStat> kstats;
@@ -185,7 +190,7 @@ uint32_t ceil_log2(uint64_t x) {
 void choose_bits(hj_ctx *c) {
     const hj_config &g = c->cfg;
     uint64_t nR = c->rel[0].n, nS = c->rel[1].n;
-    if (g.build_side == 1) c->build = HJ_REL_R;
+    if (c->force_build_r || g.build_side == 1) c->build = HJ_REL_R;
     else if (g.build_side == 2) c->build = HJ_REL_S;
     else c->build = (nS < nR) ? HJ_REL_S : HJ_REL_R;
     c->cap = g.lds_capacity ? g.lds_capacity : DEFAULT_CAP;
@@ -284,8 +289,9 @@ int check_rel(hj_ctx *c, int rel) {
     return 0;
 }
 
-void invalidate(hj_ctx *c) {
-    c->rel[0].partitioned = c->rel[1].partitioned = false;
+void invalidate(hj_ctx *c, int rel = -1) {
+    if (rel < 0) c->rel[0].partitioned = c->rel[1].partitioned = false;
+    else c->rel[rel].partitioned = false;
     c->join_planned = false;
 }
 
@@ -299,6 +305,7 @@ int partition_rel(hj_ctx *c, int r) {
     const uint32_t b1 = c->bits1, b2 = c->bits2;
     if (b1 == 0) { // nothing to partition: one partition = the input itself
         R.part_k = R.in_k; R.part_p = R.in_p; R.part_off = (const uint64_t *)R.root.p; R.nparts = 1;
+        R.pb1 = R.pb2 = 0;
         R.partitioned = true;
         c->join_planned = false;
         return 0;
@@ -328,6 +335,7 @@ int partition_rel(hj_ctx *c, int r) {
     R.part_k = (const int32_t *)R.b_k.p;
     R.part_p = (const int32_t *)R.b_p.p;
     R.part_off = (const uint64_t *)R.off2.p;
+    R.pb1 = b1; R.pb2 = b2;
     R.partitioned = true;
     c->join_planned = false;
     return 0;
@@ -420,6 +428,7 @@ int partition_both(hj_ctx *c) {
         R.part_p = (const int32_t *)R.b_p.p;
         R.part_off = (const uint64_t *)R.off2.p;
         R.nparts = b2 ? P1 * P2 : P1;
+        R.pb1 = b1; R.pb2 = b2;
         R.partitioned = true;
     }
     c->join_planned = false;
@@ -430,10 +439,12 @@ int partition_both(hj_ctx *c) {
 int run_count(hj_ctx *c, JoinArgs &a, bool &tag16) {
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
-    if (B.nparts != Pb.nparts) return fail(c, HJ_EINVAL, "relations partitioned with different fan-out");
+    if (B.nparts != Pb.nparts || B.pb1 != Pb.pb1 || B.pb2 != Pb.pb2)
+        return fail(c, HJ_EINVAL, "relations were partitioned with different radix bits (%u+%u vs %u+%u): partition both after loading both",
+                    B.pb1, B.pb2, Pb.pb1, Pb.pb2);
     hipStream_t st = c->stream;
     const uint32_t nparts = B.nparts;
-    const uint32_t rbits = c->bits1 + c->bits2;
+    const uint32_t rbits = B.pb1 + B.pb2;
     tag16 = (32 - rbits) <= 16; // the tag shortcut of jp.cu:1029 is exact only then (D2)
     const uint64_t max_items64 = (uint64_t)nparts + Pb.n / c->chunk + 1;
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
@@ -540,6 +551,8 @@ int hj_destroy(hj_ctx *c) {
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
+    if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
     release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars);
@@ -606,7 +619,7 @@ int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, u
     R.in_p = (const int32_t *)R.own_p.p;
     R.n = n;
     R.bound = true;
-    invalidate(c);
+    invalidate(c, rel);
     return HJ_OK;
 }
 
@@ -616,7 +629,7 @@ int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_p
     if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
     Rel &R = c->rel[rel];
     R.in_k = d_keys; R.in_p = d_pays; R.n = n; R.bound = true;
-    invalidate(c);
+    invalidate(c, rel);
     return HJ_OK;
 }
 
@@ -690,6 +703,76 @@ int hj_memcpy_h2d(hj_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
     if (!c) return HJ_EINVAL;
     if (bytes) HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64_t n, uint64_t segment_tuples,
+                         int payload_mode, uint64_t *matches, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    if (n && !h_keys) return fail(c, HJ_EINVAL, "keys == NULL");
+    if (payload_mode == HJ_PAYLOAD_GIVEN && n && !h_pays) return fail(c, HJ_EINVAL, "payload_mode GIVEN needs a payload column");
+    if (payload_mode < HJ_PAYLOAD_ONES || payload_mode > HJ_PAYLOAD_GIVEN) return fail(c, HJ_EINVAL, "bad payload_mode");
+    Rel &R = c->rel[HJ_REL_R];
+    if (!R.bound) return fail(c, HJ_EINVAL, "load or bind R before streaming S");
+    HIPCHK(c, hipSetDevice(c->device));
+    // segment size: the reference cuts S into |R|/4 (hjcp.cu:1697-1698, an 8 GB card); with HBM to spare a
+    // segment is at least 2^24 tuples so that the copies are long and the passes efficient
+    uint64_t seg = segment_tuples ? segment_tuples : (R.n / 4 > ((uint64_t)1 << 24) ? R.n / 4 : ((uint64_t)1 << 24));
+    if (seg > n && n) seg = n;
+    if (seg == 0) seg = 1;
+    if (!c->copy) HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        if (!c->seg_ready[i]) HIPCHK(c, hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming));
+        RET(ensure(c, c->seg_k[i], (size_t)(seg + PAD) * 4));
+        RET(ensure(c, c->seg_p[i], (size_t)(seg + PAD) * 4));
+    }
+    const bool saved_force = c->force_build_r;
+    c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
+    // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
+    c->rel[HJ_REL_S].in_k = (const int32_t *)c->seg_k[0].p;
+    c->rel[HJ_REL_S].in_p = (const int32_t *)c->seg_p[0].p;
+    c->rel[HJ_REL_S].n = seg; c->rel[HJ_REL_S].bound = true;
+    invalidate(c, HJ_REL_S);
+    int rc = 0;
+    choose_bits(c);
+    if (!R.partitioned || R.pb1 != c->bits1 || R.pb2 != c->bits2) rc = partition_rel(c, HJ_REL_R);
+    uint64_t tot_m = 0, tot_a = 0;
+    const uint64_t nseg = n ? (n + seg - 1) / seg : 0;
+    auto issue_copy = [&](uint64_t i) -> int {
+        const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
+        const int b = (int)(i & 1);
+        HIPCHK(c, hipMemcpyAsync(c->seg_k[b].p, h_keys + off, cnt * 4, hipMemcpyHostToDevice, c->copy));
+        if (payload_mode == HJ_PAYLOAD_GIVEN)
+            HIPCHK(c, hipMemcpyAsync(c->seg_p[b].p, h_pays + off, cnt * 4, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(c, hipEventRecord(c->seg_ready[b], c->copy));
+        return 0;
+    };
+    if (!rc && nseg) rc = issue_copy(0);
+    for (uint64_t i = 0; i < nseg && !rc; i++) {
+        const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
+        const int b = (int)(i & 1);
+        // the other buffer is free: the segment that used it was joined (and synchronised) last iteration
+        if (i + 1 < nseg) { rc = issue_copy(i + 1); if (rc) break; }
+        hipError_t e = hipStreamWaitEvent(c->stream, c->seg_ready[b], 0);
+        if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
+        if (payload_mode != HJ_PAYLOAD_GIVEN) {
+            e = launch_fill(c->stream, (int32_t *)c->seg_p[b].p, cnt, payload_mode, off); // row ids are global
+            if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "fill: %s", hipGetErrorString(e)); break; }
+        }
+        Rel &S = c->rel[HJ_REL_S];
+        S.in_k = (const int32_t *)c->seg_k[b].p; S.in_p = (const int32_t *)c->seg_p[b].p; S.n = cnt; S.bound = true;
+        invalidate(c, HJ_REL_S);
+        if ((rc = partition_rel(c, HJ_REL_S))) break;
+        uint64_t m = 0, a = 0;
+        if ((rc = hj_join_count(c, &m, &a))) break; // [sync]: the next copy is already in flight
+        tot_m += m; tot_a += a;
+    }
+    c->force_build_r = saved_force;
+    c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation
+    invalidate(c, HJ_REL_S);
+    if (rc) return rc;
+    if (matches) *matches = tot_m;
+    if (agg) *agg = tot_a;
     return HJ_OK;
 }
 

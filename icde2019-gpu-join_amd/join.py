@@ -125,6 +125,17 @@ class HashJoin:
         self._ck(self._L.hj_join(self._h, C.byref(m), C.byref(a)))
         return m.value, a.value
 
+    def join_stream_probe(self, S, Ps=None, payload="ones", segment_tuples=0):
+        """S stays on the host and is streamed through HBM in segments (hjcp.cu:1684-1984); R must be loaded."""
+        S, kp = _host_i32(S)
+        mode = _PAYLOAD[payload] if Ps is None else PAYLOAD_GIVEN
+        pp = None
+        if Ps is not None:
+            Ps, pp = _host_i32(Ps)
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_stream_probe(self._h, kp, pp, len(S), segment_tuples, mode, C.byref(m), C.byref(a)))
+        return m.value, a.value
+
     def join_materialize_into(self, d_key, d_payR, d_payS, cap):
         n = C.c_uint64()
         self._ck(self._L.hj_join_materialize(self._h, _dev_ptr(d_key), _dev_ptr(d_payR), _dev_ptr(d_payS), cap,

@@ -100,6 +100,14 @@ int hj_join_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d
 /* One call = hj_partition(R) + hj_partition(S) + hj_join_count (the timed region hjcp.cu:881-933). [sync] */
 int hj_join(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
 
+/* ---- streaming probe side (outOfGPU_Join3_payload, hjcp.cu:1684-1984): S stays in HOST memory and is
+ *      streamed through HBM in segments — H2D copy of segment i+1 on a copy stream while segment i is
+ *      partitioned and joined against R, which is partitioned once.  R must be loaded/bound first and always
+ *      builds.  segment_tuples = 0 picks max(|R|/4, 2^24) (the reference uses |R|/4, hjcp.cu:1697-1698).
+ *      Row-id payloads count from 0 over the whole of S.  Count-only.  [sync] ---- */
+int hj_join_stream_probe(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pays, uint64_t n,
+                         uint64_t segment_tuples, int payload_mode, uint64_t *matches, uint64_t *agg);
+
 /* ---- plain device-memory helpers for callers without a HIP runtime binding of their own ---- */
 int hj_device_malloc(hj_ctx *ctx, void **d_ptr, uint64_t bytes);
 int hj_device_free(hj_ctx *ctx, void *d_ptr);

@@ -19,7 +19,7 @@ for _ in range(4): hj.partition(0)
 t = hj.timings()
 print("ABL", os.environ.get("HJ_WC_ABLATE", "0"), round(t["k_scatter_wc"]["total_ms"] / t["k_scatter_wc"]["launches"], 3), round(t["k_hist"]["total_ms"]/t["k_hist"]["launches"], 3))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for abl in [0, 1, 2, 4, 6, 8, 14, 16, 30, 0]:
+for abl in [0, 2, 6, 0]:
     env = dict(os.environ, HJ_WC_ABLATE=str(abl))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])

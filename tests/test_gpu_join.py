@@ -260,3 +260,34 @@ def test_large_unique_properties(P, logn):
         exp_digest = hj.digest_triples(Rk, Rp, inv[Rk.long()].int(), n)
         assert hj.digest_triples(ok, opr, ops, n) == exp_digest
         assert torch.equal(Rk[opr.long()], ok) and torch.equal(Sk[ops.long()], ok)   # key == R[payR] == S[payS]
+
+
+# ---- streaming probe side (outOfGPU_Join3_payload, hjcp.cu:1684-1984) ----------------
+@pytest.mark.parametrize("seg", [0, 1000, 4096, 50_000, 10**9])
+def test_stream_probe_segments(P, seg):
+    rng = np.random.default_rng(77)
+    nR, nS = 40_000, 333_333
+    R = rng.permutation(nR).astype(np.int32)
+    S = rng.integers(0, nR + 50, nS).astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = np.arange(nS, dtype=np.int32)
+    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R, Pr)
+        assert hj.join_stream_probe(S, Ps, segment_tuples=seg) == (em, eagg)          # given payloads
+        assert hj.join_stream_probe(S, None, "rowid", segment_tuples=seg) == (em, eagg)  # global row ids
+        ones = o.join_count(R, Pr, S, None, checksum=False)
+        assert hj.join_stream_probe(S, None, "ones", segment_tuples=seg) == ones[:2]
+        # the resident path still works afterwards and agrees
+        hj.load_host(P.REL_S, S, Ps)
+        assert hj.join() == (em, eagg)
+
+
+def test_stream_probe_edge_cases(P):
+    R = np.arange(100, dtype=np.int32)
+    with P.HashJoin(0) as hj:
+        with pytest.raises(P.HJError):
+            hj.join_stream_probe(R)                       # R not loaded
+        hj.load_host(P.REL_R, R)
+        assert hj.join_stream_probe(np.empty(0, np.int32)) == (0, 0)
+        assert hj.join_stream_probe(np.array([5, 5, 200], np.int32), segment_tuples=1) == (2, 2)
