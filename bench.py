@@ -108,13 +108,45 @@ def bench_zipf(a, pkg, torch, dev, local):
                                   for k, v in kt.items() if v["launches"]}}))
 
 
+def bench_stream(a, pkg, torch, dev, local):
+    """SURVEY §8(f) rank 1 (outOfGPU_Join3_payload): R = 2^27 resident, S = 2^30 in pinned HOST memory, streamed
+    through HBM in segments.  PCIe-bound by construction; reported in DESIGN.md, not the headline."""
+    import numpy as np
+    nR, nS = 1 << 27, 1 << 30
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
+    Sk = torch.empty(nS, dtype=torch.int32, device=dev)
+    hj.gen_unique(Rk, nR, 0, nR, 3)
+    hj.fill_payload(Rp, nR, "ones")
+    hj.gen_unique(Sk, nS, 0, nR, 5)   # foreign keys: every R key 8 times
+    hj.sync()
+    S_host = torch.empty(nS, dtype=torch.int32).pin_memory()
+    S_host.copy_(Sk)
+    del Sk
+    S_np = S_host.numpy()
+    hj.bind_device(pkg.REL_R, Rk, Rp)
+    times = []
+    for i in range(a.warmup + a.steps):
+        t0 = time.perf_counter()
+        m, _ = hj.join_stream_probe(S_np, None, "ones")
+        torch.cuda.synchronize()
+        if i >= a.warmup:
+            times.append(time.perf_counter() - t0)
+        assert m == nS, (m, nS)
+    dt = sum(times) / len(times)
+    print(json.dumps({"metric": "billion tuples/sec, streaming probe side: R 2^27 in HBM, S 2^30 in pinned host memory",
+                      "value": round((nR + nS) / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1,
+                      "ms_per_step": round(dt * 1e3, 2), "h2d_GBs": round(nS * 4 / dt / 1e9, 1),
+                      "config": {"workload": "PK-FK 2^27 x 2^30, S streamed from pinned host memory in segments of max(|R|/4, 2^24)"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
-    ap.add_argument("--workload", choices=["uniform", "zipf"], default="uniform",
+    ap.add_argument("--workload", choices=["uniform", "zipf", "stream"], default="uniform",
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
@@ -138,6 +170,8 @@ def main():
     total_n = n * world
     if a.workload == "zipf":
         return bench_zipf(a, pkg, torch, dev, local)
+    if a.workload == "stream":
+        return bench_stream(a, pkg, torch, dev, local)
 
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
     if a.bits or a.probe_chunk:

@@ -64,7 +64,10 @@ struct hj_ctx {
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
     Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64)
-    bool join_planned = false;
+    bool join_planned = false;     // scanned per-wave counts + item list of the current partitions are on the device
+    JoinArgs last_args{};
+    bool last_tag16 = false;
+    uint64_t last_matches = 0, last_agg = 0;
     uint32_t max_items = 0;
     size_t lds_limit = 0;
     int scatter_variant = -1;
@@ -437,6 +440,7 @@ int partition_both(hj_ctx *c) {
 
 // work-item list + per-wave counts; leaves scanned wave counts in place for the materialising kernel
 int run_count(hj_ctx *c, JoinArgs &a, bool &tag16) {
+    c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
     if (B.nparts != Pb.nparts || B.pb1 != Pb.pb1 || B.pb2 != Pb.pb2)
@@ -648,6 +652,9 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     RET(fetch_scalars(c));
     if (matches) *matches = c->h_scalars[1];
     if (agg) *agg = c->h_scalars[2];
+    // a materialising call on the same partitions can skip the count (item list + scanned counts are in HBM)
+    c->last_args = a; c->last_tag16 = tag16; c->last_matches = c->h_scalars[1]; c->last_agg = c->h_scalars[2];
+    c->join_planned = true;
     return HJ_OK;
 }
 
@@ -657,7 +664,9 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     HIPCHK(c, hipSetDevice(c->device));
     JoinArgs a;
     bool tag16;
-    RET(run_count(c, a, tag16));
+    const bool reuse = c->join_planned;
+    if (reuse) { a = c->last_args; tag16 = c->last_tag16; }
+    else RET(run_count(c, a, tag16));
     a.wave_scanned = (const uint64_t *)c->wave_counts.p;
     a.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
     a.out_key = d_key;
@@ -665,7 +674,9 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
     a.out_cap = cap;
     { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, true)); }
+    c->join_planned = false; // conservative: one reuse per count
     RET(fetch_scalars(c));
+    if (reuse) { c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg; }
     if (n_out) *n_out = c->h_scalars[1];
     if (c->h_scalars[1] > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu",
                                            (unsigned long long)c->h_scalars[1], (unsigned long long)cap);
