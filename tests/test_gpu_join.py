@@ -291,3 +291,68 @@ def test_stream_probe_edge_cases(P):
         hj.load_host(P.REL_R, R)
         assert hj.join_stream_probe(np.empty(0, np.int32)) == (0, 0)
         assert hj.join_stream_probe(np.array([5, 5, 200], np.int32), segment_tuples=1) == (2, 2)
+
+
+# ---- API contract: errors, config, output capacity, CLI multipliers / --file -------------------------------
+def test_api_errors_and_config(P):
+    import ctypes as C
+    R = np.arange(1000, dtype=np.int32)
+    with P.HashJoin(0) as hj:
+        with pytest.raises(P.HJError):
+            hj.partition(P.REL_R)                                   # nothing loaded
+        hj.load_host(P.REL_R, R, R)
+        with pytest.raises(P.HJError):
+            hj.join_count()                                         # not partitioned
+        with pytest.raises(P.HJError):
+            hj.configure(bits1=10)                                  # at most 9 bits per pass
+        with pytest.raises(P.HJError):
+            hj.configure(lds_heads=1000)                            # power of two
+        hj.load_host(P.REL_S, np.repeat(R, 3), None, "rowid")
+        hj.configure(bits1=3, bits2=2, build_side=2, lds_capacity=512, lds_heads=128, probe_chunk=64)
+        c = hj.config()
+        assert (c["bits1"], c["bits2"], c["build_side"], c["lds_capacity"], c["lds_heads"], c["probe_chunk"]) == (3, 2, 2, 512, 128, 64)
+        assert hj.join() == (3000, o.join_count(R, R, np.repeat(R, 3), np.arange(3000, dtype=np.int32), checksum=False)[1])
+        # output capacity: nothing beyond cap is written, the call reports HJ_ECAPACITY and the true size
+        bufs = [hj.device_malloc(4 * 4000) for _ in range(3)]
+        guard = np.full(1000, -7, np.int32)
+        for b in bufs:
+            hj._ck(hj._L.hj_memcpy_h2d(hj._h, C.c_void_p(b + 4 * 2000), guard.ctypes.data_as(C.c_void_p), 4000))
+        n = C.c_uint64()
+        rc = hj._L.hj_join_materialize(hj._h, C.c_void_p(bufs[0]), C.c_void_p(bufs[1]), C.c_void_p(bufs[2]), 2000, C.byref(n))
+        assert rc == -4 and n.value == 3000                          # HJ_ECAPACITY
+        for b in bufs:
+            assert np.all(hj.to_host(b + 4 * 2000, 1000, np.int32) == -7)
+            hj.device_free(b)
+        # partitioning one relation with other bits than its partner is refused, not mis-joined
+        hj.configure(bits1=4)
+        hj.partition(P.REL_R)
+        hj.configure(bits1=5)
+        hj.partition(P.REL_S)
+        hj.configure(bits1=4)   # invalidates both
+        with pytest.raises(P.HJError):
+            hj.join_count()
+
+
+def test_bench_cli_file_and_multipliers(P, tmp_path):
+    """--file -k/-l (main.cu:186-189) and -x/-y multipliers (create_relation_n, main.cu:103-109,208-248)."""
+    import subprocess
+    g = P.generator
+    g.seed_generator(4)
+    R = g.create_relation_unique(None, 5000, 5000)
+    S = g.create_relation_unique(None, 12000, 5000)
+    g.writeToFile(str(tmp_path / "r.bin"), R)
+    g.writeToFile(str(tmp_path / "s.bin"), S)
+    expect = o.join_count(R, None, S, None, checksum=False)[0]
+    r = subprocess.run([P._lib.BENCH_PATH, "-b", "7", "-a", "HJC", "-R", "5000", "-S", "12000", "--file", "-k", "r.bin", "-l", "s.bin"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Reading from files" in r.stdout and "%d results" % expect in r.stdout
+    # short file → error, like D12 says it should be
+    r = subprocess.run([P._lib.BENCH_PATH, "-b", "7", "-a", "HJC", "-R", "5001", "-S", "12000", "--file", "-k", "r.bin", "-l", "s.bin"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1
+    # -y 3 -x 2: R = 3 copies of a 1000-key permutation, S = 2 copies → 1000 * 3 * 2 matches
+    r = subprocess.run([P._lib.BENCH_PATH, "-b", "7", "-a", "HJC", "-R", "1000", "-S", "1000", "-y", "3", "-x", "2", "--seed", "6"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "6000 results" in r.stdout
