@@ -10,7 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hj.h"
@@ -73,7 +75,8 @@ struct hj_ctx {
     int scatter_variant = -1;
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     hipStream_t copy = nullptr;     // H2D of the next probe segment
-    Buf seg_k[2], seg_p[2];         // double-buffered probe segments
+    Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
+    Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
     hipEvent_t seg_ready[2] = {};
     // timing
     bool events = true;
@@ -555,7 +558,7 @@ int hj_destroy(hj_ctx *c) {
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
+    for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
     if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
@@ -781,6 +784,121 @@ int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays
     c->force_build_r = saved_force;
     c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation
     invalidate(c, HJ_REL_S);
+    if (rc) return rc;
+    if (matches) *matches = tot_m;
+    if (agg) *agg = tot_a;
+    return HJ_OK;
+}
+
+namespace {
+
+// Host-side level-0 radix split (the role of partitions_host_omp_nontemporal_payload,
+// partition-primitives.cu:40-125, and partition_prepare/do_payload :129-232): per-thread histograms over
+// contiguous chunks, prefix, scatter.  Partition id = hj_shard_of(key, parts) (hash: balanced for dense keys).
+void host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
+                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off) {
+    if (threads < 1) threads = 1;
+    std::vector<uint64_t> hist((size_t)threads * parts, 0);
+    auto chunk = [&](uint32_t t, uint64_t &lo, uint64_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            uint64_t lo, hi; chunk(t, lo, hi);
+            uint64_t *h = hist.data() + (size_t)t * parts;
+            for (uint64_t i = lo; i < hi; i++) h[host_shard_of(K[i], parts)]++;
+        });
+    for (auto &x : th) x.join();
+    th.clear();
+    off.assign(parts + 1, 0);
+    uint64_t sum = 0;
+    for (uint32_t p = 0; p < parts; p++) {
+        off[p] = sum;
+        for (uint32_t t = 0; t < threads; t++) { uint64_t cnt = hist[(size_t)t * parts + p]; hist[(size_t)t * parts + p] = sum; sum += cnt; }
+    }
+    off[parts] = sum;
+    for (uint32_t t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            uint64_t lo, hi; chunk(t, lo, hi);
+            uint64_t *h = hist.data() + (size_t)t * parts;
+            for (uint64_t i = lo; i < hi; i++) {
+                uint64_t d = h[host_shard_of(K[i], parts)]++;
+                oK[d] = K[i];
+                if (oP) oP[d] = Pv ? Pv[i] : 1;
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+} // namespace
+
+// CPU-GPU co-processing (outOfGPU_Join2_payload, hjcp.cu:1000-1680): both relations live in HOST memory;
+// the host splits them into level-0 partitions (16-way on 16 threads in the reference, hjcp.cu:1256-1266,
+// pp.cuh:38-39), and every level-0 partition pair is an independent join (hjcp.cu:1503-1618): uploaded
+// over PCIe into double-buffered staging while the previous pair is partitioned and joined on the GPU.
+// The reference's residency knapsack (groupOptimal2, pp.cu:307-468) is not needed: one pair is resident
+// at a time and level0_parts is chosen so that it fits.
+int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64_t nR, const int32_t *h_S,
+                      const int32_t *h_Ps, uint64_t nS, uint32_t level0_parts, uint32_t host_threads, uint64_t *matches,
+                      uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    if ((nR && !h_R) || (nS && !h_S)) return fail(c, HJ_EINVAL, "keys == NULL");
+    if (level0_parts == 0) level0_parts = 16;
+    if (level0_parts > 4096) return fail(c, HJ_EINVAL, "level0_parts out of range");
+    if (host_threads == 0) host_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    HIPCHK(c, hipSetDevice(c->device));
+    // host split; the partitioned copies are pinned so that the uploads are asynchronous
+    int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
+    const uint64_t nn[2] = {nR, nS};
+    const int32_t *srcK[2] = {h_R, h_S}, *srcP[2] = {h_Pr, h_Ps};
+    std::vector<uint64_t> off[2];
+    int rc = 0;
+    for (int r = 0; r < 2 && !rc; r++) {
+        if (hipHostMalloc((void **)&pk[r], (size_t)(nn[r] + 4) * 4, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&pp[r], (size_t)(nn[r] + 4) * 4, hipHostMallocDefault) != hipSuccess)
+            rc = fail(c, HJ_ENOMEM, "pinned host buffers for the level-0 split");
+        else
+            host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r]);
+    }
+    uint64_t maxp[2] = {0, 0};
+    if (!rc)
+        for (int r = 0; r < 2; r++)
+            for (uint32_t p = 0; p < level0_parts; p++) maxp[r] = std::max(maxp[r], off[r][p + 1] - off[r][p]);
+    if (!rc && !c->copy) { if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) rc = fail(c, HJ_EHIP, "copy stream"); }
+    for (int i = 0; i < 2 && !rc; i++) {
+        if (!c->seg_ready[i] && hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
+        if (!rc) rc = ensure(c, c->cop_k[i], (size_t)(maxp[0] + PAD) * 4);
+        if (!rc) rc = ensure(c, c->cop_p[i], (size_t)(maxp[0] + PAD) * 4);
+        if (!rc) rc = ensure(c, c->seg_k[i], (size_t)(maxp[1] + PAD) * 4);
+        if (!rc) rc = ensure(c, c->seg_p[i], (size_t)(maxp[1] + PAD) * 4);
+    }
+    auto upload = [&](uint32_t p) -> int {
+        const int b = (int)(p & 1);
+        const uint64_t r0 = off[0][p], rn = off[0][p + 1] - r0, s0 = off[1][p], sn = off[1][p + 1] - s0;
+        if (rn) { HIPCHK(c, hipMemcpyAsync(c->cop_k[b].p, pk[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy));
+                  HIPCHK(c, hipMemcpyAsync(c->cop_p[b].p, pp[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy)); }
+        if (sn) { HIPCHK(c, hipMemcpyAsync(c->seg_k[b].p, pk[1] + s0, sn * 4, hipMemcpyHostToDevice, c->copy));
+                  HIPCHK(c, hipMemcpyAsync(c->seg_p[b].p, pp[1] + s0, sn * 4, hipMemcpyHostToDevice, c->copy)); }
+        HIPCHK(c, hipEventRecord(c->seg_ready[b], c->copy));
+        return 0;
+    };
+    uint64_t tot_m = 0, tot_a = 0;
+    if (!rc) rc = upload(0);
+    for (uint32_t p = 0; p < level0_parts && !rc; p++) {
+        const int b = (int)(p & 1);
+        if (p + 1 < level0_parts && (rc = upload(p + 1))) break; // the other pair of buffers was joined + synchronised last round
+        hipError_t e = hipStreamWaitEvent(c->stream, c->seg_ready[b], 0);
+        if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
+        const uint64_t rn = off[0][p + 1] - off[0][p], sn = off[1][p + 1] - off[1][p];
+        if ((rc = hj_bind_device(c, HJ_REL_R, (const int32_t *)c->cop_k[b].p, (const int32_t *)c->cop_p[b].p, rn))) break;
+        if ((rc = hj_bind_device(c, HJ_REL_S, (const int32_t *)c->seg_k[b].p, (const int32_t *)c->seg_p[b].p, sn))) break;
+        uint64_t m = 0, a = 0;
+        if ((rc = hj_join(c, &m, &a))) break; // [sync]; the next pair is already on its way
+        tot_m += m; tot_a += a;
+    }
+    (void)hipStreamSynchronize(c->copy);
+    for (int r = 0; r < 2; r++) { if (pk[r]) (void)hipHostFree(pk[r]); if (pp[r]) (void)hipHostFree(pp[r]); }
+    c->rel[0].bound = c->rel[1].bound = false; // the staging buffers are not user relations
+    invalidate(c);
     if (rc) return rc;
     if (matches) *matches = tot_m;
     if (agg) *agg = tot_a;

@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <sys/time.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include <iostream>
 
 #include "hj.h"
@@ -40,6 +43,42 @@ int run(args *in) {
     const uint64_t nR = in->R_els, nS = in->S_els;
     int32_t *out[3] = {nullptr, nullptr, nullptr};
     uint64_t matches = 0, agg = 0, nout = 0;
+    // hj_ClusteredProbe's three-way dispatch (hjcp.cu:2001-2008), decided by free HBM instead of the
+    // reference's fixed 128 000 001-tuple thresholds: everything resident (Join1) / S streamed (Join3) /
+    // both relations host-resident, CPU level-0 split (Join2).  HJ_FORCE_PATH overrides (tests).
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const double budget = 0.85 * (double)free_b;
+    // resident path: inputs + ping-pong buffers (3 x 8 B per tuple) + output columns (<= 12 B per probe tuple, PK-FK)
+    const double need_all = 24.0 * (double)(nR + nS) + 12.0 * (double)(nR > nS ? nR : nS);
+    const double need_r = 24.0 * (double)nR + 6.0 * 24.0 * (double)(nR / 4 > (1u << 24) ? nR / 4 : (1u << 24));
+    int path = need_all <= budget ? 1 : (need_r <= budget ? 3 : 2);
+    if (const char *f = getenv("HJ_FORCE_PATH")) {
+        if (!strcmp(f, "resident")) path = 1; else if (!strcmp(f, "coprocess")) path = 2; else if (!strcmp(f, "stream")) path = 3;
+    }
+    if (path != 1) {
+        const double bytes = 2.0 * (double)(nR + nS) * sizeof(int);
+        double t1 = cpu_seconds();
+        if (path == 3) {
+            rc = hj_load_host(ctx, HJ_REL_R, in->R, nullptr, nR, HJ_PAYLOAD_ONES);
+            t1 = cpu_seconds();
+            if (!rc) rc = hj_join_stream_probe(ctx, in->S, nullptr, nS, 0, HJ_PAYLOAD_ONES, &matches, &agg);
+        } else {
+            rc = hj_join_coprocess(ctx, in->R, nullptr, nR, in->S, nullptr, nS, 0, 0, &matches, &agg);
+        }
+        double t2 = cpu_seconds();
+        if (rc) fprintf(stderr, "GPU Error: %s (code %d)\n", hj_error(ctx), rc);
+        else {
+            // hjcp.cu:1972-1983 (Join3) / 1664-1679 (Join2): one throughput line and the summed counters
+            std::cout << (path == 3 ? "Total Throughput (Streaming) " : "Total Throughput (Co-processing) ")
+                      << bytes / (t2 - t1) / 1000 / 1000 << std::endl;
+            printf("%llu results\n", (unsigned long long)agg);
+        }
+        g_last.matches = matches; g_last.agg = agg; g_last.status = rc;
+        g_last.join_ms[1] = (t2 - t1) * 1e3;
+        hj_destroy(ctx);
+        return rc;
+    }
     do {
         // hjcp.cu:1991-1999 + 874-877: payloads = 1, columns to HBM (untimed)
         if ((rc = hj_load_host(ctx, HJ_REL_R, in->R, nullptr, nR, HJ_PAYLOAD_ONES))) break;

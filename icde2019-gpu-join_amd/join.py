@@ -136,6 +136,20 @@ class HashJoin:
         self._ck(self._L.hj_join_stream_probe(self._h, kp, pp, len(S), segment_tuples, mode, C.byref(m), C.byref(a)))
         return m.value, a.value
 
+    def join_coprocess(self, R, Pr, S, Ps, level0_parts=0, host_threads=0):
+        """Both relations host-resident: host level-0 split + per-partition GPU joins (hjcp.cu:1000-1680)."""
+        R, rk = _host_i32(R)
+        S, sk = _host_i32(S)
+        rp = sp = None
+        if Pr is not None:
+            Pr, rp = _host_i32(Pr)
+        if Ps is not None:
+            Ps, sp = _host_i32(Ps)
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_coprocess(self._h, rk, rp, len(R), sk, sp, len(S), level0_parts, host_threads,
+                                           C.byref(m), C.byref(a)))
+        return m.value, a.value
+
     def join_materialize_into(self, d_key, d_payR, d_payS, cap):
         n = C.c_uint64()
         self._ck(self._L.hj_join_materialize(self._h, _dev_ptr(d_key), _dev_ptr(d_payR), _dev_ptr(d_payS), cap,

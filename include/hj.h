@@ -108,6 +108,15 @@ int hj_join(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
 int hj_join_stream_probe(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pays, uint64_t n,
                          uint64_t segment_tuples, int payload_mode, uint64_t *matches, uint64_t *agg);
 
+/* ---- CPU-GPU co-processing (outOfGPU_Join2_payload, hjcp.cu:1000-1680): BOTH relations stay in host
+ *      memory.  The host splits them into level0_parts partitions on host_threads threads (16 and 16 in the
+ *      reference, hjcp.cu:1256-1266, pp.cuh:38-39; 0 = those defaults / all cores up to 64); each partition
+ *      pair is uploaded into double-buffered staging while the previous pair is joined on the GPU.
+ *      Payload columns may be NULL (= ones).  Count-only.  [sync] ---- */
+int hj_join_coprocess(hj_ctx *ctx, const int32_t *h_R, const int32_t *h_Pr, uint64_t nR, const int32_t *h_S,
+                      const int32_t *h_Ps, uint64_t nS, uint32_t level0_parts, uint32_t host_threads,
+                      uint64_t *matches, uint64_t *agg);
+
 /* ---- plain device-memory helpers for callers without a HIP runtime binding of their own ---- */
 int hj_device_malloc(hj_ctx *ctx, void **d_ptr, uint64_t bytes);
 int hj_device_free(hj_ctx *ctx, void *d_ptr);

@@ -356,3 +356,38 @@ def test_bench_cli_file_and_multipliers(P, tmp_path):
                        cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "6000 results" in r.stdout
+
+
+# ---- CPU-GPU co-processing (outOfGPU_Join2_payload, hjcp.cu:1000-1680) ---------------
+@pytest.mark.parametrize("parts,threads", [(0, 0), (1, 1), (16, 3), (7, 2), (64, 8)])
+def test_coprocess(P, parts, threads):
+    rng = np.random.default_rng(parts * 100 + threads)
+    nR, nS = 60_001, 250_000
+    R = rng.integers(-5000, 50_000, nR).astype(np.int32)
+    S = rng.integers(-5000, 50_000, nS).astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = np.arange(nS, dtype=np.int32)
+    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    with P.HashJoin(0) as hj:
+        assert hj.join_coprocess(R, Pr, S, Ps, parts, threads) == (em, eagg)
+        assert hj.join_coprocess(R, None, S, None, parts, threads) == o.join_count(R, None, S, None, checksum=False)[:2]
+        e = np.empty(0, np.int32)
+        assert hj.join_coprocess(e, None, S, None, parts, threads) == (0, 0)
+        # the resident path is usable afterwards
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, S, Ps)
+        assert hj.join() == (em, eagg)
+
+
+def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
+    """hj_ClusteredProbe's three-way dispatch (hjcp.cu:2001-2008): resident / streamed S / co-processing."""
+    R = _load(golden_dir, "unique_4096.bin")
+    S = _load(golden_dir, "zipf_S20000_a4096_t1.0_seed42.bin")
+    expect = len(S) - int((S == 4096).sum())
+    for path, line in (("stream", "Total Throughput (Streaming) "), ("coprocess", "Total Throughput (Co-processing) "),
+                       ("resident", "With materialization")):
+        monkeypatch.setenv("HJ_FORCE_PATH", path)
+        r = P.hashJoinClusteredProbe(R, S)
+        out = capfd.readouterr().out
+        assert r["status"] == 0 and r["matches"] == r["agg"] == expect, (path, r)
+        assert line in out and "%d results" % expect in out
