@@ -51,6 +51,8 @@ SIGNATURES = {
     "hj_join_count": (C.c_int, [vp, u64p, u64p]),
     "hj_join_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
     "hj_join": (C.c_int, [vp, u64p, u64p]),
+    "hj_join_late_materialize": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint32, C.c_uint64, u64p, u64p]),
+    "hj_join_nonpartitioned": (C.c_int, [vp, C.c_int, u64p, u64p]),
     "hj_join_stream_probe": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p]),
     "hj_join_coprocess": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
     "hj_device_malloc": (C.c_int, [vp, C.POINTER(vp), C.c_uint64]),

@@ -442,7 +442,7 @@ int partition_both(hj_ctx *c) {
 }
 
 // work-item list + per-wave counts; leaves scanned wave counts in place for the materialising kernel
-int run_count(hj_ctx *c, JoinArgs &a, bool &tag16) {
+int run_count(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullptr) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
@@ -486,7 +486,14 @@ int run_count(hj_ctx *c, JoinArgs &a, bool &tag16) {
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
-    { Timed t(c, "k_join_count"); HIPCHK(c, launch_join(st, a, c->max_items, tag16, false)); }
+    if (late) {
+        a.Db = late->Db; a.Dp = late->Dp; a.ncb = late->ncb; a.ncp = late->ncp; a.sb = late->sb; a.sp = late->sp;
+        Timed t(c, "k_join_late_mat");
+        HIPCHK(c, launch_join(st, a, c->max_items, tag16, 2));
+    } else {
+        Timed t(c, "k_join_count");
+        HIPCHK(c, launch_join(st, a, c->max_items, tag16, 0));
+    }
     HIPCHK(c, hipMemsetAsync(sc + 2, 0, 8, st));
     // n_items is a uint64 on the device; the scans take its low word as their length (little endian)
     const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
@@ -676,7 +683,7 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
     a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
     a.out_cap = cap;
-    { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, true)); }
+    { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, 1)); }
     c->join_planned = false; // conservative: one reuse per count
     RET(fetch_scalars(c));
     if (reuse) { c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg; }
@@ -717,6 +724,72 @@ int hj_memcpy_h2d(hj_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
     if (!c) return HJ_EINVAL;
     if (bytes) HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_join_late_materialize(hj_ctx *c, const int32_t *d_Dr, uint32_t ncolR, uint64_t strideR, const int32_t *d_Ds,
+                             uint32_t ncolS, uint64_t strideS, uint64_t *matches, uint64_t *sum) {
+    if (!c) return HJ_EINVAL;
+    if ((ncolR && !d_Dr) || (ncolS && !d_Ds)) return fail(c, HJ_EINVAL, "extra-column table == NULL");
+    if ((ncolR && strideR < c->rel[HJ_REL_R].n) || (ncolS && strideS < c->rel[HJ_REL_S].n))
+        return fail(c, HJ_EINVAL, "column stride smaller than the relation");
+    HIPCHK(c, hipSetDevice(c->device));
+    choose_bits(c);
+    JoinArgs late{};
+    const bool r_builds = c->build == HJ_REL_R;
+    late.Db = r_builds ? d_Dr : d_Ds; late.ncb = r_builds ? ncolR : ncolS; late.sb = r_builds ? strideR : strideS;
+    late.Dp = r_builds ? d_Ds : d_Dr; late.ncp = r_builds ? ncolS : ncolR; late.sp = r_builds ? strideS : strideR;
+    JoinArgs a;
+    bool tag16;
+    RET(run_count(c, a, tag16, &late));
+    RET(fetch_scalars(c));
+    if (matches) *matches = c->h_scalars[1];
+    if (sum) *sum = c->h_scalars[2];
+    return HJ_OK;
+}
+
+int hj_join_nonpartitioned(hj_ctx *c, int kind, uint64_t *matches, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    if (kind != 0 && kind != 1) return fail(c, HJ_EINVAL, "kind must be 0 (perfect array) or 1 (global chained table)");
+    if (!c->rel[0].bound || !c->rel[1].bound) return fail(c, HJ_EINVAL, "load or bind both relations first");
+    HIPCHK(c, hipSetDevice(c->device));
+    choose_bits(c);
+    const Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    HIPCHK(c, hipMemsetAsync(sc + 5, 0, 3 * 8, c->stream)); // [5] max key, [6] matches, [7] agg
+    Buf t1, t2;
+    int rc = 0;
+    if (kind == 0) {
+        // direct-address table over [0, max build key]: the best case of a non-partitioned join; needs
+        // unique, non-negative build keys (jp.cu:620-627 "perfect hashing")
+        hipError_t e = launch_np_max(c->stream, B.in_k, B.n, reinterpret_cast<uint32_t *>(sc + 5));
+        if (e != hipSuccess) return fail(c, HJ_EHIP, "k_np_max: %s", hipGetErrorString(e));
+        RET(fetch_scalars(c));
+        const uint64_t range = (uint32_t)c->h_scalars[5] + (uint64_t)1;
+        if (range > ((uint64_t)1 << 31)) return fail(c, HJ_EINVAL, "perfect array needs non-negative build keys");
+        rc = ensure(c, t1, (size_t)range * 4);
+        if (!rc) {
+            hipError_t e2 = hipMemsetAsync(t1.p, 0, (size_t)range * 4, c->stream);
+            if (e2 == hipSuccess) { Timed t(c, "k_np_perfect"); e2 = launch_np_perfect(c->stream, B.in_k, B.n, B.in_p, Pb.in_k, Pb.in_p, Pb.n, (int32_t *)t1.p, range, sc + 6); }
+            if (e2 != hipSuccess) rc = fail(c, HJ_EHIP, "perfect array: %s", hipGetErrorString(e2));
+        }
+    } else {
+        uint32_t lg = B.n > 1 ? ceil_log2(B.n) : 1; // one slot per build tuple (the reference passes p = 27 for 2^27)
+        if (lg > 31) lg = 31;
+        rc = ensure(c, t1, ((size_t)1 << lg) * 4);
+        if (!rc) rc = ensure(c, t2, (size_t)(B.n + 1) * 4);
+        if (!rc) {
+            hipError_t e2 = hipMemsetAsync(t1.p, 0, ((size_t)1 << lg) * 4, c->stream);
+            if (e2 == hipSuccess) { Timed t(c, "k_np_chained"); e2 = launch_np_chained(c->stream, B.in_k, B.in_p, B.n, Pb.in_k, Pb.in_p, Pb.n, lg, (int32_t *)t1.p, (int32_t *)t2.p, sc + 6); }
+            if (e2 != hipSuccess) rc = fail(c, HJ_EHIP, "chained table: %s", hipGetErrorString(e2));
+        }
+    }
+    if (!rc) rc = fetch_scalars(c);
+    release(t1);
+    release(t2);
+    if (rc) return rc;
+    if (matches) *matches = c->h_scalars[6];
+    if (agg) *agg = c->h_scalars[7];
     return HJ_OK;
 }
 

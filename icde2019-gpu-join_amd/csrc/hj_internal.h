@@ -50,6 +50,10 @@ struct JoinArgs {
     const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
     int32_t *out_key, *out_bpay, *out_ppay;
     uint64_t out_cap;
+    // late materialisation: column-major extra columns gathered by row id on every match
+    const int32_t *Db, *Dp;  // build side / probe side tables
+    uint32_t ncb, ncp;       // columns to gather
+    uint64_t sb, sp;         // column stride (elements)
 };
 
 hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n);
@@ -69,7 +73,12 @@ hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64
                               const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(size_t bytes);
-hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, bool mat);
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise, 2 late materialisation
+hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max);
+hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, const int32_t *bp, const int32_t *pk, const int32_t *pp,
+                             uint64_t np, int32_t *lookup, uint64_t range, uint64_t *out2);
+hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *bp, uint64_t nb, const int32_t *pk, const int32_t *pp,
+                             uint64_t np, uint32_t log_slots, int32_t *head, int32_t *next, uint64_t *out2);
 hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out);
 hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first);
 hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);

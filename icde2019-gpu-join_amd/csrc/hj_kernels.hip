@@ -727,8 +727,9 @@ __global__ void k_join_expand(const uint64_t *__restrict__ boff, const uint64_t 
 
 // LDS layout (dynamic): head[nh] u32 | pay[cap] i32 | key[cap] (u16 tag or u32 key) | next[cap] u16
 // The reference's table: elem int16 tag, payload int32, next int16, head int32[1024] (jp.cu:899-902).
-template <bool TAG16, bool MAT>
+template <bool TAG16, int JM>
 __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
+    constexpr bool MAT = JM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t item = blockIdx.x;
     if (item >= *a.n_items) return;
@@ -798,7 +799,17 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
                         if (eq) {
                             my_matches++;
-                            my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)ppay);
+                            if (JM == 2) {
+                                // late materialisation (join_partitioned_varpayload, jp.cu:1524-1533): payloads are
+                                // row ids; gather the extra columns of both sides and add them up
+                                const int32_t bval = lpay[pos];
+                                int64_t acc = 0;
+                                for (uint32_t z = 0; z < a.ncp; z++) acc += a.Dp[(uint64_t)(uint32_t)ppay + z * a.sp];
+                                for (uint32_t z = 0; z < a.ncb; z++) acc += a.Db[(uint64_t)(uint32_t)bval + z * a.sb];
+                                my_agg += (uint64_t)acc;
+                            } else {
+                                my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)ppay);
+                            }
                         }
                         pos = lnext[pos];
                     }
@@ -1108,23 +1119,121 @@ size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16) {
 }
 
 hipError_t join_set_lds_limit(size_t bytes) {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const void *fns[] = {reinterpret_cast<const void *>(&k_join<true, 0>), reinterpret_cast<const void *>(&k_join<true, 1>),
+                         reinterpret_cast<const void *>(&k_join<true, 2>), reinterpret_cast<const void *>(&k_join<false, 0>),
+                         reinterpret_cast<const void *>(&k_join<false, 1>), reinterpret_cast<const void *>(&k_join<false, 2>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, bool mat) {
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm) {
     size_t lds = join_lds_bytes(a.nh, a.cap, tag16);
     dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
-    if (tag16 && !mat) hipLaunchKernelGGL((k_join<true, false>), g, b, lds, st, a);
-    else if (tag16 && mat) hipLaunchKernelGGL((k_join<true, true>), g, b, lds, st, a);
-    else if (!tag16 && !mat) hipLaunchKernelGGL((k_join<false, false>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_join<false, true>), g, b, lds, st, a);
+    if (tag16) {
+        if (jm == 0) hipLaunchKernelGGL((k_join<true, 0>), g, b, lds, st, a);
+        else if (jm == 1) hipLaunchKernelGGL((k_join<true, 1>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join<true, 2>), g, b, lds, st, a);
+    } else {
+        if (jm == 0) hipLaunchKernelGGL((k_join<false, 0>), g, b, lds, st, a);
+        else if (jm == 1) hipLaunchKernelGGL((k_join<false, 1>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join<false, 2>), g, b, lds, st, a);
+    }
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// non-partitioned baselines (comparison curves; jp.cu:628-668 perfect array, jp.cu:681-742 global chains)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_np_max(const int32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ out_max) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t k = (uint32_t)keys[i];
+        m = k > m ? k : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if (lane_id() == 0) atomicMax(out_max, m);
+}
+
+// build_perfect_array (jp.cu:628-640): lookup[key] = row + 1 (the reference stores payload + 1; the row
+// index keeps payload 0xFFFFFFFF representable)
+__global__ __launch_bounds__(256) void k_np_build_perfect(const int32_t *__restrict__ keys, uint64_t n, int32_t *__restrict__ lookup) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        lookup[(uint32_t)keys[i]] = (int32_t)(uint32_t)(i + 1);
+}
+
+// probe_perfect_array (jp.cu:649-668): one dependent gather per probe tuple; out2 = {matches, agg}
+__global__ __launch_bounds__(256) void k_np_probe_perfect(const int32_t *__restrict__ pk, const int32_t *__restrict__ pp, uint64_t n,
+                                                          const int32_t *__restrict__ lookup, uint64_t range,
+                                                          const int32_t *__restrict__ bp, unsigned long long *__restrict__ out2) {
+    uint64_t m = 0, g = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = (uint32_t)pk[i];
+        if (key < range) {
+            const uint32_t res = (uint32_t)lookup[key];
+            if (res) { m++; g += (uint64_t)((int64_t)pp[i] * (int64_t)bp[res - 1]); }
+        }
+    }
+    m = wave_sum64(m); g = wave_sum64(g);
+    if (lane_id() == 0) { atomicAdd(&out2[0], (unsigned long long)m); atomicAdd(&out2[1], (unsigned long long)g); }
+}
+
+// build_ht_chains (jp.cu:681-698): one global chained table, slot = key & mask, LIFO insert by atomicExch
+__global__ __launch_bounds__(256) void k_np_build_chains(const int32_t *__restrict__ keys, uint64_t n, uint32_t mask,
+                                                         int32_t *__restrict__ head, int32_t *__restrict__ next) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        int last = atomicExch(&head[(uint32_t)keys[i] & mask], (int32_t)(uint32_t)(i + 1));
+        next[i] = last;
+    }
+}
+
+// chains_probing (jp.cu:713-742)
+__global__ __launch_bounds__(256) void k_np_probe_chains(const int32_t *__restrict__ pk, const int32_t *__restrict__ pp, uint64_t n,
+                                                         uint32_t mask, const int32_t *__restrict__ head, const int32_t *__restrict__ next,
+                                                         const int32_t *__restrict__ bk, const int32_t *__restrict__ bp,
+                                                         unsigned long long *__restrict__ out2) {
+    uint64_t m = 0, g = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t key = pk[i], pay = pp[i];
+        uint32_t nx = (uint32_t)head[(uint32_t)key & mask];
+        while (nx != 0) {
+            if (bk[nx - 1] == key) { m++; g += (uint64_t)((int64_t)pay * (int64_t)bp[nx - 1]); }
+            nx = (uint32_t)next[nx - 1];
+        }
+    }
+    m = wave_sum64(m); g = wave_sum64(g);
+    if (lane_id() == 0) { atomicAdd(&out2[0], (unsigned long long)m); atomicAdd(&out2[1], (unsigned long long)g); }
+}
+
+static inline uint32_t np_grid(uint64_t n) { uint64_t b = (n + 255) / 256; return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
+hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max) {
+    hipLaunchKernelGGL(k_np_max, dim3(np_grid(n)), dim3(256), 0, st, keys, n, out_max);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, const int32_t *bp, const int32_t *pk, const int32_t *pp,
+                             uint64_t np, int32_t *lookup, uint64_t range, uint64_t *out2) {
+    hipLaunchKernelGGL(k_np_build_perfect, dim3(np_grid(nb)), dim3(256), 0, st, bk, nb, lookup);
+    HJ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_np_probe_perfect, dim3(np_grid(np)), dim3(256), 0, st, pk, pp, np, lookup, range, bp,
+                       reinterpret_cast<unsigned long long *>(out2));
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *bp, uint64_t nb, const int32_t *pk, const int32_t *pp,
+                             uint64_t np, uint32_t log_slots, int32_t *head, int32_t *next, uint64_t *out2) {
+    const uint32_t mask = (log_slots >= 32) ? 0xFFFFFFFFu : ((1u << log_slots) - 1);
+    hipLaunchKernelGGL(k_np_build_chains, dim3(np_grid(nb)), dim3(256), 0, st, bk, nb, mask, head, next);
+    HJ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_np_probe_chains, dim3(np_grid(np)), dim3(256), 0, st, pk, pp, np, mask, head, next, bk, bp,
+                       reinterpret_cast<unsigned long long *>(out2));
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

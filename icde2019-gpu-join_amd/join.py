@@ -125,6 +125,19 @@ class HashJoin:
         self._ck(self._L.hj_join(self._h, C.byref(m), C.byref(a)))
         return m.value, a.value
 
+    def join_late_materialize(self, d_Dr, ncolR, strideR, d_Ds, ncolS, strideS):
+        """Row-id payloads + gather of extra columns on every match (jp.cu:1420-1557)."""
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_late_materialize(self._h, _dev_ptr(d_Dr), ncolR, strideR, _dev_ptr(d_Ds), ncolS, strideS,
+                                                  C.byref(m), C.byref(a)))
+        return m.value, a.value
+
+    def join_nonpartitioned(self, kind):
+        """Comparison baselines: 0 = perfect array (jp.cu:628-668), 1 = global chained table (jp.cu:681-742)."""
+        m, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_nonpartitioned(self._h, kind, C.byref(m), C.byref(a)))
+        return m.value, a.value
+
     def join_stream_probe(self, S, Ps=None, payload="ones", segment_tuples=0):
         """S stays on the host and is streamed through HBM in segments (hjcp.cu:1684-1984); R must be loaded."""
         S, kp = _host_i32(S)

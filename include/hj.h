@@ -100,6 +100,21 @@ int hj_join_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d
 /* One call = hj_partition(R) + hj_partition(S) + hj_join_count (the timed region hjcp.cu:881-933). [sync] */
 int hj_join(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
 
+/* ---- late materialisation / wide payloads (join_partitioned_varpayload jp.cu:1420-1557,
+ *      outOfGPU_Join_payload_var hjcp.cu:542-708): the relations must be partitioned with ROW-ID payloads;
+ *      on every match the ncolR values Dr[payR + z*strideR] and the ncolS values Ds[payS + z*strideS]
+ *      (column z of a column-major table in HBM) are gathered and added up.  *sum = that total mod 2^64
+ *      (low 32 bits = the reference's int32 aggregate, jp.cu:1526-1530).  [sync] ---- */
+int hj_join_late_materialize(hj_ctx *ctx, const int32_t *d_Dr, uint32_t ncolR, uint64_t strideR,
+                             const int32_t *d_Ds, uint32_t ncolS, uint64_t strideS, uint64_t *matches,
+                             uint64_t *sum);
+
+/* ---- non-partitioned baselines for comparison curves, on the loaded/bound (unpartitioned) relations:
+ *      kind 0 = direct-address "perfect" array (build_/probe_perfect_array jp.cu:628-668; needs unique,
+ *      non-negative build keys), kind 1 = one global chained table (build_ht_chains/chains_probing
+ *      jp.cu:681-742).  The smaller relation builds.  [sync] ---- */
+int hj_join_nonpartitioned(hj_ctx *ctx, int kind, uint64_t *matches, uint64_t *agg);
+
 /* ---- streaming probe side (outOfGPU_Join3_payload, hjcp.cu:1684-1984): S stays in HOST memory and is
  *      streamed through HBM in segments — H2D copy of segment i+1 on a copy stream while segment i is
  *      partitioned and joined against R, which is partitioned once.  R must be loaded/bound first and always

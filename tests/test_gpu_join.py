@@ -391,3 +391,58 @@ def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
         out = capfd.readouterr().out
         assert r["status"] == 0 and r["matches"] == r["agg"] == expect, (path, r)
         assert line in out and "%d results" % expect in out
+
+
+# ---- §8(f) rank 3: late materialisation (jp.cu:1420-1557) / rank 4: non-partitioned baselines (jp.cu:628-742) ----
+@pytest.mark.parametrize("cfg", [None, dict(bits1=5, bits2=4), dict(build_side=2)])
+def test_late_materialize(P, cfg):
+    rng = np.random.default_rng(31)
+    nR, nS, c1, c2 = 30_000, 100_000, 3, 2
+    R = rng.permutation(nR).astype(np.int32)
+    S = rng.integers(0, nR + 100, nS).astype(np.int32)
+    Dr = rng.integers(-2**31, 2**31 - 1, (c1, nR)).astype(np.int32)     # column-major: column z at z*stride
+    Ds = rng.integers(-2**31, 2**31 - 1, (c2, nS)).astype(np.int32)
+    rid_r, rid_s = np.arange(nR, dtype=np.int32), np.arange(nS, dtype=np.int32)
+    _, pr, ps = o.join_materialize(R, rid_r, S, rid_s)                 # matching (rowR, rowS) pairs from the oracle
+    expect = (int(Dr[:, pr].astype(np.int64).sum()) + int(Ds[:, ps].astype(np.int64).sum())) % 2**64
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.load_host(P.REL_R, R, None, "rowid")
+        hj.load_host(P.REL_S, S, None, "rowid")
+        hj.partition(P.REL_R)
+        hj.partition(P.REL_S)
+        dDr, dDs = hj.to_device(Dr), hj.to_device(Ds)
+        try:
+            assert hj.join_late_materialize(dDr, c1, nR, dDs, c2, nS) == (len(pr), expect)
+            assert hj.join_late_materialize(dDr, 1, nR, None, 0, 0)[1] == int(Dr[0, pr].astype(np.int64).sum()) % 2**64
+            assert hj.join_count()[0] == len(pr)                       # the ordinary count still works on these partitions
+        finally:
+            hj.device_free(dDr)
+            hj.device_free(dDs)
+
+
+def test_nonpartitioned_baselines(P, golden_dir):
+    rng = np.random.default_rng(32)
+    R = _load(golden_dir, "unique_4096.bin")
+    Z = _load(golden_dir, "zipf_S20000_a4096_t1.0_seed42.bin")
+    A = _load(golden_dir, "nonuniq_R6000_seed7.bin")
+    B = _load(golden_dir, "nonuniq_S9000_seed8.bin")
+    Pr = rng.integers(-2**31, 2**31 - 1, len(R)).astype(np.int32)
+    Pz = rng.integers(-2**31, 2**31 - 1, len(Z)).astype(np.int32)
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, Z, Pz)
+        exp = o.join_count(R, Pr, Z, Pz, checksum=False)[:2]
+        assert hj.join_nonpartitioned(0) == exp                        # perfect array: unique build keys
+        assert hj.join_nonpartitioned(1) == exp                        # global chained table
+        assert hj.join() == exp                                        # and the partitioned path agrees
+        hj.load_host(P.REL_R, A)
+        hj.load_host(P.REL_S, B)
+        assert hj.join_nonpartitioned(1) == o.join_count(A, None, B, None, checksum=False)[:2]   # duplicates on both sides
+        neg = np.array([-5, 3, 7], np.int32)
+        hj.load_host(P.REL_R, neg)
+        hj.load_host(P.REL_S, np.array([3, -5, -5, 9], np.int32))
+        assert hj.join_nonpartitioned(1) == (3, 3)
+        with pytest.raises(P.HJError):
+            hj.join_nonpartitioned(0)                                  # negative build keys: no direct addressing
