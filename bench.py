@@ -108,6 +108,35 @@ def bench_zipf(a, pkg, torch, dev, local):
                                   for k, v in kt.items() if v["launches"]}}))
 
 
+def bench_baselines(a, pkg, torch, dev, local):
+    """the partitioned join against the reference's non-partitioned baselines
+    (perfect array jp.cu:628-668, global chained table jp.cu:681-742) on the same unique uniform input."""
+    n = 1 << a.log2n
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    Rk, Rp, Sk, Sp = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4))
+    hj.gen_unique(Rk, n, 0, n, 1)
+    hj.gen_unique(Sk, n, 0, n, 2)
+    hj.fill_payload(Rp, n, "ones")
+    hj.fill_payload(Sp, n, "ones")
+    hj.sync()
+    hj.bind_device(pkg.REL_R, Rk, Rp)
+    hj.bind_device(pkg.REL_S, Sk, Sp)
+    out = {}
+    for name, fn in (("partitioned (radix + LDS tables)", hj.join), ("perfect array", lambda: hj.join_nonpartitioned(0)),
+                     ("global chained table", lambda: hj.join_nonpartitioned(1))):
+        for _ in range(a.warmup):
+            assert fn()[0] == n
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            assert fn()[0] == n
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        out[name] = {"ms": round(dt * 1e3, 3), "Gtuples_per_s": round(2 * n / dt / 1e9, 2)}
+    print(json.dumps({"metric": "partitioned vs non-partitioned join, 2^%d x 2^%d unique uniform int32, 1 GPU" % (a.log2n, a.log2n),
+                      "results": out}))
+
+
 def bench_stream(a, pkg, torch, dev, local):
     """SURVEY §8(f) rank 1 (outOfGPU_Join3_payload): R = 2^27 resident, S = 2^30 in pinned HOST memory, streamed
     through HBM in segments.  PCIe-bound by construction; reported in DESIGN.md, not the headline."""
@@ -146,7 +175,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
-    ap.add_argument("--workload", choices=["uniform", "zipf", "stream"], default="uniform",
+    ap.add_argument("--workload", choices=["uniform", "zipf", "stream", "baselines"], default="uniform",
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
@@ -172,6 +201,8 @@ def main():
         return bench_zipf(a, pkg, torch, dev, local)
     if a.workload == "stream":
         return bench_stream(a, pkg, torch, dev, local)
+    if a.workload == "baselines":
+        return bench_baselines(a, pkg, torch, dev, local)
 
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
     if a.bits or a.probe_chunk:

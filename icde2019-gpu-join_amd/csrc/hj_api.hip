@@ -23,7 +23,7 @@ using namespace hj;
 namespace {
 
 constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-byte tail loads)
-constexpr uint32_t TARGET_SPANS = 2048;
+constexpr uint32_t TARGET_SPANS = 1024; // 4 spans per CU: measured best (profiles/r1_spans_sweep.txt)
 constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 65536;
 constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
 
@@ -73,6 +73,7 @@ struct hj_ctx {
     uint32_t max_items = 0;
     size_t lds_limit = 0;
     int scatter_variant = -1;
+    uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
@@ -240,7 +241,8 @@ int pass_prep(hj_ctx *c, int wsid, const int32_t *in_k, const int32_t *in_p, uin
               PassArgs &pa) {
     if (nparents > (uint32_t)MAX_PARENTS || P > (uint32_t)MAX_PARTS || P == 0) return fail(c, HJ_EINVAL, "pass fan-out out of range");
     if (n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU pass (n < 2^32 required)");
-    uint64_t span64 = (n + TARGET_SPANS - 1) / TARGET_SPANS;
+    const uint32_t target_spans = c->target_spans ? c->target_spans : TARGET_SPANS;
+    uint64_t span64 = (n + target_spans - 1) / target_spans;
     span64 = ((span64 + TILE - 1) / TILE) * TILE;
     if (span64 < (uint64_t)TILE) span64 = TILE;
     pa = PassArgs{};
@@ -546,6 +548,7 @@ int hj_create(hj_ctx **out, int device) {
     c->events = !(ev && ev[0] == '1');
     const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
     if (sv) c->scatter_variant = atoi(sv);
+    if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     const char *ab = getenv("HJ_WC_ABLATE"); // timing-only experiments: results are wrong when set
     if (ab) (void)set_wc_ablate((uint32_t)atoi(ab));
     *out = c;
