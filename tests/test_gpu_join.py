@@ -446,3 +446,47 @@ def test_nonpartitioned_baselines(P, golden_dir):
         assert hj.join_nonpartitioned(1) == (3, 3)
         with pytest.raises(P.HJError):
             hj.join_nonpartitioned(0)                                  # negative build keys: no direct addressing
+
+
+# ---- randomised differential test: many small configurations against the oracle ----------------------------
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_against_oracle(P, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nR = int(rng.choice([0, 1, 7, 100, 4097, int(rng.integers(1, 60_000))]))
+    nS = int(rng.choice([0, 1, 9, 333, 8193, int(rng.integers(1, 120_000))]))
+    kind = seed % 5
+    if kind == 0:      # few distinct keys: heavy duplicates, quadratic output
+        dom = int(rng.integers(1, 40)); nR, nS = min(nR, 3000), min(nS, 3000)
+        R = rng.integers(0, dom, nR); S = rng.integers(0, dom, nS)
+    elif kind == 1:    # full int32 range incl. negatives; S partly drawn from R
+        R = rng.integers(-2**31, 2**31 - 1, nR)
+        S = np.concatenate([rng.choice(R, nS // 2) if nR else np.empty(0, np.int64), rng.integers(-2**31, 2**31 - 1, nS - nS // 2)])
+    elif kind == 2:    # dense unique PK, uniform FK
+        R = rng.permutation(nR); S = rng.integers(0, max(nR, 1) + 10, nS)
+    elif kind == 3:    # keys that differ only in high bits (tag / full-key paths, one hot partition)
+        R = (rng.integers(0, 1 << 12, nR) << 20) | 5; S = (rng.integers(0, 1 << 12, nS) << 20) | 5
+        nR, nS = len(R), len(S)
+    else:              # zipf-like
+        R = rng.permutation(nR); S = np.minimum((rng.pareto(1.0, nS) * 3).astype(np.int64), max(nR, 1))
+    R, S = R.astype(np.int32), S.astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, len(R)).astype(np.int32)
+    Ps = rng.integers(-2**31, 2**31 - 1, len(S)).astype(np.int32)
+    cfg = dict(bits1=int(rng.integers(0, 10)), bits2=int(rng.integers(0, 10)), force_bits=True,
+               build_side=int(rng.integers(0, 3)), lds_capacity=int(rng.choice([0, 64, 300, 4608])),
+               lds_heads=int(rng.choice([0, 1, 16, 1024])), probe_chunk=int(rng.choice([0, 50, 1000, 65536])))
+    if seed % 7 == 0:
+        cfg = None     # library defaults
+    em, eagg, echk = o.join_count(R, Pr, S, Ps)
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, S, Ps)
+        assert hj.join() == (em, eagg), cfg
+        k, pr, ps = hj.join_materialize()
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk, cfg
+        for rel, (kk, pp) in ((P.REL_R, (R, Pr)), (P.REL_S, (S, Ps))):
+            bad, dg = hj.verify_partitions(rel, with_digests=True)
+            c = hj.config()
+            ok, op, ooff = o.radix_partition(kk, pp, 0, c["bits1"] + c["bits2"])
+            assert bad == 0 and np.array_equal(dg, o.partition_digest(ok, op, ooff)), cfg
