@@ -179,6 +179,7 @@ def main():
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
+    ap.add_argument("--lds", type=int, nargs=2, default=None, help="experiment knob: LDS table capacity and heads of the join kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     a = ap.parse_args()
@@ -205,8 +206,9 @@ def main():
         return bench_baselines(a, pkg, torch, dev, local)
 
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
-    if a.bits or a.probe_chunk:
-        hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk)
+    if a.bits or a.probe_chunk or a.lds:
+        hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
+                     lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0)
     # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
     # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
     domain = min(total_n, 1 << 32)
