@@ -76,6 +76,8 @@ struct hj_ctx {
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     hipStream_t copy = nullptr;     // H2D of the next probe segment
+    Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)
+    uint64_t *h_shard_off = nullptr;
     Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
     Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
     hipEvent_t seg_ready[2] = {};
@@ -576,6 +578,8 @@ int hj_destroy(hj_ctx *c) {
     for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
     if (c->copy) (void)hipStreamDestroy(c->copy);
+    release(c->shard_root); release(c->shard_off);
+    if (c->h_shard_off) (void)hipHostFree(c->h_shard_off);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
     release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars);
@@ -1031,25 +1035,17 @@ int hj_shard_split(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint
     if (n && (!d_keys || !d_pays || !d_out_keys || !d_out_pays)) return fail(c, HJ_EINVAL, "null column");
     if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
-    Buf root, coff;
-    int rc = ensure(c, root, 16);
-    if (!rc) rc = ensure(c, coff, (size_t)(nshards + 1) * 8);
-    if (!rc) {
-        hipError_t e = launch_set_root(c->stream, (uint64_t *)root.p, n);
-        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "set_root: %s", hipGetErrorString(e));
-    }
-    if (!rc) rc = run_pass(c, 0, 1, d_keys, d_pays, n, (const uint64_t *)root.p, 1, 0, nshards, nshards, d_out_keys, d_out_pays,
-                           (uint64_t *)coff.p);
-    std::vector<uint64_t> off(nshards + 1);
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(off.data(), coff.p, (size_t)(nshards + 1) * 8, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "shard offsets: %s", hipGetErrorString(e));
-    }
-    release(root);
-    release(coff);
-    if (rc) return rc;
-    if (h_counts) for (uint32_t i = 0; i < nshards; i++) h_counts[i] = off[i + 1] - off[i];
+    // persistent small buffers: no hipMalloc/hipFree in the steady state (hipFree synchronises the whole
+    // device and would stall an all-to-all that is in flight on another stream)
+    RET(ensure(c, c->shard_root, 16));
+    RET(ensure(c, c->shard_off, (size_t)(MAX_PARTS + 1) * 8));
+    if (!c->h_shard_off) HIPCHK(c, hipHostMalloc((void **)&c->h_shard_off, (size_t)(MAX_PARTS + 1) * 8, hipHostMallocDefault));
+    HIPCHK(c, launch_set_root(c->stream, (uint64_t *)c->shard_root.p, n));
+    RET(run_pass(c, 0, 1, d_keys, d_pays, n, (const uint64_t *)c->shard_root.p, 1, 0, nshards, nshards, d_out_keys, d_out_pays,
+                 (uint64_t *)c->shard_off.p));
+    HIPCHK(c, hipMemcpyAsync(c->h_shard_off, c->shard_off.p, (size_t)(nshards + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_counts) for (uint32_t i = 0; i < nshards; i++) h_counts[i] = c->h_shard_off[i + 1] - c->h_shard_off[i];
     return HJ_OK;
 }
 
