@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
     ap.add_argument("--lds", type=int, nargs=2, default=None, help="experiment knob: LDS table capacity and heads of the join kernel")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even at world size 1 (sanity runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     a = ap.parse_args()
@@ -193,8 +194,14 @@ def main():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29599")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     pkg = graft.load_package()
     n = 1 << a.log2n
     total_n = n * world
@@ -205,6 +212,10 @@ def main():
     if a.workload == "baselines":
         return bench_baselines(a, pkg, torch, dev, local)
 
+    if use_dist:
+        # a stream of our own for N>1: the all-to-alls run asynchronously next to local kernels, and HIP's
+        # legacy default stream would add implicit synchronisation with other blocking streams
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
     if a.bits or a.probe_chunk or a.lds:
         hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
@@ -224,19 +235,19 @@ def main():
     dup = max(1, total_n // domain)
     expect = total_n * dup  # every key occurs dup times in R and in S
 
-    if world > 1:
+    if use_dist:
         from importlib import import_module
         dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev)
 
     def step():
-        if world == 1:
+        if not use_dist:
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, Sk, Sp)
             return hj.join()[0]
         return dj.join(Rk, Rp, Sk, Sp)[0]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -264,7 +275,7 @@ def main():
     dom = max(("k_scatter_wc", "k_scatter"), key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
     sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
     roof = None
-    if sc["launches"] and world == 1:
+    if sc["launches"] and not use_dist:
         launches_per_step = sc["launches"] / a.steps
         tuples_per_launch = float(n)  # every scatter launch moves one whole relation (keys + payloads)
         avg_ms = sc["total_ms"] / sc["launches"]
@@ -288,7 +299,7 @@ def main():
                for k, v in kt.items() if v["launches"]}
     jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
     probe = None
-    if jc["launches"] and world == 1:
+    if jc["launches"] and not use_dist:
         avg = jc["total_ms"] / jc["launches"]
         probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
                  "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1),
@@ -296,7 +307,7 @@ def main():
 
     # secondary: the materialising variant (count + scan + write of (key,payR,payS)), N=1 only
     mat = None
-    if world == 1 and not a.no_materialize:
+    if not use_dist and not a.no_materialize:
         cap = expect
         ok, opr, ops = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
         hj.timings_reset()
@@ -323,7 +334,7 @@ def main():
         del ok, opr, ops
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not use_dist and not a.no_cpu_baseline:
         cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
 
     if rank == 0:
@@ -336,13 +347,13 @@ def main():
             "config": {"workload": "2^%d ⋈ 2^%d unique uniform int32 keys per GPU, payload=1, count-only "
                                    "build+probe after %d-pass radix partition (%d+%d bits)%s" %
                                    (a.log2n, a.log2n, 2 if cfg["bits2"] else 1, cfg["bits1"], cfg["bits2"],
-                                    "" if world == 1 else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
+                                    "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
                        "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
                        "matches": int(got)},
             "roofline": roof, "probe_phase": probe, "kernels": kernels, "materialize": mat, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

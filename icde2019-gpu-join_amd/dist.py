@@ -35,6 +35,12 @@ class ShardedJoin:
             self._buf[name] = t
         return t
 
+    # RCCL (2.26, ROCm 7) returns wrong data for a single all-to-all message of 2 GiB or more (measured:
+    # 2^28 int32 elements fine, 2^29 corrupted — scratch/dbg_a2a.py), and at 2 GPUs a peer's share of a 2^30-
+    # tuple column is exactly 2^29 elements.  Columns therefore travel as grouped point-to-point
+    # sends/receives of at most CHUNK elements (512 MiB): one ncclGroup per column = one all-to-all-v.
+    CHUNK = 1 << 27
+
     def exchange_async(self, cols, send_counts):
         """All-to-all-v of several columns that share one split: cols = {name: tensor[sum(send_counts)]}.
         Returns ({name: tensor}, n_received, [work handles]); the columns are valid after work.wait()."""
@@ -43,11 +49,32 @@ class ShardedJoin:
         dist.all_to_all_single(rc, sc, group=self.ctl)
         recv_counts = [int(x) for x in rc.tolist()]
         total = sum(recv_counts)
+        soff = [0]
+        for c in send_counts:
+            soff.append(soff[-1] + int(c))
+        roff = [0]
+        for c in recv_counts:
+            roff.append(roff[-1] + c)
         out, works = {}, []
         for name, t in cols.items():
             r = self._get("recv_" + name, total)
-            works.append(dist.all_to_all_single(r[:total], t[:sum(send_counts)], recv_counts, list(send_counts),
-                                                group=self.group, async_op=True))
+            ops = []
+            for step in range(self.world):
+                p = (self.rank + step) % self.world      # rank-staggered peer order
+                q = (self.rank - step) % self.world
+                if step == 0:                             # own share: a local copy, no link involved
+                    n = int(send_counts[p])
+                    if n:
+                        r[roff[p]:roff[p] + n].copy_(t[soff[p]:soff[p] + n], non_blocking=True)
+                    continue
+                for c0 in range(0, int(send_counts[p]), self.CHUNK):
+                    c1 = min(c0 + self.CHUNK, int(send_counts[p]))
+                    ops.append(dist.P2POp(dist.isend, t[soff[p] + c0:soff[p] + c1], p, group=self.group))
+                for c0 in range(0, recv_counts[q], self.CHUNK):
+                    c1 = min(c0 + self.CHUNK, recv_counts[q])
+                    ops.append(dist.P2POp(dist.irecv, r[roff[q] + c0:roff[q] + c1], q, group=self.group))
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
             out[name] = r
         return out, total, works
 

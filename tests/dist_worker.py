@@ -60,6 +60,8 @@ def main():
         engine = OracleEngine(pkg)
     from importlib import import_module
     dj = import_module(pkg.__name__ + ".dist").ShardedJoin(engine, pkg, dev)
+    if "HJ_DIST_CHUNK" in os.environ:       # force several point-to-point chunks per peer
+        dj.CHUNK = int(os.environ["HJ_DIST_CHUNK"])
 
     # every rank generates the same global relations and keeps its own slice
     rng = np.random.default_rng(123)

@@ -25,6 +25,12 @@ def test_sharded_join_gloo_world2():
     assert res["got"] == res["expect"]
 
 
+def test_sharded_join_gloo_world2_chunked_messages():
+    """Columns travel in point-to-point chunks (RCCL corrupts single messages >= 2 GiB): force many chunks."""
+    res = _run(2, {"HJ_DIST_CHUNK": "777"}, 29643)
+    assert res["got"] == res["expect"]
+
+
 def test_shard_function_is_balanced_and_total():
     p = pkg()
     keys = np.arange(-20000, 20000, dtype=np.int32)
