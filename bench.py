@@ -239,7 +239,12 @@ def main():
         from importlib import import_module
         dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev)
 
+    first = [True]
+
     def step():
+        if use_dist and first[0]:   # fail fast if the exchange corrupts data (see dist.ShardedJoin.join)
+            first[0] = False
+            return dj.join(Rk, Rp, Sk, Sp, verify=True)[0]
         if not use_dist:
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, Sk, Sp)

@@ -84,8 +84,23 @@ class ShardedJoin:
             w.wait()
         return out, total
 
-    def join(self, Rk, Rp, Sk, Sp):
+    def _allreduce_u64(self, vals):
+        """Sum 64-bit values over the ranks mod 2^64 (as 32-bit halves: the int64 SUM cannot overflow)."""
+        halves = []
+        for v in vals:
+            halves += [v & 0xFFFFFFFF, v >> 32]
+        t = torch.tensor(halves, dtype=torch.int64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
+        h = [int(x) for x in t.tolist()]
+        mask = (1 << 64) - 1
+        return [(h[2 * i] + (h[2 * i + 1] << 32)) & mask for i in range(len(vals))]
+
+    def join(self, Rk, Rp, Sk, Sp, verify=False):
         """Local slices of R and S (int32 device columns) → (global matches, global sum payR*payS mod 2^64).
+
+        verify=True (first warm-up step of bench.py): the order-independent (key,payload) digest of everything
+        sent must equal the digest of everything received, summed over the ranks — a corrupted exchange fails
+        here at once instead of feeding garbage (one giant duplicate partition) to the join.
 
         Pipeline: split R | exchange R ‖ split S | exchange S ‖ partition R | partition S | build+probe.
         The column exchanges are asynchronous on the data communicator; xGMI moves them while the CUs
@@ -105,11 +120,14 @@ class ShardedJoin:
         e.partition(self.pkg.REL_R)                              # runs while S is on the links
         for wk in workS:
             wk.wait()
+        if verify and hasattr(e, "digest_pairs"):
+            sent = (e.digest_pairs(Rk, Rp, nR) + e.digest_pairs(Sk, Sp, nS)) & ((1 << 64) - 1)
+            got = (e.digest_pairs(gotR["kR"], gotR["pR"], totR) + e.digest_pairs(gotS["kS"], gotS["pS"], totS)) & ((1 << 64) - 1)
+            n_sent, n_got, d_sent, d_got = self._allreduce_u64([nR + nS, totR + totS, sent, got])
+            if (n_sent, d_sent) != (n_got, d_got):
+                raise RuntimeError("all-to-all exchange corrupted the relations: sent %d tuples (digest %#x), received %d (digest %#x)"
+                                   % (n_sent, d_sent, n_got, d_got))
         e.partition(self.pkg.REL_S)
         m, agg = e.join_count()                                   # unchanged single-GPU build+probe
-        # 64-bit results as 32-bit halves so the SUM all-reduce cannot overflow int64
-        t = torch.tensor([m & 0xFFFFFFFF, m >> 32, agg & 0xFFFFFFFF, agg >> 32], dtype=torch.int64, device=self.dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
-        v = [int(x) for x in t.tolist()]
-        mask = (1 << 64) - 1
-        return (v[0] + (v[1] << 32)) & mask, (v[2] + (v[3] << 32)) & mask
+        gm, ga = self._allreduce_u64([m, agg])
+        return gm, ga

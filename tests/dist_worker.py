@@ -36,6 +36,10 @@ class OracleEngine:
         k, p, n = self.rel[rel]
         return k[:n].numpy().copy(), p[:n].numpy().copy()
 
+    def digest_pairs(self, keys, pays, n):
+        k, p = keys[:n].numpy(), pays[:n].numpy()
+        return int(o.partition_digest(k, p, np.array([0, n], np.uint64))[0]) if n else 0
+
     def partition(self, rel):
         self.rel[("part", rel)] = self._snap(rel)   # by now the exchange of this relation must be complete
 
@@ -76,8 +80,8 @@ def main():
         return torch.from_numpy(a[lo:hi].copy()).to(dev)
 
     res = []
-    for _ in range(2):  # twice: buffers are reused across steps
-        res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS)))
+    for i in range(2):  # twice: buffers are reused across steps; the first with the exchange check on
+        res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS), verify=(i == 0)))
     # an empty local slice on one rank must work too
     e = torch.empty(0, dtype=torch.int32, device=dev)
     if rank == 0:
