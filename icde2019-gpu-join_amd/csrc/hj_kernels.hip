@@ -1045,13 +1045,15 @@ size_t scatter_lds_bytes(int threads, int u) {
 
 template <int MODE, int THREADS, int U>
 static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {}; // per device: one process may hold contexts on several GPUs
     const size_t lds = scatter_lds_bytes(THREADS, U);
     auto fn = k_scatter<MODE, THREADS, U>;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
@@ -1064,13 +1066,15 @@ size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (siz
 
 template <int MODE, int U>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {}; // per device
     const size_t lds = scatter_wc_lds_bytes();
     auto fn = k_scatter_wc<MODE, U>;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
