@@ -17,6 +17,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -227,7 +230,25 @@ typedef struct {
     uint64_t *off; /* 2^bits + 1 */
 } o_parted;
 
-/* pass over [0,n): per-thread histograms on digit (key>>shift)&mask → contiguous partitions */
+/* pass over [0,n): per-thread histograms on digit (key>>shift)&mask → contiguous partitions.
+ * The scatter goes through per-thread software write-combining buffers — one 64-byte line of keys and
+ * one of payloads per partition — flushed as whole lines, with non-temporal AVX2 stores when the
+ * destination is 32-byte aligned: the scheme of the reference's CPU partitioner
+ * (partitions_host_omp_nontemporal_payload, partition-primitives.cu:40-125: per-partition buffers filled
+ * tuple by tuple, _mm256_stream_si256 on flush; histogram + prefix in partition_prepare_payload :129-220). */
+#define O_WC 16 /* tuples per write-combining line (64 bytes) */
+
+static inline void o_flush_line(int32_t *dst, const int32_t *src, unsigned cnt) {
+#ifdef __AVX2__
+    if (cnt == O_WC && (((uintptr_t)dst) & 31) == 0) {
+        _mm256_stream_si256((__m256i *)dst, _mm256_loadu_si256((const __m256i *)src));
+        _mm256_stream_si256((__m256i *)(dst + 8), _mm256_loadu_si256((const __m256i *)(src + 8)));
+        return;
+    }
+#endif
+    memcpy(dst, src, cnt * sizeof(int32_t));
+}
+
 static void o_par_partition(const int32_t *K, const int32_t *P, uint64_t n, uint32_t shift,
                             uint32_t bits, int32_t *oK, int32_t *oP, uint64_t *off, int threads) {
     uint64_t parts = 1ULL << bits;
@@ -261,11 +282,40 @@ static void o_par_partition(const int32_t *K, const int32_t *P, uint64_t n, uint
             }
             off[parts] = sum;
         }
+        /* write-combining buffers of this thread: [parts][O_WC] keys and payloads, and their fill */
+        int32_t *bk = (int32_t *)aligned_alloc(64, parts * O_WC * sizeof(int32_t));
+        int32_t *bp = (int32_t *)aligned_alloc(64, parts * O_WC * sizeof(int32_t));
+        uint8_t *fill = (uint8_t *)calloc(parts, 1);
+        /* the first line of a partition run is shortened so that later flushes land on 64-byte boundaries */
+        for (uint64_t p = 0; p < parts; p++) fill[p] = (uint8_t)(h[p] & (O_WC - 1));
         for (uint64_t i = lo; i < hi; i++) {
-            uint64_t d = h[(((uint32_t)K[i]) >> shift) & mask]++;
-            oK[d] = K[i];
-            oP[d] = P ? P[i] : 1;
+            uint32_t d = (((uint32_t)K[i]) >> shift) & mask;
+            unsigned f = fill[d];
+            bk[d * O_WC + f] = K[i];
+            bp[d * O_WC + f] = P ? P[i] : 1;
+            if (++f == O_WC) {
+                unsigned first = (unsigned)(h[d] & (O_WC - 1)); /* non-zero only for the run's first line */
+                o_flush_line(oK + h[d], bk + d * O_WC + first, O_WC - first);
+                o_flush_line(oP + h[d], bp + d * O_WC + first, O_WC - first);
+                h[d] += O_WC - first;
+                f = 0;
+            }
+            fill[d] = (uint8_t)f;
         }
+        for (uint64_t p = 0; p < parts; p++) { /* tails */
+            unsigned first = (unsigned)(h[p] & (O_WC - 1)), f = fill[p];
+            if (f > first) {
+                memcpy(oK + h[p], bk + p * O_WC + first, (f - first) * sizeof(int32_t));
+                memcpy(oP + h[p], bp + p * O_WC + first, (f - first) * sizeof(int32_t));
+                h[p] += f - first;
+            }
+        }
+#ifdef __AVX2__
+        _mm_sfence();
+#endif
+        free(bk);
+        free(bp);
+        free(fill);
     }
     free(hist);
 }
