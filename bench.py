@@ -28,9 +28,29 @@ def cpu_baseline(pkg, hj, torch, dev, max_log2n, budget_s=20.0):
     """The oracle's OpenMP radix join ("port") on a bounded sample of the same workload shape, on
     this box's host cores.  Only this leg touches oracle/.  The sample size is calibrated so that the
     join takes about budget_s seconds (at most the full 2^max_log2n workload)."""
+    import math
     import psutil
     from oracle import pyoracle as o
-    threads = o.max_threads()
+
+    def usable_cpus():
+        """Cores this process may actually use: OpenMP's maximum, the affinity mask and the cgroup CPU
+        quota (the GPU boxes show 256 logical CPUs under a 16-CPU quota: 128 threads run slower than 16)."""
+        n = min(o.max_threads(), len(os.sched_getaffinity(0)))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+            if quota != "max":
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except Exception:
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, math.ceil(q / p)))
+            except Exception:
+                pass
+        return n
+
+    threads = usable_cpus()
 
     def sample(log2n):
         n = 1 << log2n
@@ -67,8 +87,8 @@ def cpu_baseline(pkg, hj, torch, dev, max_log2n, budget_s=20.0):
     return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port",
             "sample": "2^%d x 2^%d unique uniform int32 (the GPU workload's generator and shape%s), oracle "
                       "o_radix_join_omp: two-pass OpenMP radix partition + per-partition chained build/probe, "
-                      "%d threads, %.1f s" % (log2n, log2n, ", full size" if log2n == max_log2n else ", bounded sample",
-                                               threads, dt)}
+                      "%d threads (= min of OpenMP max, affinity mask and cgroup CPU quota), %.1f s" %
+                      (log2n, log2n, ", full size" if log2n == max_log2n else ", bounded sample", threads, dt)}
 
 
 def bench_zipf(a, pkg, torch, dev, local):
