@@ -930,7 +930,18 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     if ((nR && !h_R) || (nS && !h_S)) return fail(c, HJ_EINVAL, "keys == NULL");
     if (level0_parts == 0) level0_parts = 16;
     if (level0_parts > 4096) return fail(c, HJ_EINVAL, "level0_parts out of range");
-    if (host_threads == 0) host_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (host_threads == 0) {
+        host_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        // containers: honour the cgroup v2 CPU quota (oversubscribed threads partition slower, not faster)
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32]; long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                long cpus = (atol(q) + period - 1) / period;
+                if (cpus >= 1 && (unsigned long)cpus < host_threads) host_threads = (uint32_t)cpus;
+            }
+            fclose(f);
+        }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     // host split; the partitioned copies are pinned so that the uploads are asynchronous
     int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
