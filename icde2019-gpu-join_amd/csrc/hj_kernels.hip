@@ -428,6 +428,7 @@ constexpr int WC_THREADS = 1024;
 constexpr int WC_LINE = 32;   // tuples per 128-byte line
 constexpr int WC_EXTRA = 64;  // spare lines for heavy digits
 constexpr int WC_LINES = MAX_PARTS + WC_EXTRA;
+constexpr int WC_HSTRIDE = MAX_PARTS + 64; // arrival counters per parity + 64 per-lane trash counters (branch-free ranking)
 
 struct WcLds {
     int32_t *bufK, *bufP;                   // [WC_LINES][32] each
@@ -467,17 +468,28 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
     for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
     uint32_t par = 0;
     for (uint32_t r0 = 0; r0 < rhi; r0 += ROUND, par ^= 1) {
-        uint32_t *h = hh + par * MAX_PARTS, *hprev = hh + (par ^ 1) * MAX_PARTS;
+        uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
         // ---- A: finish the previous round (kept tuples open the next line, digit owners advance
         //         their state), and rank this round's tuples (arrival counters alternate by parity) ----
+        // Lean 512-way path: BRANCH-FREE.  Operations that must not happen (nothing kept, not a tuple of
+        // this span) are redirected to per-thread trash slots/counters instead of being jumped over, so
+        // the compiler issues the 8 LDS operations of a phase back to back — one LDS round trip, not 8.
+        constexpr bool BF = (KFIX == 1 && !SKEW);
+        const uint32_t trash = MAX_PARTS * WC_LINE + tid; // a slot in the (unused on this path) spare lines
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
+            for (int e = 0; e < 4; e++) {
+                if (BF) {
+                    const uint32_t k = keep[u * 4 + e];
+                    const uint32_t idx = k != 0xFFFFFFFFu ? k : trash;
+                    bufK[idx] = elem(kk[u], e);
+                    bufP[idx] = elem(pp[u], e);
+                } else if (keep[u * 4 + e] != 0xFFFFFFFFu) {
                     bufK[keep[u * 4 + e]] = elem(kk[u], e);
                     bufP[keep[u * 4 + e]] = elem(pp[u], e);
                 }
+            }
         if (tid < P) {
             const uint32_t total = cur[tid] + hprev[tid];
             const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
@@ -494,14 +506,61 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
                 const bool valid = r + e >= rlo && r + e < rhi;
                 const uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
                 uint32_t rk = 0;
-                if (SKEW && heavy_span) rk = rank_in_digit(h, d, valid); // workgroup-uniform branch
+                if (BF) rk = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
+                else if (SKEW && heavy_span) rk = rank_in_digit(h, d, valid); // workgroup-uniform branch
                 else if (valid) { if (abl & 8u) rk = 0; else rk = atomicAdd(&h[d], 1u); }
                 code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
             }
         }
         __syncthreads();
         // ---- B: place: lines that fill this round / keep for the next line / straight to HBM ----
-        if (!(abl & 4u))
+        if (BF) {
+            uint32_t cdv[U * 4], hdv[U * 4];
+#pragma unroll
+            for (int j = 0; j < U * 4; j++) { // all 16 LDS reads first
+                const uint32_t dj = code[j] != 0xFFFFFFFFu ? code[j] >> 16 : 0u;
+                cdv[j] = cur[dj];
+                hdv[j] = h[dj];
+            }
+            bool any_bypass = false;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = u * 4 + e;
+                    const uint32_t c = code[j];
+                    const bool valid = c != 0xFFFFFFFFu;
+                    const uint32_t d = valid ? c >> 16 : 0u;
+                    const uint32_t q = cdv[j] + (c & 0xFFFFu);
+                    const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
+                    // one line per digit: slots < 32 are stored now (they either leave this round or nothing
+                    // leaves); beyond the lines that leave → kept; in between (>= 2 lines in a round) → bypass
+                    const bool now = valid && q < (uint32_t)WC_LINE;
+                    const bool kept = valid && !now && q >= full;
+                    any_bypass |= valid && !now && q < full;
+                    const uint32_t idx = now ? d * WC_LINE + q : trash;
+                    bufK[idx] = elem(kv[u], e);
+                    bufP[idx] = elem(pv[u], e);
+                    keep[j] = kept ? d * WC_LINE + (q - full) : 0xFFFFFFFFu;
+                }
+            if (any_bypass) { // rare (a digit received more than a line in one round)
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int j = u * 4 + e;
+                        const uint32_t c = code[j];
+                        if (c != 0xFFFFFFFFu) {
+                            const uint32_t q = cdv[j] + (c & 0xFFFFu);
+                            const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
+                            if (q >= (uint32_t)WC_LINE && q < full) {
+                                out_keys[line[c >> 16] + q] = elem(kv[u], e);
+                                out_pays[line[c >> 16] + q] = elem(pv[u], e);
+                            }
+                        }
+                    }
+            }
+        } else if (!(abl & 4u))
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -613,7 +672,7 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
     }
     // ---- epilogue: phase A of the last round, then the partially filled last line of every digit ----
     {
-        uint32_t *hprev = hh + (par ^ 1) * MAX_PARTS;
+        uint32_t *hprev = hh + (par ^ 1) * WC_HSTRIDE;
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -653,7 +712,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     L_.bufK = reinterpret_cast<int32_t *>(smem);
     L_.bufP = L_.bufK + WC_LINES * WC_LINE;
     L_.hh = reinterpret_cast<uint32_t *>(L_.bufP + WC_LINES * WC_LINE); // [2][MAX_PARTS] arrivals, by round parity
-    L_.cur = L_.hh + 2 * MAX_PARTS;   // occupied slots of the digit's lines
+    L_.cur = L_.hh + 2 * WC_HSTRIDE;  // occupied slots of the digit's lines
     L_.line = L_.cur + MAX_PARTS;     // output position of slot 0 (multiple of 32)
     L_.lo = L_.line + MAX_PARTS;      // first valid slot (non-zero only for the first line)
     L_.capb = L_.lo + MAX_PARTS;      // (number of lines << 16) | first line of the digit   (SKEW path)
@@ -688,7 +747,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     (void)block_excl_scan<uint32_t>(heavy, scratch, &any_heavy);
     if (tid < P) L_.capb[tid] = ((K + extra) << 16) | (tid * K + ex);
     __syncthreads();                     // scratch (aliases hh) is no longer read
-    for (uint32_t d = tid; d < 2 * MAX_PARTS; d += WC_THREADS) L_.hh[d] = 0;
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     __syncthreads();
     // block_excl_scan hands the workgroup totals to every thread: the branch is workgroup-uniform
     if (total_extra == 0 && any_heavy == 0) {
@@ -1062,7 +1121,7 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
 
 hipError_t set_wc_ablate(uint32_t v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wc_ablate), &v, sizeof v); }
 
-size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 6 + (WC_THREADS / 64) * 32 * 4; }
+size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 4 + (size_t)WC_HSTRIDE * 4 * 2 + (WC_THREADS / 64) * 32 * 4; }
 
 template <int MODE, int U>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
