@@ -845,6 +845,32 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
             const uint64_t i = w0 + (uint64_t)lane_id() * 4;
             int4 kv = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
             if (i < q1) { kv = load4(a.pk, i, a.p_nalloc); pv = load4(a.pp, i, a.p_nalloc); }
+            if (JM == 0) {
+                // count-only: the four bucket heads of this lane's four tuples are fetched first and the four
+                // chains are walked in lockstep, so their LDS reads overlap instead of completing one by one
+                uint32_t pos4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint64_t idx = i + e;
+                    const bool valid = idx >= q0 && idx < q1;
+                    pos4[e] = (valid ? head[((uint32_t)elem(kv, e) >> bits) & nhm] : 0xFFFFFFFFu) & 0xFFFFu;
+                }
+                while ((pos4[0] & pos4[1] & pos4[2] & pos4[3]) != 0xFFFFu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t pos = pos4[e];
+                        if (pos != 0xFFFFu) {
+                            const uint32_t key = (uint32_t)elem(kv, e);
+                            const bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                            if (eq) {
+                                my_matches++;
+                                my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)elem(pv, e));
+                            }
+                            pos4[e] = lnext[pos];
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 uint64_t idx = i + e;
