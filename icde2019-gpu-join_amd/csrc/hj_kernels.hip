@@ -11,8 +11,10 @@
 // What this file does instead (MI355X-first):
 //   * partitions are CONTIGUOUS (64-bit offsets), not bucket chains: a keys-only histogram kernel,
 //     a device-side scan, and a scatter kernel whose workgroups own long contiguous spans, so each
-//     (span, digit) output run is a private, contiguous HBM region that the workgroup fills tile by
-//     tile through an LDS reorder buffer (wave64, 512-thread workgroups, 8192-tuple tiles).
+//     (span, digit) output run is a private, contiguous HBM region.  The workgroup (1024 threads,
+//     wave64) appends tuples to per-digit 128-byte LDS write-combining lines and flushes only whole,
+//     128-byte-aligned lines with 16-byte stores (k_scatter_wc); a sorted-tile variant (k_scatter)
+//     serves narrow fan-out (the multi-GPU shard split).
 //     Nothing is read back to the host between kernels; grids are launched at their upper bound.
 //   * the join kernel builds a chained hash table in LDS per build partition (16-bit tags when the
 //     radix bits leave <= 16 key bits, full keys otherwise) and probes it with coalesced 16-byte
