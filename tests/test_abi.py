@@ -57,3 +57,31 @@ def test_fails_loudly_without_gpu():
     import numpy as np
     r = p.hashJoinClusteredProbe(np.arange(8, dtype=np.int32), np.arange(8, dtype=np.int32))
     assert r["status"] != 0 and r["matches"] == 0
+
+
+def _build_c_client(tmp_path):
+    """gcc (not hipcc), C99, only include/*.h: the ABI is consumable from plain C."""
+    import subprocess
+    p = pkg()
+    p._lib.build()
+    exe = str(tmp_path / "c_abi_client")
+    libdir = os.path.dirname(p._lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_client.c"), "-o", exe, "-L", libdir, "-lhj",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_c_client_builds_and_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_client_on_gpu(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_abi_client ok: 150000 matches" in r.stdout
