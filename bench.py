@@ -348,6 +348,10 @@ def main():
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / reps
         assert nout == expect
+        if dup == 1:
+            # full-size property check (outside the timed region): with unique keys and payloads = 1 the output
+            # multiset is {(k,1,1) : k in R}; its order-independent digest must equal that of (R keys, 1, 1)
+            assert hj.digest_triples(ok, opr, ops, nout) == hj.digest_triples(Rk, Rp, Sp, n), "materialised output digest"
         km = hj.timings()
         mk = km.get("k_join_materialize", {"launches": 0, "total_ms": 0.0})
         mat = {"value": round(2.0 * n / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3),
