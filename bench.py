@@ -189,6 +189,26 @@ def bench_stream(a, pkg, torch, dev, local):
                       "config": {"workload": "PK-FK 2^27 x 2^30, S streamed from pinned host memory in segments of max(|R|/4, 2^24)"}}))
 
 
+def launch_ranks(n):
+    """Re-run this script under torch.distributed.run with n ranks on this node (child process, never an exec:
+    this process has not touched the GPU and stays alive to forward the result)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout[-4000:] + p.stderr[-8000:])
+        sys.exit(p.returncode or 1)
+    print(lines[-1])
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,11 +223,19 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even at world size 1 (sanity runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stream-copy ceiling and the phase split (profiling runs)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, RCCL over
+        # xGMI) before anything here touches the GPU, forward rank 0's JSON line and the launcher's exit code.
+        return launch_ranks(a.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

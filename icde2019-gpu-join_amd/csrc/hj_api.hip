@@ -149,8 +149,29 @@ hipEvent_t get_event(hj_ctx *c) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr; // the caller skips timing this launch
     return e;
+}
+
+void account(hj_ctx *c, const Stamp &s) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+        KStat &k = c->kstats[s.kid];
+        k.launches++;
+        k.total_ms += ms;
+        k.last_ms = ms;
+    }
+    c->pool.push_back(s.a);
+    c->pool.push_back(s.b);
+}
+
+// Stamps whose end event has completed are folded into the per-kernel statistics and their events go back
+// to the pool.  Called from every launch once the backlog is long, so a caller that never asks for
+// hj_timings (or never synchronises) holds a bounded number of HIP events.
+void resolve_completed(hj_ctx *c) {
+    size_t done = 0;
+    while (done < c->stamps.size() && hipEventQuery(c->stamps[done].b) == hipSuccess) account(c, c->stamps[done++]);
+    if (done) c->stamps.erase(c->stamps.begin(), c->stamps.begin() + (long)done);
 }
 
 // RAII: HIP events on the context stream around one kernel launch
@@ -168,9 +189,16 @@ struct Timed {
     Timed(hj_ctx *ctx, const char *name, hipStream_t stream = nullptr, bool use_given = false)
         : c(ctx), on(ctx->events == 2 || (ctx->events == 1 && is_main(name))), st(use_given ? stream : ctx->stream) {
         if (!on) return;
+        if (c->stamps.size() >= 256) resolve_completed(c);
         s.kid = kid_of(c, name);
         s.a = get_event(c);
         s.b = get_event(c);
+        if (!s.a || !s.b) { // out of events: run untimed rather than record a null event
+            if (s.a) c->pool.push_back(s.a);
+            if (s.b) c->pool.push_back(s.b);
+            on = false;
+            return;
+        }
         (void)hipEventRecord(s.a, st);
     }
     ~Timed() {
@@ -180,18 +208,9 @@ struct Timed {
     }
 };
 
+// after a synchronisation of every stream that carries stamps
 void resolve_stamps(hj_ctx *c) {
-    for (auto &s : c->stamps) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-            KStat &k = c->kstats[s.kid];
-            k.launches++;
-            k.total_ms += ms;
-            k.last_ms = ms;
-        }
-        c->pool.push_back(s.a);
-        c->pool.push_back(s.b);
-    }
+    for (auto &s : c->stamps) account(c, s);
     c->stamps.clear();
 }
 
@@ -479,10 +498,7 @@ int run_count(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullpt
     uint64_t *sc = (uint64_t *)c->scalars.p;
     const size_t lds = join_lds_bytes(c->nh, c->cap, tag16);
     if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
-    if (lds > c->lds_limit) {
-        HIPCHK(c, join_set_lds_limit(lds));
-        c->lds_limit = lds;
-    }
+    HIPCHK(c, join_set_lds_limit(c->device, lds)); // per device, only ever raised (contexts share the functions)
     { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, B.part_off, Pb.part_off, nparts, c->chunk, (uint32_t *)c->items_cnt.p)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
@@ -516,6 +532,7 @@ int run_count(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullpt
 int fetch_scalars(hj_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 8 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_completed(c); // every [sync] entry point folds finished stamps: the event backlog stays bounded
     return 0;
 }
 
@@ -867,8 +884,11 @@ int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays
         if ((rc = hj_join_count(c, &m, &a))) break; // [sync]: the next copy is already in flight
         tot_m += m; tot_a += a;
     }
+    // on every exit path: the H2D copy of the next segment may still be reading the caller's columns
+    (void)hipStreamSynchronize(c->copy);
     c->force_build_r = saved_force;
-    c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation
+    c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation: S is unbound afterwards (hj.h)
+    c->rel[HJ_REL_S].n = 0;
     invalidate(c, HJ_REL_S);
     if (rc) return rc;
     if (matches) *matches = tot_m;

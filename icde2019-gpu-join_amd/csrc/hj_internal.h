@@ -72,7 +72,7 @@ hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t
 hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
                               const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
-hipError_t join_set_lds_limit(size_t bytes);
+hipError_t join_set_lds_limit(int device, size_t bytes);
 hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise, 2 late materialisation
 hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max);
 hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, const int32_t *bp, const int32_t *pk, const int32_t *pp,

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "hj_internal.h"
 
 namespace hj {
@@ -1072,6 +1074,10 @@ __global__ __launch_bounds__(256) void k_verify_partitions(const int32_t *__rest
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (device, function) pair, not to a context: the
+// high-water marks are kept per device and only ever raised, under a lock (one context per host thread).
+static std::mutex g_attr_mutex;
+
 #define HJ_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n) {
@@ -1137,6 +1143,7 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     auto fn = k_scatter<MODE, THREADS, U>;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1158,6 +1165,7 @@ static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
     auto fn = k_scatter_wc<MODE, U>;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1209,7 +1217,10 @@ size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16) {
     return (b + 15) & ~(size_t)15;
 }
 
-hipError_t join_set_lds_limit(size_t bytes) {
+hipError_t join_set_lds_limit(int device, size_t bytes) {
+    static size_t limit[64] = {};
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (device >= 0 && device < 64 && bytes <= limit[device]) return hipSuccess;
     const void *fns[] = {reinterpret_cast<const void *>(&k_join<true, 0>), reinterpret_cast<const void *>(&k_join<true, 1>),
                          reinterpret_cast<const void *>(&k_join<true, 2>), reinterpret_cast<const void *>(&k_join<false, 0>),
                          reinterpret_cast<const void *>(&k_join<false, 1>), reinterpret_cast<const void *>(&k_join<false, 2>)};
@@ -1217,6 +1228,7 @@ hipError_t join_set_lds_limit(size_t bytes) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }
+    if (device >= 0 && device < 64) limit[device] = bytes;
     return hipSuccess;
 }
 

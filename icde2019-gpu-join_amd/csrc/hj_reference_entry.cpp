@@ -24,7 +24,7 @@
 
 namespace {
 
-hj_last_result g_last;
+thread_local hj_last_result g_last; // one per calling thread: contexts on several GPUs may be driven by several threads
 
 double cpu_seconds() { // common-host.cpp:26-30
     struct timeval tp;

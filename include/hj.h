@@ -54,7 +54,10 @@ typedef struct hj_config {
     uint32_t reserved[9];
 } hj_config;
 
-/* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream). */
+/* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream).
+ * Timing of the data-moving kernels is on by default (HJ_KERNEL_EVENTS=none switches it off); finished
+ * measurements are folded into the statistics at every [sync] call and whenever 256 are pending, so the
+ * number of live HIP events is bounded whether or not hj_timings is ever called. */
 typedef struct hj_kernel_time {
     char name[32];
     uint32_t launches; /* launches since hj_timings_reset */
@@ -119,7 +122,10 @@ int hj_join_nonpartitioned(hj_ctx *ctx, int kind, uint64_t *matches, uint64_t *a
  *      streamed through HBM in segments — H2D copy of segment i+1 on a copy stream while segment i is
  *      partitioned and joined against R, which is partitioned once.  R must be loaded/bound first and always
  *      builds.  segment_tuples = 0 picks max(|R|/4, 2^24) (the reference uses |R|/4, hjcp.cu:1697-1698).
- *      Row-id payloads count from 0 over the whole of S.  Count-only.  [sync] ---- */
+ *      Row-id payloads count from 0 over the whole of S.  Count-only.  [sync]
+ *      Side effects: any S relation bound/loaded before the call is unbound afterwards (the staging buffers
+ *      take its place); R's partitions are reused across calls while the radix bits stay the same, so re-bind
+ *      R after modifying a bound column in place. ---- */
 int hj_join_stream_probe(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pays, uint64_t n,
                          uint64_t segment_tuples, int payload_mode, uint64_t *matches, uint64_t *agg);
 

@@ -22,3 +22,11 @@ def golden_dir():
 def manifest():
     import json
     return json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.fixture(scope="session")
+def join_answers():
+    """What the REFERENCE's own joinCpu (hjcp.cu:2013-2059, compiled from where it lies by oracle/Makefile)
+    printed for pairs of golden relations: s = matching pairs, g = sum of matching S keys mod 2^32."""
+    import json
+    return json.load(open(os.path.join(GOLDEN, "join_answers.json")))["joins"]

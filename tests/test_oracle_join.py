@@ -129,3 +129,53 @@ def test_config1_full_size():
     assert o.join_count(R, None, R, None, checksum=False)[0] == n
     assert o.joinCpu(R, R, threads=o.max_threads())[0] == n
     assert o.radix_join_omp(R, None, R, None, 5, 5, o.max_threads())[0] == n
+
+
+# ---- the join half of the oracle, pinned to the REFERENCE's own CPU join ---------------------------
+def test_oracle_matches_reference_joinCpu_answers(join_answers, golden_dir):
+    """tests/golden/join_answers.json holds what the reference's joinCpu + h_hashMurmur
+    (hash_join_clustered_probe.cu:2013-2059, compiled unmodified from where it lies: oracle/_ref/refjoin,
+    script tests/golden/make_golden.py) printed for these golden pairs.  Every oracle restatement of the
+    join must reproduce its match count s and its key sum g."""
+    assert len(join_answers) >= 15
+    for a in join_answers:
+        R, S = _load(golden_dir, a["R"]), _load(golden_dir, a["S"])
+        assert a["build"] == len(R) and a["c"] == len(R) + len(S)
+        m, agg, chk = o.join_count(R, None, S, None)
+        assert m == a["s"], (a, m)                                     # sort-merge restatement
+        assert o.joinCpu(R, S) == (a["s"], a["g"]), a                  # restated joinCpu: same s AND g
+        assert o.joinCpu(R, S, threads=3) == (a["s"], a["g"]), a
+        assert o.radix_join_omp(R, None, S, None, 4, 3, 2)[0] == a["s"], a
+        # g through the payload path: payR = 1, payS = key → sum payR*payS = sum of matching S keys
+        assert o.join_count(R, None, S, S)[1] % 2**32 == a["g"], a
+        k, pr, ps = o.join_materialize(R, None, S, None)
+        assert len(k) == a["s"] and int(k.astype(np.int64).sum()) % 2**32 == a["g"], a
+
+
+REFJOIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "refjoin")
+
+
+@pytest.mark.skipif(not os.path.exists(REFJOIN), reason="oracle/_ref/refjoin is only built where /root/reference exists")
+def test_oracle_vs_reference_joinCpu_live(tmp_path):
+    """In the build container: the reference's joinCpu run live on fresh seeded inputs (duplicates on both
+    sides, negative keys, empty sides) against the oracle."""
+    import subprocess
+    rng = np.random.default_rng(2024)
+    cases = [(rng.integers(-500, 500, 3000), rng.integers(-500, 500, 5000)),
+             (rng.integers(0, 2**31 - 1, 4000), rng.integers(0, 2**31 - 1, 4000)),
+             (rng.permutation(20000), rng.integers(0, 25000, 50000)),
+             (np.full(300, 7), np.full(200, 7)),
+             (np.arange(10), np.empty(0, np.int64)),
+             (np.array([-2**31, 2**31 - 1, 0, -1]), np.array([-1, -2**31, 5, 2**31 - 1, -1]))]
+    for i, (R, S) in enumerate(cases):
+        R, S = R.astype(np.int32), S.astype(np.int32)
+        fr, fs = tmp_path / ("r%d.bin" % i), tmp_path / ("s%d.bin" % i)
+        R.tofile(fr)
+        S.tofile(fs)
+        out = subprocess.run([REFJOIN, str(fr), str(fs)], stdout=subprocess.PIPE, check=True,
+                             env=dict(os.environ, OMP_NUM_THREADS="1")).stdout.decode().splitlines()
+        s, c, g = (int(x) for x in [l for l in out if l.startswith("===")][1][3:].split())
+        assert c == len(R) + len(S)
+        assert o.join_count(R, None, S, None)[0] == s
+        assert o.joinCpu(R, S) == (s, g)
+        assert o.join_count(R, None, S, S)[1] % 2**32 == g
