@@ -325,7 +325,7 @@ def main():
 
     # roofline of the dominant kernel: the radix scatter (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
-    dom = max(("k_scatter_wc", "k_scatter"), key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
+    dom = max(("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter"), key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
     sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
     roof = None
     if sc["launches"] and not use_dist:

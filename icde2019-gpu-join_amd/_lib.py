@@ -16,7 +16,7 @@ vp = C.c_void_p
 class Config(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
                 ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
-                ("probe_chunk", C.c_uint32), ("reserved", C.c_uint32 * 9)]
+                ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("reserved", C.c_uint32 * 8)]
 
 
 class KernelTime(C.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     "hj_load_host": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64, C.c_int]),
     "hj_bind_device": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64]),
     "hj_partition": (C.c_int, [vp, C.c_int]),
+    "hj_partition_layout": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "hj_join_count": (C.c_int, [vp, u64p, u64p]),
     "hj_join_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
     "hj_join": (C.c_int, [vp, u64p, u64p]),

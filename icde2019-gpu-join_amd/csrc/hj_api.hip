@@ -41,12 +41,19 @@ struct Rel {
     bool bound = false;
     Buf own_k, own_p;         // hj_load_host copies
     Buf a_k, a_p, b_k, b_p;   // pass-1 / final partitioned columns
-    Buf off1, off2, root;     // partition offsets (uint64)
+    Buf off1, off2, root;     // partition offsets (uint64) of the exact passes
+    Buf beg, end;             // final partition ranges [nparts] (uint64): what the join reads, whichever path ran
+    Buf s1beg, s1end;         // slot ranges written by the histogram-free pass 1 [P1 * nspans]
+    Buf flag;                 // device uint32: the histogram-free passes gave up (a slot overflowed)
+    Buf comp_k, comp_p, comp_off; // gap-free copy for hj_get_partitions when the layout is slotted
     const int32_t *part_k = nullptr, *part_p = nullptr;
-    const uint64_t *part_off = nullptr;
+    const uint64_t *part_beg = nullptr, *part_end = nullptr;
+    const uint64_t *part_off = nullptr; // nparts+1 contiguous offsets: only valid when the exact passes ran
+    uint64_t n_alloc = 0;      // elements of the partitioned columns (bounds of 16-byte tail loads)
     uint32_t nparts = 0;
     uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
     bool partitioned = false;
+    bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
 };
 
 } // namespace
@@ -61,8 +68,6 @@ struct hj_ctx {
     Rel rel[2];
     // workspace
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
-    hipStream_t aux = nullptr;   // histograms of one relation run here while the other relation scatters
-    hipEvent_t dep[10] = {};     // dependency events between the two streams (no timing)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
     Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64)
@@ -71,10 +76,10 @@ struct hj_ctx {
     bool last_tag16 = false;
     uint64_t last_matches = 0, last_agg = 0;
     uint32_t max_items = 0;
-    size_t lds_limit = 0;
     int scatter_variant = -1;
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
+    int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)
     uint64_t *h_shard_off = nullptr;
@@ -181,7 +186,7 @@ struct Timed {
     bool on;
     hipStream_t st;
     static bool is_main(const char *n) {
-        return !strncmp(n, "k_hist", 6) || !strncmp(n, "k_scatter", 9) || !strncmp(n, "k_join_count", 12) ||
+        return !strncmp(n, "k_hist", 6) || !strncmp(n, "k_scatter", 9) || !strncmp(n, "k_part", 6) || !strncmp(n, "k_join_count", 12) ||
                !strncmp(n, "k_join_mat", 10) || !strncmp(n, "k_join_late", 11) || !strncmp(n, "k_np_", 5);
     }
     // Each timed launch costs two event records on the stream; timing all ~35 launches of a step costs 4 %
@@ -260,27 +265,27 @@ void choose_bits(hj_ctx *c) {
     }
 }
 
-// one radix pass: in(keys,pays) partitioned by parents → out, child offsets → coff.
-// prep (allocations, may synchronise) / histogram chain / scatter are separate so that the histogram
-// chain of one relation can run on the aux stream while the other relation scatters.
+// one exact radix pass: in(keys,pays), parents = contiguous ranges poff[0..nparents] → out, child offsets → coff
 int pass_prep(hj_ctx *c, int wsid, const int32_t *in_k, const int32_t *in_p, uint64_t n, const uint64_t *poff,
               uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
               PassArgs &pa) {
-    if (nparents > (uint32_t)MAX_PARENTS || P > (uint32_t)MAX_PARTS || P == 0) return fail(c, HJ_EINVAL, "pass fan-out out of range");
+    if (nparents > (uint32_t)MAX_SEGS || P > (uint32_t)MAX_PARTS || P == 0) return fail(c, HJ_EINVAL, "pass fan-out out of range");
     if (n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU pass (n < 2^32 required)");
     const uint32_t target_spans = c->target_spans ? c->target_spans : TARGET_SPANS;
     uint64_t span64 = (n + target_spans - 1) / target_spans;
     span64 = ((span64 + TILE - 1) / TILE) * TILE;
     if (span64 < (uint64_t)TILE) span64 = TILE;
     pa = PassArgs{};
-    pa.keys = in_k; pa.pays = in_p; pa.nalloc = n; pa.poff = poff; pa.nparents = nparents;
+    pa.keys = in_k; pa.pays = in_p; pa.nalloc = n;
+    pa.sbeg = poff; pa.send = poff + 1; pa.nseg = nparents; pa.spp = 1; pa.nparents = nparents;
     pa.span = (uint32_t)span64;
     pa.max_spans = (uint32_t)((n + span64 - 1) / span64) + nparents;
     pa.shift = shift; pa.P = P; pa.mask_or_n = mask_or_n;
+    pa.n_out = n;
     const uint64_t max_len = (uint64_t)pa.max_spans * P;
     const uint64_t nchunks = (max_len + SCAN_CHUNK - 1) / SCAN_CHUNK + 2;
     hj_ctx::PassWs &w = c->ws[wsid];
-    RET(ensure(c, w.span_start, (size_t)(MAX_PARENTS + 1) * 4));
+    RET(ensure(c, w.span_start, (size_t)(MAX_SEGS + 1) * 4));
     RET(ensure(c, w.hist, (size_t)max_len * 4));
     RET(ensure(c, w.chunk_sums, (size_t)nchunks * 8));
     RET(ensure(c, w.chunk_prefix, (size_t)nchunks * 8));
@@ -294,9 +299,9 @@ int pass_prep(hj_ctx *c, int wsid, const int32_t *in_k, const int32_t *in_p, uin
 
 int pass_hist(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa, uint64_t n, uint64_t *coff) {
     const uint64_t max_len = (uint64_t)pa.max_spans * pa.P;
-    { Timed t(c, "k_plan", st, true); HIPCHK(c, launch_plan(st, pa.poff, pa.nparents, pa.span, pa.span_start)); }
+    { Timed t(c, "k_plan", st, true); HIPCHK(c, launch_plan(st, pa)); }
     { Timed t(c, "k_hist", st, true); HIPCHK(c, launch_hist(st, mode, pa)); }
-    { Timed t(c, "k_scan", st, true); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + pa.nparents, pa.P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr)); }
+    { Timed t(c, "k_scan", st, true); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + pa.nseg, pa.P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr, pa.run_if)); }
     { Timed t(c, "k_offsets", st, true); HIPCHK(c, launch_offsets(st, pa, n, coff)); }
     return 0;
 }
@@ -309,11 +314,14 @@ int pass_scatter(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa) {
     return 0;
 }
 
+// run_if: optional device flag; the whole pass is skipped on the device when it reads 0.  beg/end: optional
+// ranges of the child partitions for the join.
 int run_pass(hj_ctx *c, int wsid, int mode, const int32_t *in_k, const int32_t *in_p, uint64_t n, const uint64_t *poff,
              uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
-             uint64_t *coff) {
+             uint64_t *coff, const uint32_t *run_if = nullptr, uint64_t *beg = nullptr, uint64_t *end = nullptr) {
     PassArgs pa;
     RET(pass_prep(c, wsid, in_k, in_p, n, poff, nparents, shift, P, mask_or_n, out_k, out_p, pa));
+    pa.run_if = run_if; pa.beg = beg; pa.end = end;
     RET(pass_hist(c, c->stream, mode, pa, n, coff));
     return pass_scatter(c, c->stream, mode, pa);
 }
@@ -330,6 +338,25 @@ void invalidate(hj_ctx *c, int rel = -1) {
     c->join_planned = false;
 }
 
+// Geometry of the histogram-free passes for a relation of n tuples (see hj_kernels.hip): spans of pass 1, slot
+// capacities of both passes.  false when the slotted layout would not fit 32-bit positions.
+struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; };
+bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f) {
+    if (n == 0) return false;
+    const uint32_t target = c->target_spans ? c->target_spans : 512; // 2 workgroups per CU
+    uint64_t span = (n + target - 1) / target;
+    span = ((span + TILE - 1) / TILE) * TILE;
+    uint64_t nspans = (n + span - 1) / span;
+    while (nspans > 1024) { span += TILE; nspans = (n + span - 1) / span; } // one LDS table entry per span in pass 2
+    f.span = (uint32_t)span; f.nspans = (uint32_t)nspans;
+    f.cap1 = fast_slot_cap((span + P1 - 1) / P1, P1);
+    f.cap2 = fast_slot_cap((n + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
+    f.sizeA = (uint64_t)P1 * nspans * f.cap1;
+    f.sizeB = (uint64_t)P1 * P2 * f.cap2;
+    const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
+    return f.sizeA < lim && f.sizeB < lim;
+}
+
 int partition_rel(hj_ctx *c, int r) {
     Rel &R = c->rel[r];
     if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
@@ -338,140 +365,92 @@ int partition_rel(hj_ctx *c, int r) {
     RET(ensure(c, R.root, 2 * 8));
     { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n)); }
     const uint32_t b1 = c->bits1, b2 = c->bits2;
+    R.fast_tried = false;
+    R.part_off = nullptr;
     if (b1 == 0) { // nothing to partition: one partition = the input itself
-        R.part_k = R.in_k; R.part_p = R.in_p; R.part_off = (const uint64_t *)R.root.p; R.nparts = 1;
+        R.part_k = R.in_k; R.part_p = R.in_p; R.nparts = 1; R.n_alloc = R.n;
+        R.part_off = (const uint64_t *)R.root.p;
+        R.part_beg = R.part_off; R.part_end = R.part_off + 1;
         R.pb1 = R.pb2 = 0;
         R.partitioned = true;
         c->join_planned = false;
         return 0;
     }
-    const size_t colbytes = (size_t)(R.n + PAD) * 4;
-    RET(ensure(c, R.b_k, colbytes));
-    RET(ensure(c, R.b_p, colbytes));
     const uint32_t P1 = 1u << b1, P2 = 1u << b2;
+    const uint32_t nparts = b2 ? P1 * P2 : P1;
+    FastPlan f{};
+    const bool fast = b2 && c->fast_path && !c->cfg.exact_only && plan_fast(c, R.n, P1, P2, f);
+    const uint64_t elemsA = std::max<uint64_t>(R.n, fast ? f.sizeA : 0), elemsB = std::max<uint64_t>(R.n, fast ? f.sizeB : 0);
+    RET(ensure(c, R.b_k, (size_t)(elemsB + PAD) * 4));
+    RET(ensure(c, R.b_p, (size_t)(elemsB + PAD) * 4));
+    RET(ensure(c, R.beg, (size_t)nparts * 8));
+    RET(ensure(c, R.end, (size_t)nparts * 8));
+    uint64_t *beg = (uint64_t *)R.beg.p, *end = (uint64_t *)R.end.p;
     if (b2 == 0) {
         RET(ensure(c, R.off2, (size_t)(P1 + 1) * 8));
         RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, 0, P1, P1 - 1, (int32_t *)R.b_k.p,
-                     (int32_t *)R.b_p.p, (uint64_t *)R.off2.p));
-        R.nparts = P1;
+                     (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, nullptr, beg, end));
     } else {
-        RET(ensure(c, R.a_k, colbytes));
-        RET(ensure(c, R.a_p, colbytes));
+        RET(ensure(c, R.a_k, (size_t)(elemsA + PAD) * 4));
+        RET(ensure(c, R.a_p, (size_t)(elemsA + PAD) * 4));
         RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
         RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
+        const uint32_t *run_if = nullptr;
+        if (fast) {
+            // ---- histogram-free passes first; the exact passes below are queued behind them and run (on the
+            //      device's say-so, no host round trip) only if a slot overflowed ----
+            RET(ensure(c, R.flag, 64));
+            RET(ensure(c, R.s1beg, (size_t)P1 * f.nspans * 8));
+            RET(ensure(c, R.s1end, (size_t)P1 * f.nspans * 8));
+            uint32_t *ovf = (uint32_t *)R.flag.p;
+            HIPCHK(c, hipMemsetAsync(ovf, 0, 4, st));
+            FastArgs fa{};
+            fa.keys = R.in_k; fa.pays = R.in_p; fa.n = R.n; fa.span = f.span; fa.nspans = f.nspans;
+            fa.shift = b2; fa.P = P1; fa.cap = f.cap1;
+            fa.out_keys = (int32_t *)R.a_k.p; fa.out_pays = (int32_t *)R.a_p.p;
+            fa.obeg = (uint64_t *)R.s1beg.p; fa.oend = (uint64_t *)R.s1end.p; fa.ovf = ovf;
+            { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(st, fa)); }
+            FastArgs fb{};
+            fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
+            fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = f.nspans;
+            fb.shift = 0; fb.P = P2; fb.cap = f.cap2;
+            fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
+            fb.obeg = beg; fb.oend = end; fb.ovf = ovf;
+            { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(st, fb)); }
+            run_if = ovf;
+            R.fast_tried = true;
+        }
         // pass 1 on key bits [b2, b2+b1), pass 2 on bits [0, b2): final partition id = low b1+b2 key
         // bits, pass-1 digit major — the order of jp.cu:402 ((pid << log_parts2) + j)
         RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, (int32_t *)R.a_k.p,
-                     (int32_t *)R.a_p.p, (uint64_t *)R.off1.p));
+                     (int32_t *)R.a_p.p, (uint64_t *)R.off1.p, run_if));
         RET(run_pass(c, r, 0, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
-                     P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, (uint64_t *)R.off2.p));
-        R.nparts = P1 * P2;
+                     P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, run_if, beg, end));
     }
+    R.nparts = nparts;
     R.part_k = (const int32_t *)R.b_k.p;
     R.part_p = (const int32_t *)R.b_p.p;
-    R.part_off = (const uint64_t *)R.off2.p;
+    R.part_beg = beg; R.part_end = end;
+    R.part_off = R.fast_tried ? nullptr : (const uint64_t *)R.off2.p;
+    R.n_alloc = elemsB;
     R.pb1 = b1; R.pb2 = b2;
     R.partitioned = true;
     c->join_planned = false;
     return 0;
 }
 
-// Both relations, interleaved: scatters run back to back on the main stream in the order R1, S1, R2, S2
-// while the (keys-only, 2 KB LDS) histogram chains run on the aux stream next to the other relation's
-// scatter — k_scatter_wc leaves the HBM pipe idle during its LDS phases and k_hist fills it.  Only the
-// first histogram is exposed.  Dependencies are HIP events; nothing is read back to the host.
-int partition_both(hj_ctx *c) {
-    for (int r = 0; r < 2; r++)
-        if (!c->rel[r].bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
-    choose_bits(c);
-    const uint32_t b1 = c->bits1, b2 = c->bits2;
-    if (b1 == 0 || !c->aux) { // nothing to overlap
-        RET(partition_rel(c, 0));
-        return partition_rel(c, 1);
-    }
-    const uint32_t P1 = 1u << b1, P2 = 1u << b2;
-    hipStream_t mainst = c->stream, aux = c->aux;
-    PassArgs p1[2], p2[2];
-    // ---- all allocations first (they may synchronise) ----
-    for (int r = 0; r < 2; r++) {
-        Rel &R = c->rel[r];
-        const size_t colbytes = (size_t)(R.n + PAD) * 4;
-        RET(ensure(c, R.root, 2 * 8));
-        RET(ensure(c, R.b_k, colbytes));
-        RET(ensure(c, R.b_p, colbytes));
-        if (b2) {
-            RET(ensure(c, R.a_k, colbytes));
-            RET(ensure(c, R.a_p, colbytes));
-            RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
-            RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
-        } else {
-            RET(ensure(c, R.off2, (size_t)(P1 + 1) * 8));
-        }
-    }
-    for (int r = 0; r < 2; r++) {
-        Rel &R = c->rel[r];
-        int32_t *o1k = (int32_t *)(b2 ? R.a_k.p : R.b_k.p), *o1p = (int32_t *)(b2 ? R.a_p.p : R.b_p.p);
-        RET(pass_prep(c, r, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, o1k, o1p, p1[r]));
-    }
-    // pass 2 shares the relation's workspace with pass 1 (serial per relation): size it for the larger
-    if (b2) {
-        for (int r = 0; r < 2; r++) {
-            Rel &R = c->rel[r];
-            PassArgs tmp;
-            RET(pass_prep(c, r, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
-                          P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, tmp));
-        }
-        for (int r = 0; r < 2; r++) { // again: the buffers may have grown, take the final pointers
-            Rel &R = c->rel[r];
-            int32_t *o1k = (int32_t *)R.a_k.p, *o1p = (int32_t *)R.a_p.p;
-            RET(pass_prep(c, r, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, o1k, o1p, p1[r]));
-            RET(pass_prep(c, r, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
-                          P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, p2[r]));
-        }
-    }
-    hipEvent_t *ev = c->dep;
-    // fork: aux starts after whatever produced the inputs on the main stream
-    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(mainst, (uint64_t *)c->rel[0].root.p, c->rel[0].n));
-      HIPCHK(c, launch_set_root(mainst, (uint64_t *)c->rel[1].root.p, c->rel[1].n)); }
-    HIPCHK(c, hipEventRecord(ev[0], mainst));
-    HIPCHK(c, hipStreamWaitEvent(aux, ev[0], 0));
-    uint64_t *off_first[2] = {(uint64_t *)(b2 ? c->rel[0].off1.p : c->rel[0].off2.p), (uint64_t *)(b2 ? c->rel[1].off1.p : c->rel[1].off2.p)};
-    // aux: hist R1, hist S1
-    RET(pass_hist(c, aux, 0, p1[0], c->rel[0].n, off_first[0])); HIPCHK(c, hipEventRecord(ev[1], aux));
-    RET(pass_hist(c, aux, 0, p1[1], c->rel[1].n, off_first[1])); HIPCHK(c, hipEventRecord(ev[2], aux));
-    // main: scatter R1 (after hist R1), scatter S1 (after hist S1)
-    HIPCHK(c, hipStreamWaitEvent(mainst, ev[1], 0));
-    RET(pass_scatter(c, mainst, 0, p1[0])); HIPCHK(c, hipEventRecord(ev[3], mainst));
-    if (b2) { // aux: hist R2 needs scatter R1
-        HIPCHK(c, hipStreamWaitEvent(aux, ev[3], 0));
-        RET(pass_hist(c, aux, 0, p2[0], c->rel[0].n, (uint64_t *)c->rel[0].off2.p)); HIPCHK(c, hipEventRecord(ev[4], aux));
-    }
-    HIPCHK(c, hipStreamWaitEvent(mainst, ev[2], 0));
-    RET(pass_scatter(c, mainst, 0, p1[1])); HIPCHK(c, hipEventRecord(ev[5], mainst));
-    if (b2) {
-        // NB: hist of pass 2 reuses the relation's hist/scan workspace that scatter pass 1 has just finished reading
-        HIPCHK(c, hipStreamWaitEvent(aux, ev[5], 0));
-        RET(pass_hist(c, aux, 0, p2[1], c->rel[1].n, (uint64_t *)c->rel[1].off2.p)); HIPCHK(c, hipEventRecord(ev[6], aux));
-        HIPCHK(c, hipStreamWaitEvent(mainst, ev[4], 0));
-        RET(pass_scatter(c, mainst, 0, p2[0]));
-        HIPCHK(c, hipStreamWaitEvent(mainst, ev[6], 0));
-        RET(pass_scatter(c, mainst, 0, p2[1]));
-    }
-    for (int r = 0; r < 2; r++) {
-        Rel &R = c->rel[r];
-        R.part_k = (const int32_t *)R.b_k.p;
-        R.part_p = (const int32_t *)R.b_p.p;
-        R.part_off = (const uint64_t *)R.off2.p;
-        R.nparts = b2 ? P1 * P2 : P1;
-        R.pb1 = b1; R.pb2 = b2;
-        R.partitioned = true;
-    }
-    c->join_planned = false;
+// Which layout does a relation whose histogram-free passes were queued have?  Reads the device flag.  [sync]
+int resolve_layout(hj_ctx *c, Rel &R) {
+    if (!R.fast_tried) return 0;
+    uint32_t ovf = 0;
+    HIPCHK(c, hipMemcpyAsync(&ovf, R.flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ovf) { R.part_off = (const uint64_t *)R.off2.p; R.fast_tried = false; } // the exact passes ran: contiguous
     return 0;
 }
 
 // work-item list + per-wave counts; leaves scanned wave counts in place for the materialising kernel
-int run_count(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullptr) {
+int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nullptr) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
@@ -499,17 +478,18 @@ int run_count(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullpt
     const size_t lds = join_lds_bytes(c->nh, c->cap, tag16);
     if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
     HIPCHK(c, join_set_lds_limit(c->device, lds)); // per device, only ever raised (contexts share the functions)
-    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, B.part_off, Pb.part_off, nparts, c->chunk, (uint32_t *)c->items_cnt.p)); }
-    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
-                                                      (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
-    { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, B.part_off, Pb.part_off, nparts, c->chunk, (const uint32_t *)c->items_cnt.p,
-                                                                (const uint64_t *)c->jchunk_prefix.p, (uint2 *)c->items.p)); }
+    JoinArgs &a = a_out;
     a = JoinArgs{};
-    a.bk = B.part_k; a.bp = B.part_p; a.boff = B.part_off; a.b_nalloc = B.n;
-    a.pk = Pb.part_k; a.pp = Pb.part_p; a.poff = Pb.part_off; a.p_nalloc = Pb.n;
+    a.bk = B.part_k; a.bp = B.part_p; a.bbeg = B.part_beg; a.bend = B.part_end; a.b_nalloc = B.n_alloc;
+    a.pk = Pb.part_k; a.pp = Pb.part_p; a.pbeg = Pb.part_beg; a.pend = Pb.part_end; a.p_nalloc = Pb.n_alloc;
     a.items = (const uint2 *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
+    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p)); }
+    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
+                                                      (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
+    { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
+                                                                (const uint64_t *)c->jchunk_prefix.p, (uint2 *)c->items.p)); }
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
     if (late) {
@@ -557,20 +537,13 @@ int hj_create(hj_ctx **out, int device) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_EHIP; }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) c->aux = nullptr;
-    for (auto &e : c->dep)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->aux = nullptr; break; }
-    // The interleaved two-stream schedule (partition_both) measured SLOWER than the serial one on MI355X
-    // (23.4 vs 21.7-22.9 ms per 2^30 x 2^30 step: the co-running k_hist slows k_scatter_wc by more than it
-    // hides), so it is opt-in for experiments only.
-    const char *ov = getenv("HJ_OVERLAP");
-    if (!(ov && ov[0] == '1')) { if (c->aux) (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
     if (hipMalloc(&c->scalars.p, 64) != hipSuccess) { delete c; return HJ_ENOMEM; }
     c->scalars.cap = 64;
     if (hipHostMalloc((void **)&c->h_scalars, 64, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
     memset(c->h_scalars, 0, 64);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *ev = getenv("HJ_NO_KERNEL_EVENTS")) { if (ev[0] == '1') c->events = 0; }
+    if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
     if (sv) c->scatter_variant = atoi(sv);
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
@@ -590,14 +563,14 @@ int hj_destroy(hj_ctx *c) {
         Rel &R = c->rel[r];
         release(R.own_k); release(R.own_p); release(R.a_k); release(R.a_p); release(R.b_k); release(R.b_p);
         release(R.off1); release(R.off2); release(R.root);
+        release(R.beg); release(R.end); release(R.s1beg); release(R.s1end); release(R.flag);
+        release(R.comp_k); release(R.comp_p); release(R.comp_off);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
-    for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
     if (c->copy) (void)hipStreamDestroy(c->copy);
     release(c->shard_root); release(c->shard_off);
     if (c->h_shard_off) (void)hipHostFree(c->h_shard_off);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
     release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -634,6 +607,7 @@ int hj_get_config(const hj_ctx *c, hj_config *cfg) {
     cfg->bits1 = c->bits1; cfg->bits2 = c->bits2; cfg->force_bits = c->cfg.force_bits;
     cfg->build_side = c->build == HJ_REL_R ? 1 : 2;
     cfg->lds_capacity = c->cap; cfg->lds_heads = c->nh; cfg->probe_chunk = c->chunk;
+    cfg->exact_only = c->cfg.exact_only || !c->fast_path;
     return HJ_OK;
 }
 
@@ -726,7 +700,8 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
 int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    RET(partition_both(c));
+    RET(partition_rel(c, HJ_REL_R));
+    RET(partition_rel(c, HJ_REL_S));
     return hj_join_count(c, matches, agg);
 }
 
@@ -1027,10 +1002,46 @@ int hj_get_partitions(hj_ctx *c, int rel, const int32_t **d_keys, const int32_t 
     RET(check_rel(c, rel));
     Rel &R = c->rel[rel];
     if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
+    HIPCHK(c, hipSetDevice(c->device));
+    RET(resolve_layout(c, R));
+    if (R.fast_tried) {
+        // slotted layout (histogram-free passes): hand out a gap-free copy with contiguous offsets
+        const uint32_t np = R.nparts;
+        std::vector<uint64_t> hb(np), he(np), off((size_t)np + 1);
+        HIPCHK(c, hipMemcpyAsync(hb.data(), R.part_beg, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(he.data(), R.part_end, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        off[0] = 0;
+        for (uint32_t i = 0; i < np; i++) off[i + 1] = off[i] + (he[i] - hb[i]);
+        if (off[np] != R.n) return fail(c, HJ_EHIP, "partition sizes add up to %llu, relation has %llu tuples",
+                                        (unsigned long long)off[np], (unsigned long long)R.n);
+        RET(ensure(c, R.comp_k, (size_t)(R.n + PAD) * 4));
+        RET(ensure(c, R.comp_p, (size_t)(R.n + PAD) * 4));
+        RET(ensure(c, R.comp_off, ((size_t)np + 1) * 8));
+        HIPCHK(c, hipMemcpyAsync(R.comp_off.p, off.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_compact(c->stream, R.part_k, R.part_p, R.part_beg, R.part_end, np, (const uint64_t *)R.comp_off.p,
+                                 (int32_t *)R.comp_k.p, (int32_t *)R.comp_p.p));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // `off` is pageable host memory
+        if (d_keys) *d_keys = (const int32_t *)R.comp_k.p;
+        if (d_pays) *d_pays = (const int32_t *)R.comp_p.p;
+        if (d_offsets) *d_offsets = (const uint64_t *)R.comp_off.p;
+        if (nparts) *nparts = np;
+        return HJ_OK;
+    }
     if (d_keys) *d_keys = R.part_k;
     if (d_pays) *d_pays = R.part_p;
     if (d_offsets) *d_offsets = R.part_off;
     if (nparts) *nparts = R.nparts;
+    return HJ_OK;
+}
+
+int hj_partition_layout(hj_ctx *c, int rel, int *slotted) {
+    RET(check_rel(c, rel));
+    Rel &R = c->rel[rel];
+    if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
+    HIPCHK(c, hipSetDevice(c->device));
+    RET(resolve_layout(c, R));
+    if (slotted) *slotted = R.fast_tried ? 1 : 0;
     return HJ_OK;
 }
 
@@ -1134,7 +1145,7 @@ int hj_verify_partitions(hj_ctx *c, int rel, uint64_t *misplaced, uint64_t *d_di
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t *sc = (uint64_t *)c->scalars.p;
     HIPCHK(c, hipMemsetAsync(sc + 4, 0, 8, c->stream));
-    HIPCHK(c, launch_verify_partitions(c->stream, R.part_k, R.part_p, R.part_off, R.nparts, sc + 4, d_digests));
+    HIPCHK(c, launch_verify_partitions(c->stream, R.part_k, R.part_p, R.part_beg, R.part_end, R.nparts, 0, 0, sc + 4, d_digests, nullptr));
     RET(fetch_scalars(c));
     if (misplaced) *misplaced = c->h_scalars[4];
     return HJ_OK;

@@ -22,26 +22,51 @@ constexpr int SCAN_CHUNK = 1 << SCAN_CHUNK_LOG; // = SCAN_THREADS * SCAN_PER
 constexpr int JOIN_THREADS = 512;
 constexpr int JOIN_WAVES = JOIN_THREADS / 64;
 
+constexpr int MAX_SEGS = 8192;                  // segments of one exact pass (parents x segments per parent)
+
+// One exact (histogram + scan + scatter) radix pass.  The input is a list of segments [sbeg[i], send[i]) of the
+// input columns; spp consecutive segments form one parent partition (contiguous partitions: sbeg = offsets,
+// send = offsets + 1, spp = 1).
 struct PassArgs {
     const int32_t *keys, *pays; // input columns
     uint64_t nalloc;            // true length of the input arrays
-    const uint64_t *poff;       // parent offsets [nparents+1]
+    const uint64_t *sbeg, *send; // segment ranges [nseg]
+    uint32_t nseg, spp;         // nparents = nseg / spp
     uint32_t nparents;
-    uint32_t *span_start;       // [nparents+1]
+    uint32_t *span_start;       // [nseg+1]
     uint32_t span;              // tuples per span
     uint32_t max_spans;         // launch bound
     uint32_t shift, P, mask_or_n;
     uint32_t *hist;             // [max_spans * P]
     uint64_t *chunk_sums, *chunk_prefix;
     int32_t *out_keys, *out_pays;
+    uint64_t n_out;             // tuples of the pass (end of the last child partition)
+    uint64_t *beg, *end;        // optional: child partition ranges for the join [nparents * P]
+    const uint32_t *run_if;     // optional device flag: every kernel of the pass returns at once when it is 0
+};
+
+// The histogram-free ("optimistic") passes.  Output slots have a fixed capacity: pass 1 gives every
+// (digit, span) pair a slot of cap tuples, pass 2 every final partition; a slot that would overflow raises
+// *ovf and the exact passes redo the relation.  See hj_kernels.hip.
+struct FastArgs {
+    const int32_t *keys, *pays;  // input columns
+    uint64_t n;                  // pass 1: tuples of the (contiguous) input
+    uint32_t span, nspans;       // pass 1: tuples per workgroup, number of workgroups
+    const uint64_t *sbeg, *send; // pass 2: input segments [nparents * spp]
+    uint32_t nparents, spp;
+    uint32_t shift, P;           // digit = (key >> shift) & (P - 1)
+    uint32_t cap;                // slot capacity in tuples (multiple of the digit's LDS lines)
+    int32_t *out_keys, *out_pays;
+    uint64_t *obeg, *oend;       // slot ranges written by the pass: pass 1 [P * nspans] (digit major), pass 2 [nparents * P]
+    uint32_t *ovf;               // overflow flag (also read: a set flag makes the kernel return at once)
 };
 
 struct JoinArgs {
     const int32_t *bk, *bp;  // build side, partitioned
-    const uint64_t *boff;
+    const uint64_t *bbeg, *bend; // partition p = [bbeg[p], bend[p])
     uint64_t b_nalloc;
     const int32_t *pk, *pp;  // probe side, partitioned
-    const uint64_t *poff;
+    const uint64_t *pbeg, *pend;
     uint64_t p_nalloc;
     const uint2 *items;      // (partition, probe chunk)
     const uint64_t *n_items;
@@ -57,20 +82,25 @@ struct JoinArgs {
 };
 
 hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n);
-hipError_t launch_plan(hipStream_t st, const uint64_t *poff, uint32_t nparents, uint32_t span, uint32_t *span_start);
+hipError_t launch_plan(hipStream_t st, const PassArgs &pa);
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out, const uint32_t *run_if = nullptr);
 hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
 hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa);
+hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
+hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
+uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
+hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
+hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
+                          uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
 size_t scatter_lds_bytes(int threads, int u);
 hipError_t set_wc_ablate(uint32_t v);
-hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
-                            uint32_t *items_cnt);
-hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
-                              const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items);
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt);
+hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
+                              const uint64_t *chunk_prefix, uint2 *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(int device, size_t bytes);
 hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise, 2 late materialisation
@@ -84,8 +114,9 @@ hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_
 hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
 hipError_t launch_gen_zipf(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta, uint64_t seed);
 hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, const int32_t *c, uint64_t n, uint64_t *out);
-hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *off,
-                                    uint32_t nparts, uint64_t *misplaced, uint64_t *digests);
+hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *beg,
+                                    const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
+                                    uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
 uint32_t host_shard_of(int32_t key, uint32_t nshards);
 
 } // namespace hj

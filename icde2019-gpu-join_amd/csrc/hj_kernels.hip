@@ -145,20 +145,32 @@ __device__ __forceinline__ uint32_t rank_in_digit(uint32_t *cnt, uint32_t d, boo
 // partition pass: plan → histogram → scan → offsets → scatter
 // ------------------------------------------------------------------------------------------------
 
-// One thread per parent partition: number of spans (<= span tuples each) it is cut into, and the
-// exclusive prefix of that.  span_start has nparents+1 entries.  Single workgroup, nparents <= 1024.
-__global__ __launch_bounds__(1024) void k_plan(const uint64_t *__restrict__ poff, uint32_t nparents,
-                                               uint32_t span, uint32_t *__restrict__ span_start) {
+// Input of a pass = a list of SEGMENTS (contiguous tuple ranges [sbeg[i], send[i]) of the input columns);
+// `spp` consecutive segments form one PARENT partition.  A single-GPU pass over contiguous partitions has
+// one segment per parent (sbeg = offsets, send = offsets + 1); after the multi-GPU exchange a parent is the
+// run of that pass-1 digit received from each peer (spp = number of GPUs) — the reference feeds its pass 1
+// a segment list the same way (jp.cu:84-99,112-117).
+// One thread per segment: number of spans (<= span tuples each) it is cut into, and the exclusive prefix
+// of that.  span_start has nseg+1 entries.  Single workgroup, any nseg (chunks of 1024 with a carry).
+__global__ __launch_bounds__(1024) void k_plan(const uint64_t *__restrict__ sbeg, const uint64_t *__restrict__ send,
+                                               uint32_t nseg, uint32_t span, uint32_t *__restrict__ span_start,
+                                               const uint32_t *__restrict__ run_if) {
     __shared__ uint32_t scratch[17];
-    uint32_t c = 0;
-    if (threadIdx.x < nparents) {
-        uint64_t cnt = poff[threadIdx.x + 1] - poff[threadIdx.x];
-        c = (uint32_t)((cnt + span - 1) / span);
+    if (run_if && !*run_if) return;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nseg; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t c = 0;
+        if (i < nseg) {
+            uint64_t cnt = send[i] - sbeg[i];
+            c = (uint32_t)((cnt + span - 1) / span);
+        }
+        uint32_t total;
+        uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &total);
+        if (i < nseg) span_start[i] = carry + ex;
+        carry += total;
     }
-    uint32_t total;
-    uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &total);
-    if (threadIdx.x < nparents) span_start[threadIdx.x] = ex;
-    if (threadIdx.x == 0) span_start[nparents] = total;
+    if (threadIdx.x == 0) span_start[nseg] = carry;
 }
 
 struct SpanInfo {
@@ -167,23 +179,24 @@ struct SpanInfo {
 };
 
 // Decode blockIdx.x into a span.  Every thread runs the same search (wave-uniform scalar loads).
-__device__ __forceinline__ bool decode_span(const uint64_t *__restrict__ poff, uint32_t nparents,
-                                            const uint32_t *__restrict__ span_start, uint32_t span,
-                                            SpanInfo &si) {
+__device__ __forceinline__ bool decode_span(const uint64_t *__restrict__ sbeg, const uint64_t *__restrict__ send,
+                                            uint32_t nseg, uint32_t spp, const uint32_t *__restrict__ span_start,
+                                            uint32_t span, SpanInfo &si) {
     const uint32_t b = blockIdx.x;
-    if (b >= span_start[nparents]) return false;
-    uint32_t lo = 0, hi = nparents;
+    if (b >= span_start[nseg]) return false;
+    uint32_t lo = 0, hi = nseg;
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (span_start[mid] <= b) lo = mid; else hi = mid;
     }
-    // parents with zero spans share span_start with their successor: take the last one <= b
-    si.parent = lo;
-    si.first = span_start[lo];
-    si.nsp = span_start[lo + 1] - si.first;
+    // segments with zero spans share span_start with their successor: take the last one <= b
+    const uint32_t seg = lo;
+    si.parent = seg / spp;
+    si.first = span_start[si.parent * spp];
+    si.nsp = span_start[(si.parent + 1) * spp] - si.first;
     si.s = b - si.first;
-    uint64_t p0 = poff[lo], p1 = poff[lo + 1];
-    si.lo = p0 + (uint64_t)si.s * span;
+    uint64_t p0 = sbeg[seg], p1 = send[seg];
+    si.lo = p0 + (uint64_t)(b - span_start[seg]) * span;
     si.hi = si.lo + span < p1 ? si.lo + span : p1;
     return true;
 }
@@ -191,13 +204,15 @@ __device__ __forceinline__ bool decode_span(const uint64_t *__restrict__ poff, u
 // Histogram of one span: hist[(first*P) + d*nsp + s].  4 B/tuple read, nothing else.
 template <int MODE>
 __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict__ keys, uint64_t nalloc,
-                                                       const uint64_t *__restrict__ poff, uint32_t nparents,
+                                                       const uint64_t *__restrict__ sbeg, const uint64_t *__restrict__ send,
+                                                       uint32_t nseg, uint32_t spp,
                                                        const uint32_t *__restrict__ span_start, uint32_t span,
                                                        uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                       uint32_t *__restrict__ hist) {
+                                                       uint32_t *__restrict__ hist, const uint32_t *__restrict__ run_if) {
     __shared__ uint32_t h[MAX_PARTS];
+    if (run_if && !*run_if) return;
     SpanInfo si;
-    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
     for (uint32_t d = threadIdx.x; d < P; d += PART_THREADS) h[d] = 0;
     __syncthreads();
     const uint64_t a0 = si.lo & ~(uint64_t)3;
@@ -222,8 +237,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
 // The value of entry i is then data[i] + chunk_prefix[i >> 12].  L = (*len_ptr) * mul, or mul. ----
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ data, const uint32_t *__restrict__ len_ptr,
-                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums) {
+                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums,
+                                                             const uint32_t *__restrict__ run_if) {
     __shared__ T scratch[17];
+    if (run_if && !*run_if) return;
     const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
     const uint64_t start = (uint64_t)blockIdx.x * SCAN_CHUNK;
     if (start >= L) return;
@@ -248,8 +265,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ dat
 // Single workgroup: exclusive scan of the chunk sums; chunk_prefix[nchunks] and *total_out = total.
 __global__ __launch_bounds__(1024) void k_scan_top(const uint64_t *__restrict__ chunk_sums, const uint32_t *__restrict__ len_ptr,
                                                    uint64_t mul, uint64_t *__restrict__ chunk_prefix,
-                                                   uint64_t *__restrict__ total_out) {
+                                                   uint64_t *__restrict__ total_out, const uint32_t *__restrict__ run_if) {
     __shared__ uint64_t scratch[17];
+    if (run_if && !*run_if) return;
     const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
     const uint64_t nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
     uint64_t carry = 0;
@@ -268,18 +286,26 @@ __global__ __launch_bounds__(1024) void k_scan_top(const uint64_t *__restrict__ 
 }
 
 // Child partition offsets: coff[parent*P + d] = output position of (parent, d, span 0); coff[last] = n.
+// The same values go to beg[]/end[] (partition p = [beg[p], end[p])), the form the join reads.
 __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__restrict__ chunk_prefix,
-                          const uint32_t *__restrict__ span_start, uint32_t nparents, uint32_t P,
-                          uint64_t n, uint64_t *__restrict__ coff) {
+                          const uint32_t *__restrict__ span_start, uint32_t nparents, uint32_t spp, uint32_t P,
+                          uint64_t n, uint64_t *__restrict__ coff, uint64_t *__restrict__ beg, uint64_t *__restrict__ end,
+                          const uint32_t *__restrict__ run_if) {
+    if (run_if && !*run_if) return;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nchild = (uint64_t)nparents * P;
     if (t > nchild) return;
-    if (t == nchild) { coff[t] = n; return; }
-    const uint32_t parent = (uint32_t)(t / P), d = (uint32_t)(t % P);
-    const uint64_t total = (uint64_t)span_start[nparents] * P;
-    const uint32_t first = span_start[parent], nsp = span_start[parent + 1] - first;
-    const uint64_t idx = (uint64_t)first * P + (uint64_t)d * nsp;
-    coff[t] = idx < total ? (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG] : n;
+    uint64_t v = n;
+    if (t < nchild) {
+        const uint32_t parent = (uint32_t)(t / P), d = (uint32_t)(t % P);
+        const uint64_t total = (uint64_t)span_start[nparents * spp] * P;
+        const uint32_t first = span_start[parent * spp], nsp = span_start[(parent + 1) * spp] - first;
+        const uint64_t idx = (uint64_t)first * P + (uint64_t)d * nsp;
+        v = idx < total ? (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG] : n;
+    }
+    coff[t] = v;
+    if (beg && t < nchild) beg[t] = v;
+    if (end && t > 0) end[t - 1] = v;
 }
 
 // Scatter one span.  Per tile (THREADS*4*U tuples): LDS histogram with ranks (one returning LDS
@@ -292,12 +318,15 @@ __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__r
 // Algorithmic traffic: 8 B read + 8 B written per tuple.
 template <int MODE, int THREADS, int U>
 __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                     uint64_t nalloc, const uint64_t *__restrict__ poff,
-                                                     uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                     uint64_t nalloc, const uint64_t *__restrict__ sbeg,
+                                                     const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
+                                                     const uint32_t *__restrict__ span_start,
                                                      uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
                                                      const uint32_t *__restrict__ hist,
                                                      const uint64_t *__restrict__ chunk_prefix,
-                                                     int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+                                                     int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
+                                                     uint64_t n_out, const uint32_t *__restrict__ run_if) {
+    if (run_if && !*run_if) return;
     constexpr uint32_t TILE_T = THREADS * 4 * U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t *bufK = reinterpret_cast<int32_t *>(smem);
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
     uint32_t *gbase = delta + MAX_PARTS;                        // next output position of each digit (n < 2^32)
     uint32_t *scratch = gbase + MAX_PARTS;                      // 32 words
     SpanInfo si;
-    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
     const uint32_t tid = threadIdx.x, wv = tid >> 6;
     for (uint32_t d = tid; d < P; d += THREADS) {
         uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
@@ -705,13 +734,16 @@ __device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, con
 
 template <int MODE, int U>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                           uint64_t nalloc, const uint64_t *__restrict__ poff,
-                                                           uint32_t nparents, const uint32_t *__restrict__ span_start,
+                                                           uint64_t nalloc, const uint64_t *__restrict__ sbeg,
+                                                           const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
+                                                           const uint32_t *__restrict__ span_start,
                                                            uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
                                                            const uint32_t *__restrict__ hist,
                                                            const uint64_t *__restrict__ chunk_prefix,
-                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays) {
+                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
+                                                           uint64_t n_out, const uint32_t *__restrict__ run_if) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (run_if && !*run_if) return;
     WcLds L_;
     L_.bufK = reinterpret_cast<int32_t *>(smem);
     L_.bufP = L_.bufK + WC_LINES * WC_LINE;
@@ -722,18 +754,18 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     L_.capb = L_.lo + MAX_PARTS;      // (number of lines << 16) | first line of the digit   (SKEW path)
     L_.wlist = L_.capb + MAX_PARTS;
     SpanInfo si;
-    if (!decode_span(poff, nparents, span_start, span, si)) return;
+    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t ROUND = WC_THREADS * 4 * U;
     // ---- span start: output cursors, and spare lines for the digits this span's histogram marks heavy ----
     uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
     const uint32_t K = (uint32_t)MAX_PARTS / P; // lines per digit: 2x the expected arrivals of a round
-    const uint64_t L = (uint64_t)span_start[nparents] * P;
+    const uint64_t L = (uint64_t)span_start[nseg] * P;
     uint32_t extra = 0, cnt = 0;
     if (tid < P) {
         const uint64_t idx = (uint64_t)si.first * P + (uint64_t)tid * si.nsp + si.s;
         const uint64_t g0 = (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG];
-        const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : poff[nparents];
+        const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : n_out;
         cnt = (uint32_t)(g1 - g0);
         L_.line[tid] = (uint32_t)g0 & ~(uint32_t)(WC_LINE - 1);
         L_.cur[tid] = L_.lo[tid] = (uint32_t)g0 & (WC_LINE - 1);
@@ -763,26 +795,423 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// histogram-free ("optimistic") passes
+// ------------------------------------------------------------------------------------------------
+// The exact pass above pays a keys-only histogram kernel (4 B/tuple of extra HBM reads, 15 % of a 2^30 x 2^30
+// step) for exact, gap-free output offsets.  The reference has no such pass: its partition kernels bump-allocate
+// fixed-size buckets as they go (jp.cu:138-192).  The same idea, kept contention-free: every output SLOT has a
+// fixed capacity, sized from the expected count plus 8 standard deviations, and belongs to exactly one
+// workgroup, so there is no histogram, no scan and no global atomic:
+//   pass 1: workgroup s owns one contiguous span of the input; its tuples of digit d go to slot (d, s)
+//           = out[(d*nspans + s)*cap ...], filled front to back in whole 128-byte lines (slots are line-aligned);
+//   pass 2: workgroup d owns pass-1 digit d = the nspans slots (d, *) and splits them again; child c goes to slot
+//           (d, c) = out[(d*P + c)*cap ...] — the final partition.
+// Each pass writes the ranges [beg, end) of its slots; the join reads partitions as ranges.  A slot that would
+// overflow (skewed keys) raises *ovf, nothing is written past a slot, and the host side has the exact passes
+// queued behind, which run only when the flag is set (run_if).  Uniform and near-uniform inputs never overflow.
+// The per-round machinery (rank by one LDS atomic, per-digit write-combining lines, full lines leave as aligned
+// 128-byte stores) is that of k_scatter_wc; all lines are aligned here, so there is no first-line masking.
+constexpr int WF_TRASH_LINES = WC_THREADS / WC_LINE;   // one trash slot per thread (branch-free placement)
+constexpr int WF_LINES = MAX_PARTS + WF_TRASH_LINES;
+constexpr int WF_MAXSEG = 1024;                        // segments of one parent (= pass-1 workgroups)
+
+struct WfLds {
+    int32_t *bufK, *bufP;        // [WF_LINES][32] each
+    uint32_t *hh, *cur, *line;   // arrival counters by round parity; occupied slots; output position of slot 0
+    uint32_t *wlist;             // [16 waves][32] flush work lists
+    uint32_t *pc4, *sb;          // pass 2: prefix of 4-tuple units per segment [nseg+1]; segment start | padding
+};
+
+struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slotA + d*slotB, at slot*cap
+
+template <int U, int KFIX, int SRC>
+__device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                        uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
+                                        uint32_t P, uint32_t K_rt, const FastGeom g, int32_t *__restrict__ out_keys,
+                                        int32_t *__restrict__ out_pays, uint64_t *__restrict__ obeg,
+                                        uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf) {
+    int32_t *bufK = L_.bufK, *bufP = L_.bufP;
+    uint32_t *hh = L_.hh, *cur = L_.cur, *line = L_.line;
+    const uint32_t K = KFIX ? (uint32_t)KFIX : K_rt;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+    const uint32_t mask = P - 1;
+    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
+    constexpr bool BF = (KFIX == 1);
+    // ---- input feeder ----
+    // SRC 0: the contiguous tuples [lo64, hi64): thread t of round r loads the 16 bytes at a0 + r*ROUND + (u*1024+t)*4.
+    // SRC 1: the parent's segments as one stream of 4-tuple units (segments are 16-byte aligned and padded to whole
+    //        units); the stream is cut into 16 contiguous ranges, one per wave, so that a wave's loads are consecutive
+    //        1-KiB pieces and a lane's segment cursor moves rarely.
+    const uint64_t a0 = lo64 & ~(uint64_t)3;
+    const uint32_t rlo = (uint32_t)(lo64 - a0), rhi = (uint32_t)(hi64 - a0);
+    const int32_t *kin = keys + a0, *pin = pays + a0;
+    const uint64_t navail = nalloc - a0;
+    uint32_t nrounds, wbeg = 0, wend = 0, ci = 0, clo = 0, chi = 0, csb = 0;
+    if (SRC == 0) {
+        nrounds = (rhi + ROUND - 1) / ROUND;
+    } else {
+        const uint32_t T4 = L_.pc4[nseg];
+        const uint32_t R = ((T4 + (WC_THREADS / 64) * 64 - 1) / ((WC_THREADS / 64) * 64)) * 64; // units per wave, multiple of 64
+        nrounds = (R + 64 * U - 1) / (64 * U);
+        wbeg = wv * R;
+        wend = wbeg + R < T4 ? wbeg + R : T4;
+        const uint32_t unit0 = wbeg + ln;
+        if (unit0 < wend) { // segment of the lane's first unit: the last i with pc4[i] <= unit0
+            uint32_t a = 0, b = nseg;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (L_.pc4[m] <= unit0) a = m; else b = m; }
+            ci = a; clo = L_.pc4[a]; chi = L_.pc4[a + 1]; csb = L_.sb[a];
+        }
+    }
+    auto fetch = [&](uint32_t round, int u, int4 &kv, int4 &pv, uint32_t &vm) {
+        kv = make_int4(0, 0, 0, 0); pv = make_int4(0, 0, 0, 0); vm = 0;
+        if (SRC == 0) {
+            const uint32_t r = round * ROUND + (u * WC_THREADS + tid) * 4;
+            if (round < nrounds && r < rhi) {
+                kv = load4(kin, r, navail);
+                pv = load4(pin, r, navail);
+#pragma unroll
+                for (int e = 0; e < 4; e++) vm |= (r + e >= rlo && r + e < rhi) ? (1u << e) : 0u;
+            }
+        } else {
+            const uint32_t unit = wbeg + (round * U + u) * 64 + ln;
+            if (round < nrounds && unit < wend) {
+                while (unit >= chi) { ci++; clo = chi; chi = L_.pc4[ci + 1]; csb = L_.sb[ci]; }
+                const uint32_t addr = (csb & ~3u) + (unit - clo) * 4;
+                kv = *reinterpret_cast<const int4 *>(keys + addr);
+                pv = *reinterpret_cast<const int4 *>(pays + addr);
+                vm = (unit + 1 == chi) ? (0xFu >> (csb & 3u)) : 0xFu; // the segment's last unit may be padded
+            }
+        }
+    };
+    int4 kv[U], pv[U];
+    uint32_t vm[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) fetch(0, u, kv[u], pv[u], vm[u]);
+    int4 kk[U], pp[U];     // the previous round's tuples: the kept ones are stored one phase later
+    uint32_t keep[U * 4];  // LDS word index of a kept tuple, 0xFFFFFFFF = none
+#pragma unroll
+    for (int j = 0; j < U * 4; j++) keep[j] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
+    // the digit this thread owns (tid < P): slot geometry
+    const uint32_t my_base = (g.slotA + tid * g.slotB) * g.cap, my_lim = my_base + g.cap;
+    const uint32_t trash = MAX_PARTS * WC_LINE + tid;
+    uint32_t par = 0;
+    for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
+        uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
+        // ---- A: finish the previous round (kept tuples open the next line, digit owners advance their state) and
+        //         rank this round's tuples.  512-way: branch-free (trash slots / trash counters), see k_scatter_wc ----
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (BF) {
+                    const uint32_t k = keep[u * 4 + e];
+                    const uint32_t idx = k != 0xFFFFFFFFu ? k : trash;
+                    bufK[idx] = elem(kk[u], e);
+                    bufP[idx] = elem(pp[u], e);
+                } else if (keep[u * 4 + e] != 0xFFFFFFFFu) {
+                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
+                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
+                }
+            }
+        if (tid < P) {
+            const uint32_t total = cur[tid] + hprev[tid];
+            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
+            if (full) {
+                uint32_t nl = line[tid] + full;
+                if (nl + K * WC_LINE > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
+                line[tid] = nl;
+            }
+            cur[tid] = total - full;
+            hprev[tid] = 0;
+        }
+        uint32_t code[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool valid = (vm[u] >> e) & 1u;
+                const uint32_t d = ((uint32_t)elem(kv[u], e) >> shift) & mask;
+                uint32_t rk = 0;
+                if (BF) rk = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u);
+                else if (valid) rk = atomicAdd(&h[d], 1u);
+                code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
+            }
+        __syncthreads();
+        // ---- B: place ----
+        if (BF) {
+            uint32_t cdv[U * 4], hdv[U * 4];
+#pragma unroll
+            for (int j = 0; j < U * 4; j++) {
+                const uint32_t dj = code[j] != 0xFFFFFFFFu ? code[j] >> 16 : 0u;
+                cdv[j] = cur[dj];
+                hdv[j] = h[dj];
+            }
+            bool any_bypass = false;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = u * 4 + e;
+                    const uint32_t c = code[j];
+                    const bool valid = c != 0xFFFFFFFFu;
+                    const uint32_t d = valid ? c >> 16 : 0u;
+                    const uint32_t q = cdv[j] + (c & 0xFFFFu);
+                    const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
+                    const bool now = valid && q < (uint32_t)WC_LINE;
+                    const bool kept = valid && !now && q >= full;
+                    any_bypass |= valid && !now && q < full;
+                    const uint32_t idx = now ? d * WC_LINE + q : trash;
+                    bufK[idx] = elem(kv[u], e);
+                    bufP[idx] = elem(pv[u], e);
+                    keep[j] = kept ? d * WC_LINE + (q - full) : 0xFFFFFFFFu;
+                }
+            if (any_bypass) { // rare: a digit received more than a line in one round
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int j = u * 4 + e;
+                        const uint32_t c = code[j];
+                        if (c != 0xFFFFFFFFu) {
+                            const uint32_t q = cdv[j] + (c & 0xFFFFu);
+                            const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
+                            if (q >= (uint32_t)WC_LINE && q < full) {
+                                const uint32_t d = c >> 16, o = line[d] + q;
+                                if (o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
+                                else *ovf = 1u;
+                            }
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t c = code[u * 4 + e];
+                    keep[u * 4 + e] = 0xFFFFFFFFu;
+                    if (c != 0xFFFFFFFFu) {
+                        const uint32_t d = c >> 16;
+                        const uint32_t cd = cur[d];
+                        const uint32_t q = cd + (c & 0xFFFFu);
+                        const uint32_t full = (cd + h[d]) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
+                        const uint32_t cap = K * WC_LINE, base = d * cap;              // K lines per digit
+                        if (q >= full) {             // remainder: stays in LDS after this round's flush
+                            if (full == 0) {         // nothing is flushed: append in place
+                                bufK[base + q] = elem(kv[u], e);
+                                bufP[base + q] = elem(pv[u], e);
+                            } else {
+                                keep[u * 4 + e] = base + (q - full);
+                            }
+                        } else if (q < cap) {        // a line that fills up this round
+                            bufK[base + q] = elem(kv[u], e);
+                            bufP[base + q] = elem(pv[u], e);
+                        } else {                     // beyond the digit's lines: straight to HBM
+                            const uint32_t o = line[d] + q;
+                            if (o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
+                            else *ovf = 1u;
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            kk[u] = kv[u]; pp[u] = pv[u];
+            fetch(round + 1, u, kv[u], pv[u], vm[u]); // next round's loads fly while the lines are flushed
+        }
+        __syncthreads();
+        // ---- C: flush every line that filled up: aligned 128-byte stores ----
+        if (BF) {
+            uint32_t *wlist = L_.wlist + wv * 32;
+            for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
+                const uint32_t dl = dbase + (ln & 31u);
+                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
+                const uint64_t m = __ballot(fullq);
+                const uint32_t nfull = (uint32_t)__popcll(m);
+                if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = dl;
+                __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
+                const uint32_t c4 = (ln & 7u) * 4;
+                for (uint32_t t = 0; t < nfull; t += 8) {
+                    const uint32_t idx = t + (ln >> 3);
+                    if (idx < nfull) {
+                        const uint32_t d = wlist[idx];
+                        const uint32_t gpos = line[d] + c4;
+                        const int4 kq = *reinterpret_cast<const int4 *>(bufK + d * WC_LINE + c4);
+                        const int4 pq = *reinterpret_cast<const int4 *>(bufP + d * WC_LINE + c4);
+                        *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
+                        *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            const uint32_t groups = (P + 31) / 32;
+            const uint32_t nrep = groups >= (uint32_t)(WC_THREADS / 64) ? 1u : (uint32_t)(WC_THREADS / 64) / groups;
+            const uint32_t rep = wv / groups;
+            for (uint32_t dbase = (wv % groups) * 32; dbase < P && rep < nrep; dbase += (WC_THREADS / 64) * 32) {
+                const uint32_t dl = dbase + (ln & 31u);
+                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
+                uint64_t m = __ballot(fullq);
+                const uint32_t s = ln & (WC_LINE - 1);
+                while (m) {
+                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t cap = K * WC_LINE, base = d * cap;
+                    uint32_t full = (cur[d] + h[d]) & ~(uint32_t)(WC_LINE - 1);
+                    if (full > cap) full = cap;
+                    const uint32_t gl = line[d];
+                    for (uint32_t j = rep * WC_LINE; j < full; j += nrep * WC_LINE) {
+                        if (ln < (uint32_t)WC_LINE) out_keys[gl + j + s] = bufK[base + j + s];
+                        else out_pays[gl + j + s] = bufP[base + j + s];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: phase A of the last round, the partially filled last line of every digit, the slot ranges ----
+    {
+        uint32_t *hprev = hh + (par ^ 1) * WC_HSTRIDE;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
+                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
+                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
+                }
+        if (tid < P) {
+            const uint32_t total = cur[tid] + hprev[tid];
+            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
+            if (full) {
+                uint32_t nl = line[tid] + full;
+                if (nl + K * WC_LINE > my_lim) { *ovf = 1u; nl = my_base; }
+                line[tid] = nl;
+            }
+            cur[tid] = total - full;
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
+        const uint32_t s = ln & (WC_LINE - 1);
+        const uint32_t base = d * K * WC_LINE;
+        if (s < cur[d]) {
+            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[base + s];
+            else out_pays[line[d] + s] = bufP[base + s];
+        }
+    }
+    if (tid < P) {
+        const uint32_t slot = g.slotA + tid * g.slotB;
+        obeg[slot] = my_base;
+        oend[slot] = (uint64_t)line[tid] + cur[tid];
+    }
+}
+
+__device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
+    L_.bufK = reinterpret_cast<int32_t *>(smem);
+    L_.bufP = L_.bufK + WF_LINES * WC_LINE;
+    L_.hh = reinterpret_cast<uint32_t *>(L_.bufP + WF_LINES * WC_LINE);
+    L_.cur = L_.hh + 2 * WC_HSTRIDE;
+    L_.line = L_.cur + MAX_PARTS;
+    L_.wlist = L_.line + MAX_PARTS;
+    L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32;
+    L_.sb = L_.pc4 + WF_MAXSEG + 4;
+}
+size_t fast_lds_bytes() {
+    return (size_t)WF_LINES * WC_LINE * 4 * 2 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 * 2 +
+           (WC_THREADS / 64) * 32 * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4;
+}
+
+// pass 1: one workgroup per span of the contiguous input
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WfLds L_;
+    wf_carve(L_, smem);
+    const uint32_t tid = threadIdx.x, s = blockIdx.x;
+    const uint64_t lo = (uint64_t)s * a.span;
+    const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
+    const uint32_t K = (uint32_t)MAX_PARTS / a.P;
+    FastGeom g{s, a.nspans, a.cap};
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
+    if (tid < a.P) { L_.cur[tid] = 0; L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap; }
+    __syncthreads();
+    if (K == 1) wc_fast<U, 1, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (*a.ovf) return; // pass 1 gave up: the exact passes take over
+    WfLds L_;
+    wf_carve(L_, smem);
+    const uint32_t tid = threadIdx.x, parent = blockIdx.x;
+    const uint32_t K = (uint32_t)MAX_PARTS / a.P;
+    FastGeom g{parent * a.P, 1u, a.cap};
+    uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
+    // segment table of this parent: 4-tuple units per segment, scanned
+    uint32_t units = 0;
+    if (tid < a.spp) {
+        const uint64_t b = a.sbeg[(uint64_t)parent * a.spp + tid], e = a.send[(uint64_t)parent * a.spp + tid];
+        const uint32_t cnt = (uint32_t)(e - b);
+        units = (cnt + 3) >> 2;
+        L_.sb[tid] = (uint32_t)b | (units * 4 - cnt); // segment start (multiple of 4) | padding of its last unit
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
+    if (tid < a.spp) L_.pc4[tid] = ex;
+    if (tid == 0) L_.pc4[a.spp] = total;
+    __syncthreads();
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
+    if (tid < a.P) { L_.cur[tid] = 0; L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap; }
+    __syncthreads();
+    if (K == 1) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// partition ranges from an offsets array (single-pass / unpartitioned layouts): beg[i] = off[i], end[i] = off[i+1]
+__global__ void k_range_from_offsets(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ beg, uint64_t *__restrict__ end) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { beg[i] = off[i]; end[i] = off[i + 1]; }
+}
+
+// gap-free copy of a partitioned relation given as ranges: partition p moves to [off[p], off[p+1]) (introspection)
+__global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, const int32_t *__restrict__ p,
+                                                 const uint64_t *__restrict__ beg, const uint64_t *__restrict__ end, uint32_t nparts,
+                                                 const uint64_t *__restrict__ off, int32_t *__restrict__ ok, int32_t *__restrict__ op) {
+    for (uint32_t q = blockIdx.x; q < nparts; q += gridDim.x) {
+        const uint64_t b = beg[q], n = end[q] - b, o = off[q];
+        for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) { ok[o + i] = k[b + i]; op[o + i] = p[b + i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // join: plan → (count) → scan → (materialise)
 // ------------------------------------------------------------------------------------------------
 
 // items per partition: probe partition cut into chunks of <= chunk tuples (decompose_chains,
 // jp.cu:843-874, threshold = 2*bucket_size at hjcp.cu:904); no item when either side is empty.
-__global__ void k_join_plan(const uint64_t *__restrict__ boff, const uint64_t *__restrict__ poff,
+__global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
+                            const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                             uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nparts) return;
-    uint64_t nb = boff[p + 1] - boff[p], np = poff[p + 1] - poff[p];
+    uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
     items_cnt[p] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
 }
 
 // items_cnt has been scanned (local + chunk prefix): write the item list and the item count.
-__global__ void k_join_expand(const uint64_t *__restrict__ boff, const uint64_t *__restrict__ poff,
+__global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
+                              const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                               uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
                               const uint64_t *__restrict__ chunk_prefix, uint2 *__restrict__ items) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nparts) return;
-    uint64_t nb = boff[p + 1] - boff[p], np = poff[p + 1] - poff[p];
+    uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
     uint64_t at = (uint64_t)items_scanned[p] + chunk_prefix[p >> SCAN_CHUNK_LOG];
     for (uint32_t j = 0; j < c; j++) items[at + j] = make_uint2(p, j);
@@ -806,9 +1235,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const uint2 it = a.items[item];
     const uint32_t p = it.x;
-    const uint64_t b0 = a.boff[p], nb = a.boff[p + 1] - b0;
-    const uint64_t q0 = a.poff[p] + (uint64_t)it.y * a.chunk;
-    const uint64_t pend = a.poff[p + 1];
+    const uint64_t b0 = a.bbeg[p], nb = a.bend[p] - b0;
+    const uint64_t q0 = a.pbeg[p] + (uint64_t)it.y * a.chunk;
+    const uint64_t pend = a.pend[p];
     const uint64_t q1 = q0 + a.chunk < pend ? q0 + a.chunk : pend;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
 
@@ -1046,22 +1475,23 @@ __global__ __launch_bounds__(256) void k_digest(const int32_t *__restrict__ a, c
     if (lane_id() == 0) atomicAdd(out, (unsigned long long)s);
 }
 
-// one workgroup per partition: tuples whose low radix bits differ from the partition id, and the
-// partition's (key,pay) digest
+// one workgroup per partition: tuples whose radix bits differ from the partition id, the partition's (key,pay)
+// digest and its size
 __global__ __launch_bounds__(256) void k_verify_partitions(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                           const uint64_t *__restrict__ off, uint32_t nparts,
-                                                           unsigned long long *__restrict__ misplaced,
-                                                           uint64_t *__restrict__ digests) {
+                                                           const uint64_t *__restrict__ beg, const uint64_t *__restrict__ end,
+                                                           uint32_t nparts, unsigned long long *__restrict__ misplaced,
+                                                           uint64_t *__restrict__ digests, uint64_t *__restrict__ sizes) {
     __shared__ uint64_t red[4];
     for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
         uint64_t bad = 0, dg = 0;
-        for (uint64_t i = off[p] + threadIdx.x; i < off[p + 1]; i += blockDim.x) {
+        for (uint64_t i = beg[p] + threadIdx.x; i < end[p]; i += blockDim.x) {
             if ((((uint32_t)keys[i]) & (nparts - 1)) != p) bad++;
             dg += mix_pair(keys[i], pays[i]);
         }
         bad = wave_sum64(bad);
         dg = wave_sum64(dg);
         if (lane_id() == 0 && bad) atomicAdd(misplaced, (unsigned long long)bad);
+        if (sizes && threadIdx.x == 0) sizes[p] = end[p] - beg[p];
         if (digests) {
             if (lane_id() == 0) red[threadIdx.x >> 6] = dg;
             __syncthreads();
@@ -1086,8 +1516,8 @@ hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n) {
     return hipSuccess;
 }
 
-hipError_t launch_plan(hipStream_t st, const uint64_t *poff, uint32_t nparents, uint32_t span, uint32_t *span_start) {
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, poff, nparents, span, span_start);
+hipError_t launch_plan(hipStream_t st, const PassArgs &pa) {
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, pa.sbeg, pa.send, pa.nseg, pa.span, pa.span_start, pa.run_if);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1095,20 +1525,20 @@ hipError_t launch_plan(hipStream_t st, const uint64_t *poff, uint32_t nparents, 
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa) {
     dim3 g(pa.max_spans), b(PART_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.run_if);
     else
-        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.poff, pa.nparents, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.run_if);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out, const uint32_t *run_if) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, run_if);
     HJ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out, run_if);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1117,9 +1547,9 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, (const uint32_t *)nullptr);
     HJ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out, (const uint32_t *)nullptr);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1127,7 +1557,7 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff) {
     uint64_t nthreads = (uint64_t)pa.nparents * pa.P + 1;
     hipLaunchKernelGGL(k_offsets, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, st, pa.hist, pa.chunk_prefix,
-                       pa.span_start, pa.nparents, pa.P, n, coff);
+                       pa.span_start, pa.nparents, pa.spp, pa.P, n, coff, pa.beg, pa.end, pa.run_if);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1149,8 +1579,9 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
-                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
+                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
+                       pa.n_out, pa.run_if);
     return hipGetLastError();
 }
 
@@ -1171,8 +1602,9 @@ static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.poff, pa.nparents,
-                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays);
+    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
+                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
+                       pa.n_out, pa.run_if);
     return hipGetLastError();
 }
 
@@ -1197,17 +1629,16 @@ hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs 
     }
 }
 
-hipError_t launch_join_plan(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
-                            uint32_t *items_cnt) {
-    hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, boff, poff, nparts, chunk, items_cnt);
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt) {
+    hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-hipError_t launch_join_expand(hipStream_t st, const uint64_t *boff, const uint64_t *poff, uint32_t nparts, uint32_t chunk,
-                              const uint32_t *items_scanned, const uint64_t *chunk_prefix, uint2 *items) {
-    hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, boff, poff, nparts, chunk, items_scanned,
-                       chunk_prefix, items);
+hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
+                              const uint64_t *chunk_prefix, uint2 *items) {
+    hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
+                       items_scanned, chunk_prefix, items);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1380,10 +1811,66 @@ hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, con
     return hipSuccess;
 }
 
-hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *off,
-                                    uint32_t nparts, uint64_t *misplaced, uint64_t *digests) {
-    hipLaunchKernelGGL(k_verify_partitions, dim3(nparts < 4096 ? nparts : 4096), dim3(256), 0, st, keys, pays, off, nparts,
-                       reinterpret_cast<unsigned long long *>(misplaced), digests);
+hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *beg,
+                                    const uint64_t *end, uint32_t nparts, uint32_t, uint32_t, uint64_t *misplaced,
+                                    uint64_t *digests, uint64_t *sizes) {
+    hipLaunchKernelGGL(k_verify_partitions, dim3(nparts < 4096 ? nparts : 4096), dim3(256), 0, st, keys, pays, beg, end, nparts,
+                       reinterpret_cast<unsigned long long *>(misplaced), digests, sizes);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// slot capacity of the histogram-free passes: expected count + 8 standard deviations (Poisson), rounded to the
+// digit's LDS lines (K = 512/P lines of 32 tuples), plus one such granule (a slot counts as full one granule early)
+uint32_t fast_slot_cap(uint64_t expected, uint32_t P) {
+    const uint64_t gran = (uint64_t)(MAX_PARTS / P) * WC_LINE;
+    uint64_t sd = 1;
+    while (sd * sd < expected) sd++;
+    uint64_t c = expected + 8 * sd + 32;
+    c = ((c + gran - 1) / gran) * gran + gran;
+    return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+}
+
+template <typename F>
+static hipError_t fast_attr(F fn, bool *flags) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (dev < 0 || dev >= 64 || !flags[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds_bytes());
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) flags[dev] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
+    static bool set[64] = {};
+    auto fn = k_part1_fast<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    return hipGetLastError();
+}
+
+hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa) {
+    static bool set[64] = {};
+    auto fn = k_part2_fast<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(fa.nparents), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end) {
+    hipLaunchKernelGGL(k_range_from_offsets, dim3((n + 255) / 256), dim3(256), 0, st, off, n, beg, end);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
+                          uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op) {
+    hipLaunchKernelGGL(k_compact, dim3(nparts < 8192 ? nparts : 8192), dim3(256), 0, st, k, p, beg, end, nparts, off, ok, op);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -83,9 +83,10 @@ class HashJoin:
         self._ck(self._L.hj_set_stream(self._h, own if stream is None else C.c_void_p(int(stream))))
 
     def configure(self, bits1=0, bits2=0, force_bits=False, build_side=0, lds_capacity=0, lds_heads=0,
-                  probe_chunk=0):
+                  probe_chunk=0, exact_only=False):
         cfg = _lib.Config(bits1=bits1, bits2=bits2, force_bits=int(force_bits), build_side=build_side,
-                          lds_capacity=lds_capacity, lds_heads=lds_heads, probe_chunk=probe_chunk)
+                          lds_capacity=lds_capacity, lds_heads=lds_heads, probe_chunk=probe_chunk,
+                          exact_only=int(exact_only))
         self._ck(self._L.hj_configure(self._h, C.byref(cfg)))
 
     def config(self):
@@ -114,6 +115,12 @@ class HashJoin:
     # -- the path ---------------------------------------------------------------------------------
     def partition(self, rel):
         self._ck(self._L.hj_partition(self._h, rel))
+
+    def partition_layout(self, rel):
+        """'slotted' if the histogram-free passes produced the partitions, 'exact' if the histogram passes did."""
+        v = C.c_int()
+        self._ck(self._L.hj_partition_layout(self._h, rel, C.byref(v)))
+        return "slotted" if v.value else "exact"
 
     def join_count(self):
         m, a = C.c_uint64(), C.c_uint64()

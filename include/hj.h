@@ -51,7 +51,11 @@ typedef struct hj_config {
     uint32_t lds_capacity; /* build tuples per LDS hash table; 0 = default */
     uint32_t lds_heads;    /* hash-table heads (power of two); 0 = default */
     uint32_t probe_chunk;  /* probe tuples per work item (decompose_chains threshold, hjcp.cu:904); 0 = default */
-    uint32_t reserved[9];
+    uint32_t exact_only;   /* 1: always run the histogram + scan + scatter passes (gap-free partitions).  0: two-pass
+                            * partitioning first tries the histogram-free passes (fixed-capacity slots per partition, the
+                            * bump-allocated buckets of jp.cu:138-192 without their atomics) and falls back to the exact
+                            * passes on the device when skew overflows a slot. */
+    uint32_t reserved[8];
 } hj_config;
 
 /* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream).
@@ -145,9 +149,13 @@ int hj_memcpy_d2h(hj_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes); 
 int hj_memcpy_h2d(hj_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes); /* [sync] */
 
 /* ---- introspection for parity tests ---- */
-/* Device pointers of the partitioned columns and of the nparts+1 partition offsets (uint64). */
+/* Device pointers of the partitioned columns and of the nparts+1 partition offsets (uint64): partition p =
+ * [offsets[p], offsets[p+1]).  When the histogram-free passes produced the partitions (fixed-capacity slots), this
+ * returns a gap-free copy owned by the context.  [sync] */
 int hj_get_partitions(hj_ctx *ctx, int rel, const int32_t **d_keys, const int32_t **d_pays,
                       const uint64_t **d_offsets, uint64_t *nparts);
+/* *slotted = 1 if the relation's partitions came from the histogram-free passes, 0 if from the exact passes. [sync] */
+int hj_partition_layout(hj_ctx *ctx, int rel, int *slotted);
 int hj_timings_reset(hj_ctx *ctx);
 /* [sync] fills up to cap entries, returns the number of kernels known in *n. */
 int hj_timings(hj_ctx *ctx, hj_kernel_time *out, uint32_t cap, uint32_t *n);

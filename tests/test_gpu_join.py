@@ -22,6 +22,15 @@ def _load(golden_dir, name):
 
 
 def _check_join(P, R, Pr, S, Ps, cfg=None, materialize=True):
+    """Every configuration is checked twice: with the histogram-free passes enabled (the default; they fall back to
+    the exact passes on the device when a slot overflows) and with the exact passes only."""
+    out = None
+    for exact_only in (False, True):
+        out = _check_join_1(P, R, Pr, S, Ps, dict(cfg or {}, exact_only=exact_only), materialize)
+    return out
+
+
+def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
     em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=materialize)
     with P.HashJoin(0) as hj:
         if cfg:
@@ -43,6 +52,11 @@ def _check_join(P, R, Pr, S, Ps, cfg=None, materialize=True):
 
 
 def _check_partitions(P, keys, pays, cfg):
+    for exact_only in (False, True):
+        _check_partitions_1(P, keys, pays, dict(cfg, exact_only=exact_only))
+
+
+def _check_partitions_1(P, keys, pays, cfg):
     with P.HashJoin(0) as hj:
         hj.configure(**cfg)
         hj.load_host(P.REL_R, keys, pays)
@@ -179,6 +193,43 @@ def test_tag16_vs_full_key_paths(P):
     S[:2] = [0x40010000, 0x10010000]
     for cfg in (dict(bits1=8, bits2=8), dict(bits1=9, bits2=9), dict(bits1=8, bits2=7), dict(bits1=2)):
         _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
+
+
+# ---- histogram-free passes: taken on uniform keys, abandoned (on the device) under skew -------------------------
+def test_fast_path_layout_and_fallback(P):
+    rng = np.random.default_rng(55)
+    n = 1 << 18
+    uni = rng.permutation(n).astype(np.int32)
+    skew = np.where(rng.random(n) < 0.5, 12345, rng.integers(0, n, n)).astype(np.int32)      # one key holds half
+    stride = (rng.permutation(n).astype(np.int64) * 512 % (1 << 31)).astype(np.int32)        # pass-2 digit always 0
+    pay = np.arange(n, dtype=np.int32)
+    for keys, expect in ((uni, "slotted"), (skew, "exact"), (stride, "exact")):
+        for cfg in (dict(bits1=9, bits2=9), dict(bits1=9, bits2=7), dict(bits1=5, bits2=4), dict(bits1=7, bits2=2)):
+            with P.HashJoin(0) as hj:
+                hj.configure(**cfg)
+                hj.load_host(P.REL_R, keys, pay)
+                hj.load_host(P.REL_S, uni, pay)
+                hj.partition(P.REL_R)
+                hj.partition(P.REL_S)
+                assert hj.partition_layout(P.REL_S) == "slotted"
+                lay = hj.partition_layout(P.REL_R)
+                if keys is uni or cfg["bits2"] >= 7:
+                    assert lay == expect, (lay, expect, cfg)
+                gk, gp, goff = hj.partitions(P.REL_R, n)
+                ok, op, ooff = o.radix_partition(keys, pay, 0, cfg["bits1"] + cfg["bits2"])
+                assert np.array_equal(goff, ooff)
+                assert np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+                assert hj.join_count() == o.join_count(keys, pay, uni, pay, checksum=False)[:2]
+                hj.configure(exact_only=True, **cfg)
+                hj.partition(P.REL_R)
+                assert hj.partition_layout(P.REL_R) == "exact"
+    # a single pass has no histogram-free form
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=6)
+        hj.load_host(P.REL_R, uni, pay)
+        hj.load_host(P.REL_S, uni, pay)
+        hj.partition(P.REL_R)
+        assert hj.partition_layout(P.REL_R) == "exact"
 
 
 # ---- partition parity --------------------------------------------------------------------------------
@@ -525,7 +576,8 @@ def test_fuzz_against_oracle(P, seed):
     Ps = rng.integers(-2**31, 2**31 - 1, len(S)).astype(np.int32)
     cfg = dict(bits1=int(rng.integers(0, 10)), bits2=int(rng.integers(0, 10)), force_bits=True,
                build_side=int(rng.integers(0, 3)), lds_capacity=int(rng.choice([0, 64, 300, 4608])),
-               lds_heads=int(rng.choice([0, 1, 16, 1024])), probe_chunk=int(rng.choice([0, 50, 1000, 65536])))
+               lds_heads=int(rng.choice([0, 1, 16, 1024])), probe_chunk=int(rng.choice([0, 50, 1000, 65536])),
+               exact_only=bool(seed % 3 == 0))
     if seed % 7 == 0:
         cfg = None     # library defaults
     em, eagg, echk = o.join_count(R, Pr, S, Ps)
