@@ -209,6 +209,41 @@ def launch_ranks(n):
     sys.exit(0)
 
 
+PROBE_TARGET_FRAC = 0.60  # stated probe-phase target: k_join_count >= 60 % of the 8 TB/s roofline
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def join_cpu_baseline(hj, torch, dev, threads, log2n=22):
+    """The reference's own CPU join, restated (oracle o_joinCpu = joinCpu + h_hashMurmur, hjcp.cu:2013-2059: one
+    2^20-slot chained table, serial build, OpenMP probe), at a size where it is meaningful (chains of 2^log2n / 2^20)."""
+    from oracle import pyoracle as o
+    n = 1 << log2n
+    k = torch.empty(n, dtype=torch.int32, device=dev)
+    hj.gen_unique(k, n, 0, n, 1)
+    hj.sync()
+    R = k.cpu().numpy()
+    hj.gen_unique(k, n, 0, n, 2)
+    hj.sync()
+    S = k.cpu().numpy()
+    t0 = time.perf_counter()
+    m, _ = o.joinCpu(R, S, threads=threads)
+    dt = time.perf_counter() - t0
+    assert m == n, (m, n)
+    return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port",
+            "sample": "2^%d x 2^%d unique uniform int32, oracle o_joinCpu (restatement of the reference's joinCpu, "
+                      "hash_join_clustered_probe.cu:2013-2059: 2^20-slot chained table, serial build, %d-thread probe), %.2f s"
+                      % (log2n, log2n, threads, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,10 +255,11 @@ def main():
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
     ap.add_argument("--lds", type=int, nargs=2, default=None, help="experiment knob: LDS table capacity and heads of the join kernel")
+    ap.add_argument("--exact-only", action="store_true", help="histogram + scan + scatter passes only (no histogram-free passes)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even at world size 1 (sanity runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the stream-copy ceiling and the phase split (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the HBM ceilings and the phase split (profiling runs)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -265,9 +301,9 @@ def main():
         # legacy default stream would add implicit synchronisation with other blocking streams
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
-    if a.bits or a.probe_chunk or a.lds:
+    if a.bits or a.probe_chunk or a.lds or a.exact_only:
         hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
-                     lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0)
+                     lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0, exact_only=a.exact_only)
     # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
     # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
     domain = min(total_n, 1 << 32)
@@ -283,21 +319,18 @@ def main():
     dup = max(1, total_n // domain)
     expect = total_n * dup  # every key occurs dup times in R and in S
 
+    dj = None
     if use_dist:
         from importlib import import_module
         dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev)
 
-    first = [True]
-
-    def step():
-        if use_dist and first[0]:   # fail fast if the exchange corrupts data (see dist.ShardedJoin.join)
-            first[0] = False
-            return dj.join(Rk, Rp, Sk, Sp, verify=True)[0]
+    def step(verify=False):
         if not use_dist:
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, Sk, Sp)
             return hj.join()[0]
-        return dj.join(Rk, Rp, Sk, Sp)[0]
+        # verify: the digest of everything sent must equal the digest of everything received (dist.ShardedJoin.join)
+        return dj.join(Rk, Rp, Sk, Sp, verify=verify)[0]
 
     def barrier():
         if use_dist:
@@ -305,7 +338,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        got = step()
+        got = step(verify=True)   # every warm-up step checks the exchange
         assert got == expect, (got, expect)
     hj.timings_reset()
     barrier()
@@ -322,41 +355,86 @@ def main():
     kt = hj.timings()
     ms_per_step = dt / a.steps * 1e3
     value = 2.0 * total_n * a.steps / dt / 1e9
+    layout = [hj.partition_layout(pkg.REL_R), hj.partition_layout(pkg.REL_S)]
 
-    # roofline of the dominant kernel: the radix scatter (4 launches per step at N=1: 2 passes x 2
+    dist_info = None
+    if use_dist:
+        recv = torch.tensor(list(dj.last_received), dtype=torch.int64, device=dev)
+        allrecv = [torch.empty_like(recv) for _ in range(world)]
+        dist.all_gather(allrecv, recv)
+        dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
+
+    # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
-    dom = max(("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter"), key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
+    passes = ("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter")
+    dom = max(passes, key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
     sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
     roof = None
     if sc["launches"] and not use_dist:
         launches_per_step = sc["launches"] / a.steps
-        tuples_per_launch = float(n)  # every scatter launch moves one whole relation (keys + payloads)
+        tuples_per_launch = float(n)  # every pass launch moves one whole relation (keys + payloads)
         avg_ms = sc["total_ms"] / sc["launches"]
         achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/): separate
         # --pmc runs for FETCH_SIZE and WRITE_SIZE, KB units, FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH §HBM)
-        traffic = None
+        traffic, src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_2p30.json")))["kernels"]
-            key = [k for k in pm if k.startswith("hj::" + dom + "<0")]
-            if key and a.log2n == 30:
-                traffic = pm[key[0]]["hbm_bytes_per_launch"]
+            src = "profiles/r2_pmc_2p%d.json" % a.log2n
+            pm = json.load(open(os.path.join(ROOT, src)))["kernels"]
+            key = [k for k in pm if k.startswith("hj::" + dom)]
+            traffic = pm[key[0]]["hbm_bytes_per_launch"] if key else None
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r1_pmc_2p30.json (rocprofv3 --pmc passes of this command)" if traffic else None,
+                "traffic_source": (src + " (rocprofv3 --pmc passes of this command)") if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch}
+        if not a.no_extras:
+            # on-box ceilings, same run: what HBM gives this access pattern with no partitioning work at all
+            tk, tp = torch.empty_like(Rk), torch.empty_like(Rp)
+            copy = hj.ubench("copy", Rk, Rp, tk, tp, n)
+            scat = hj.ubench("line_scatter", Rk, Rp, tk, tp, n)
+            del tk, tp
+            roof.update({"stream_copy_ceiling": round(copy, 1), "frac_of_stream_copy": round(achieved / copy, 4),
+                         "line_scatter_ceiling": round(scat, 1), "frac_of_line_scatter": round(achieved / scat, 4),
+                         "ceilings": "hj_ubench, same run: 16 B/lane copy of a 2^%d-tuple column pair; same reads with every 128-B "
+                                     "line stored at a pseudo-random aligned line position" % a.log2n})
     kernels = {k: {"launches_per_step": v["launches"] / a.steps, "ms_per_step": round(v["total_ms"] / a.steps, 4)}
                for k, v in kt.items() if v["launches"]}
     jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
     probe = None
     if jc["launches"] and not use_dist:
         avg = jc["total_ms"] / jc["launches"]
+        frac = 8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
         probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
-                 "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1),
-                 "frac_of_8TBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                 "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1), "frac_of_8TBs": round(frac, 4),
+                 "target_frac": PROBE_TARGET_FRAC, "meets_target": bool(frac >= PROBE_TARGET_FRAC)}
+
+    # the reference's phase split (hjcp.cu:938-940: Partition / Joins / Total throughput in MB/s of 2*(|R|+|S|)*4 bytes)
+    phase = None
+    if not use_dist and not a.no_extras:
+        reps = max(2, a.steps // 2)
+        tp_, tj_ = 0.0, 0.0
+        for _ in range(reps):
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hj.partition(pkg.REL_R)
+            hj.partition(pkg.REL_S)
+            hj.sync()
+            t3 = time.perf_counter()
+            assert hj.join_count()[0] == expect
+            t2 = time.perf_counter()
+            tp_ += t3 - t1
+            tj_ += t2 - t3
+        nbytes = 2.0 * (2 * n) * 4
+        phase = {"partition_ms": round(tp_ / reps * 1e3, 3), "join_ms": round(tj_ / reps * 1e3, 3),
+                 "partition_MBps": round(nbytes / (tp_ / reps) / 1e6, 0), "joins_MBps": round(nbytes / (tj_ / reps) / 1e6, 0),
+                 "total_MBps": round(nbytes / ((tp_ + tj_) / reps) / 1e6, 0),
+                 "units": "the reference's printed lines (hjcp.cu:938-940): 2*(|R|+|S|)*sizeof(int) bytes / seconds / 10^6"}
 
     # secondary: the materialising variant (count + scan + write of (key,payR,payS)), N=1 only
     mat = None
@@ -393,11 +471,15 @@ def main():
     cpu = None
     if rank == 0 and not use_dist and not a.no_cpu_baseline:
         cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
+        cpu["cpu_model"] = cpu_model()
+        cpu["joinCpu"] = join_cpu_baseline(hj, torch, dev, cpu["cores"])
 
     if rank == 0:
         cfg = hj.config()
         line = {
-            "metric": "billion tuples/sec (build+probe), 2^30⋈2^30 int32 uniform, 1/2/4/8 GPU",
+            "metric": "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)
+                      if world == 1 else
+                      "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform per GPU, %d GPUs" % (a.log2n, a.log2n, world),
             "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -406,8 +488,9 @@ def main():
                                    (a.log2n, a.log2n, 2 if cfg["bits2"] else 1, cfg["bits1"], cfg["bits2"],
                                     "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
                        "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
-                       "matches": int(got)},
-            "roofline": roof, "probe_phase": probe, "kernels": kernels, "materialize": mat, "cpu_baseline": cpu,
+                       "partition_layout_R_S": layout, "matches": int(got)},
+            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat,
+            "cpu_baseline": cpu, "dist": dist_info,
         }
         print(json.dumps(line))
     if use_dist:

@@ -54,6 +54,7 @@ struct Rel {
     uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
     bool partitioned = false;
     bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
+    bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
 };
 
 } // namespace
@@ -70,7 +71,7 @@ struct hj_ctx {
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
     Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
-    uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64)
+    uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // scanned per-wave counts + item list of the current partitions are on the device
     JoinArgs last_args{};
     bool last_tag16 = false;
@@ -379,7 +380,7 @@ int partition_rel(hj_ctx *c, int r) {
     const uint32_t P1 = 1u << b1, P2 = 1u << b2;
     const uint32_t nparts = b2 ? P1 * P2 : P1;
     FastPlan f{};
-    const bool fast = b2 && c->fast_path && !c->cfg.exact_only && plan_fast(c, R.n, P1, P2, f);
+    const bool fast = b2 && c->fast_path && !c->cfg.exact_only && !R.prefer_exact && plan_fast(c, R.n, P1, P2, f);
     const uint64_t elemsA = std::max<uint64_t>(R.n, fast ? f.sizeA : 0), elemsB = std::max<uint64_t>(R.n, fast ? f.sizeB : 0);
     RET(ensure(c, R.b_k, (size_t)(elemsB + PAD) * 4));
     RET(ensure(c, R.b_p, (size_t)(elemsB + PAD) * 4));
@@ -445,7 +446,7 @@ int resolve_layout(hj_ctx *c, Rel &R) {
     uint32_t ovf = 0;
     HIPCHK(c, hipMemcpyAsync(&ovf, R.flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ovf) { R.part_off = (const uint64_t *)R.off2.p; R.fast_tried = false; } // the exact passes ran: contiguous
+    if (ovf) { R.part_off = (const uint64_t *)R.off2.p; R.fast_tried = false; R.prefer_exact = true; } // the exact passes ran: contiguous
     return 0;
 }
 
@@ -511,7 +512,15 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
 
 int fetch_scalars(hj_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+    // the same round trip brings back the overflow flags of relations whose histogram-free passes were queued: the host
+    // learns which layout holds, and a binding that overflowed goes straight to the exact passes next time
+    for (int r = 0; r < 2; r++)
+        if (c->rel[r].fast_tried) HIPCHK(c, hipMemcpyAsync(c->h_scalars + 8 + r, c->rel[r].flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < 2; r++) {
+        Rel &R = c->rel[r];
+        if (R.fast_tried && (uint32_t)c->h_scalars[8 + r]) { R.fast_tried = false; R.part_off = (const uint64_t *)R.off2.p; R.prefer_exact = true; }
+    }
     resolve_completed(c); // every [sync] entry point folds finished stamps: the event backlog stays bounded
     return 0;
 }
@@ -539,8 +548,8 @@ int hj_create(hj_ctx **out, int device) {
     c->stream = c->own_stream;
     if (hipMalloc(&c->scalars.p, 64) != hipSuccess) { delete c; return HJ_ENOMEM; }
     c->scalars.cap = 64;
-    if (hipHostMalloc((void **)&c->h_scalars, 64, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
-    memset(c->h_scalars, 0, 64);
+    if (hipHostMalloc((void **)&c->h_scalars, 128, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    memset(c->h_scalars, 0, 128);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *ev = getenv("HJ_NO_KERNEL_EVENTS")) { if (ev[0] == '1') c->events = 0; }
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
@@ -637,6 +646,7 @@ int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, u
     R.in_p = (const int32_t *)R.own_p.p;
     R.n = n;
     R.bound = true;
+    R.prefer_exact = false; // new data: the histogram-free passes get their chance again
     invalidate(c, rel);
     return HJ_OK;
 }
@@ -646,6 +656,8 @@ int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_p
     if (n && (!d_keys || !d_pays)) return fail(c, HJ_EINVAL, "device columns == NULL");
     if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
     Rel &R = c->rel[rel];
+    // re-binding the same columns keeps what the last run learned about them (skewed keys: exact passes at once)
+    if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) R.prefer_exact = false;
     R.in_k = d_keys; R.in_p = d_pays; R.n = n; R.bound = true;
     invalidate(c, rel);
     return HJ_OK;
@@ -1115,6 +1127,29 @@ int hj_fill_payload(hj_ctx *c, int32_t *d_pays, uint64_t n, int mode, uint64_t f
     if (mode != HJ_PAYLOAD_ONES && mode != HJ_PAYLOAD_ROWID) return fail(c, HJ_EINVAL, "bad payload_mode");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_fill(c->stream, d_pays, n, mode, first_rowid));
+    return HJ_OK;
+}
+
+int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p, uint64_t n,
+              uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch) {
+    if (!c || (kind != 0 && kind != 1) || !reps) return HJ_EINVAL;
+    if (n < 32 || !d_in_k || !d_in_p || !d_out_k || !d_out_p) return fail(c, HJ_EINVAL, "hj_ubench needs four columns of >= 32 tuples");
+    if (((uintptr_t)d_in_k | (uintptr_t)d_in_p | (uintptr_t)d_out_k | (uintptr_t)d_out_p) & 15) return fail(c, HJ_EINVAL, "columns must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t a = get_event(c), b = get_event(c);
+    if (!a || !b) return fail(c, HJ_EHIP, "no HIP events");
+    HIPCHK(c, launch_ubench(c->stream, kind, d_in_k, d_in_p, d_out_k, d_out_p, n)); // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    for (uint32_t i = 0; i < reps; i++) HIPCHK(c, launch_ubench(c->stream, kind, d_in_k, d_in_p, d_out_k, d_out_p, n));
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    c->pool.push_back(a); c->pool.push_back(b);
+    uint64_t lines = n / 32, pow2 = 1;
+    while (pow2 * 2 <= lines) pow2 *= 2;
+    if (avg_ms) *avg_ms = (double)ms / reps;
+    if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * 16; // 8 B read + 8 B written per tuple
     return HJ_OK;
 }
 

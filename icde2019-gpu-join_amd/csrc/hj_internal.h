@@ -117,6 +117,7 @@ hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, con
 hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *beg,
                                     const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
+hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
 uint32_t host_shard_of(int32_t key, uint32_t nshards);
 
 } // namespace hj

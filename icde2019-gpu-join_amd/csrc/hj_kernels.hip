@@ -24,6 +24,7 @@
 //   All arithmetic is integer; there is no MFMA-shaped work on this path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -814,29 +815,40 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
 constexpr int WF_TRASH_LINES = WC_THREADS / WC_LINE;   // one trash slot per thread (branch-free placement)
 constexpr int WF_LINES = MAX_PARTS + WF_TRASH_LINES;
 constexpr int WF_MAXSEG = 1024;                        // segments of one parent (= pass-1 workgroups)
+constexpr uint32_t WF_NONE = 0xFFFFFFFFu;
 
 struct WfLds {
-    int32_t *bufK, *bufP;        // [WF_LINES][32] each
-    uint32_t *hh, *cur, *line;   // arrival counters by round parity; occupied slots; output position of slot 0
+    int2 *buf;                   // [WF_LINES][32] (key, payload) pairs: K = 512/P lines per digit + one trash slot per thread
+    uint32_t *hh, *line;         // per digit and round parity: (line fill at round start << 16) | arrivals; output position of slot 0
     uint32_t *wlist;             // [16 waves][32] flush work lists
     uint32_t *pc4, *sb;          // pass 2: prefix of 4-tuple units per segment [nseg+1]; segment start | padding
 };
 
 struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slotA + d*slotB, at slot*cap
 
+// One workgroup, one input stream, P digits with K = 512/P LDS lines each.  Per round of 8192 tuples:
+//   A  kept tuples of the previous round open their digit's next line; digit owners advance the output position by
+//      the lines flushed last round; every tuple takes its slot with ONE returning LDS atomic on a word that holds
+//      (fill of the digit's lines at round start << 16 | arrivals this round), so the returned value IS the slot;
+//   B  with the round's totals known (one LDS read per tuple): slots inside lines that leave this round, or in a
+//      digit none of whose lines leaves, are stored now ((key,payload) as one 8-byte LDS write); slots past the
+//      leaving lines are kept in registers for phase A; the digit owners seed the next round's counters;
+//   C  every full line leaves: 8 lanes move one line (two 16-byte LDS reads, a 16-byte store to each column).
+// All LDS traffic of a phase is issued back to back: operations that must not happen are pointed at per-thread
+// trash slots / per-lane trash counters instead of being branched around.
 template <int U, int KFIX, int SRC>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
-                                        uint32_t P, uint32_t K_rt, const FastGeom g, int32_t *__restrict__ out_keys,
+                                        uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
                                         int32_t *__restrict__ out_pays, uint64_t *__restrict__ obeg,
                                         uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf) {
-    int32_t *bufK = L_.bufK, *bufP = L_.bufP;
-    uint32_t *hh = L_.hh, *cur = L_.cur, *line = L_.line;
-    const uint32_t K = KFIX ? (uint32_t)KFIX : K_rt;
+    int2 *buf = L_.buf;
+    uint32_t *hh = L_.hh, *line = L_.line;
+    const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : (uint32_t)__builtin_ctz((uint32_t)MAX_PARTS / P);
+    const uint32_t K = 1u << kshift, capS = K * WC_LINE; // lines / slots per digit in LDS
     const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
     const uint32_t mask = P - 1;
     constexpr uint32_t ROUND = WC_THREADS * 4 * U;
-    constexpr bool BF = (KFIX == 1);
     // ---- input feeder ----
     // SRC 0: the contiguous tuples [lo64, hi64): thread t of round r loads the 16 bytes at a0 + r*ROUND + (u*1024+t)*4.
     // SRC 1: the parent's segments as one stream of 4-tuple units (segments are 16-byte aligned and padded to whole
@@ -888,9 +900,9 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
     for (int u = 0; u < U; u++) fetch(0, u, kv[u], pv[u], vm[u]);
     int4 kk[U], pp[U];     // the previous round's tuples: the kept ones are stored one phase later
-    uint32_t keep[U * 4];  // LDS word index of a kept tuple, 0xFFFFFFFF = none
+    uint32_t keep[U * 4];  // LDS pair index of a kept tuple, WF_NONE = none
 #pragma unroll
-    for (int j = 0; j < U * 4; j++) keep[j] = 0xFFFFFFFFu;
+    for (int j = 0; j < U * 4; j++) keep[j] = WF_NONE;
 #pragma unroll
     for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
     // the digit this thread owns (tid < P): slot geometry
@@ -899,116 +911,73 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     uint32_t par = 0;
     for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
         uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
-        // ---- A: finish the previous round (kept tuples open the next line, digit owners advance their state) and
-        //         rank this round's tuples.  512-way: branch-free (trash slots / trash counters), see k_scatter_wc ----
+        // ---- A ----
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if (BF) {
-                    const uint32_t k = keep[u * 4 + e];
-                    const uint32_t idx = k != 0xFFFFFFFFu ? k : trash;
-                    bufK[idx] = elem(kk[u], e);
-                    bufP[idx] = elem(pp[u], e);
-                } else if (keep[u * 4 + e] != 0xFFFFFFFFu) {
-                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
-                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
-                }
+                const uint32_t k = keep[u * 4 + e];
+                buf[k != WF_NONE ? k : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
             }
-        if (tid < P) {
-            const uint32_t total = cur[tid] + hprev[tid];
-            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
+        // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
+        // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
+        if (tid == 0 && (round & 3u) == 0) L_.wlist[(WC_THREADS / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < P) { // the lines flushed last round move this digit's output position
+            const uint32_t w = hprev[tid];
+            const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
             if (full) {
                 uint32_t nl = line[tid] + full;
-                if (nl + K * WC_LINE > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
+                if (nl + capS > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
                 line[tid] = nl;
             }
-            cur[tid] = total - full;
-            hprev[tid] = 0;
         }
-        uint32_t code[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple
+        uint32_t code[U * 4]; // digit << 16 | slot in the digit's lines ; WF_NONE = not a tuple
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const bool valid = (vm[u] >> e) & 1u;
                 const uint32_t d = ((uint32_t)elem(kv[u], e) >> shift) & mask;
-                uint32_t rk = 0;
-                if (BF) rk = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u);
-                else if (valid) rk = atomicAdd(&h[d], 1u);
-                code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
+                const uint32_t old = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
+                code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
         __syncthreads();
-        // ---- B: place ----
-        if (BF) {
-            uint32_t cdv[U * 4], hdv[U * 4];
+        // ---- B ----
+        const uint32_t stop = L_.wlist[(WC_THREADS / 64) * 32];
+        uint32_t hw[U * 4];
 #pragma unroll
-            for (int j = 0; j < U * 4; j++) {
-                const uint32_t dj = code[j] != 0xFFFFFFFFu ? code[j] >> 16 : 0u;
-                cdv[j] = cur[dj];
-                hdv[j] = h[dj];
+        for (int j = 0; j < U * 4; j++) hw[j] = h[code[j] != WF_NONE ? code[j] >> 16 : 0u]; // all LDS reads first
+        if (tid < P) { // next round's counter starts at the fill the digit's open line will have
+            const uint32_t w = h[tid];
+            hprev[tid] = (((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1)) << 16;
+        }
+        bool any_bypass = false;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int j = u * 4 + e;
+                const uint32_t c = code[j];
+                const bool valid = c != WF_NONE;
+                const uint32_t d = valid ? c >> 16 : 0u, q = c & 0xFFFFu;
+                const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
+                const bool leaves = q < full;
+                const bool now = valid && (leaves ? q < capS : full == 0);
+                any_bypass |= valid && leaves && q >= capS;
+                buf[now ? d * capS + q : trash] = make_int2(elem(kv[u], e), elem(pv[u], e));
+                keep[j] = (valid && !leaves && full != 0) ? d * capS + (q - full) : WF_NONE;
             }
-            bool any_bypass = false;
+        if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int j = u * 4 + e;
                     const uint32_t c = code[j];
-                    const bool valid = c != 0xFFFFFFFFu;
-                    const uint32_t d = valid ? c >> 16 : 0u;
-                    const uint32_t q = cdv[j] + (c & 0xFFFFu);
-                    const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
-                    const bool now = valid && q < (uint32_t)WC_LINE;
-                    const bool kept = valid && !now && q >= full;
-                    any_bypass |= valid && !now && q < full;
-                    const uint32_t idx = now ? d * WC_LINE + q : trash;
-                    bufK[idx] = elem(kv[u], e);
-                    bufP[idx] = elem(pv[u], e);
-                    keep[j] = kept ? d * WC_LINE + (q - full) : 0xFFFFFFFFu;
-                }
-            if (any_bypass) { // rare: a digit received more than a line in one round
-#pragma unroll
-                for (int u = 0; u < U; u++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int j = u * 4 + e;
-                        const uint32_t c = code[j];
-                        if (c != 0xFFFFFFFFu) {
-                            const uint32_t q = cdv[j] + (c & 0xFFFFu);
-                            const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
-                            if (q >= (uint32_t)WC_LINE && q < full) {
-                                const uint32_t d = c >> 16, o = line[d] + q;
-                                if (o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
-                                else *ovf = 1u;
-                            }
-                        }
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const uint32_t c = code[u * 4 + e];
-                    keep[u * 4 + e] = 0xFFFFFFFFu;
-                    if (c != 0xFFFFFFFFu) {
-                        const uint32_t d = c >> 16;
-                        const uint32_t cd = cur[d];
-                        const uint32_t q = cd + (c & 0xFFFFu);
-                        const uint32_t full = (cd + h[d]) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
-                        const uint32_t cap = K * WC_LINE, base = d * cap;              // K lines per digit
-                        if (q >= full) {             // remainder: stays in LDS after this round's flush
-                            if (full == 0) {         // nothing is flushed: append in place
-                                bufK[base + q] = elem(kv[u], e);
-                                bufP[base + q] = elem(pv[u], e);
-                            } else {
-                                keep[u * 4 + e] = base + (q - full);
-                            }
-                        } else if (q < cap) {        // a line that fills up this round
-                            bufK[base + q] = elem(kv[u], e);
-                            bufP[base + q] = elem(pv[u], e);
-                        } else {                     // beyond the digit's lines: straight to HBM
+                    if (c != WF_NONE) {
+                        const uint32_t d = c >> 16, q = c & 0xFFFFu;
+                        const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
+                        if (q < full && q >= capS) {
                             const uint32_t o = line[d] + q;
                             if (o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
                             else *ovf = 1u;
@@ -1022,106 +991,81 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             fetch(round + 1, u, kv[u], pv[u], vm[u]); // next round's loads fly while the lines are flushed
         }
         __syncthreads();
-        // ---- C: flush every line that filled up: aligned 128-byte stores ----
-        if (BF) {
+        // ---- C: the wave owns 32 of the 512 LDS lines (line ls belongs to digit ls >> kshift); the full ones are
+        //         compacted into a list and flushed 8 lanes per line ----
+        {
             uint32_t *wlist = L_.wlist + wv * 32;
-            for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
-                const uint32_t dl = dbase + (ln & 31u);
-                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-                const uint64_t m = __ballot(fullq);
-                const uint32_t nfull = (uint32_t)__popcll(m);
-                if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = dl;
-                __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
-                const uint32_t c4 = (ln & 7u) * 4;
-                for (uint32_t t = 0; t < nfull; t += 8) {
-                    const uint32_t idx = t + (ln >> 3);
-                    if (idx < nfull) {
-                        const uint32_t d = wlist[idx];
-                        const uint32_t gpos = line[d] + c4;
-                        const int4 kq = *reinterpret_cast<const int4 *>(bufK + d * WC_LINE + c4);
-                        const int4 pq = *reinterpret_cast<const int4 *>(bufP + d * WC_LINE + c4);
-                        *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
-                        *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            const uint32_t groups = (P + 31) / 32;
-            const uint32_t nrep = groups >= (uint32_t)(WC_THREADS / 64) ? 1u : (uint32_t)(WC_THREADS / 64) / groups;
-            const uint32_t rep = wv / groups;
-            for (uint32_t dbase = (wv % groups) * 32; dbase < P && rep < nrep; dbase += (WC_THREADS / 64) * 32) {
-                const uint32_t dl = dbase + (ln & 31u);
-                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-                uint64_t m = __ballot(fullq);
-                const uint32_t s = ln & (WC_LINE - 1);
-                while (m) {
-                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t cap = K * WC_LINE, base = d * cap;
-                    uint32_t full = (cur[d] + h[d]) & ~(uint32_t)(WC_LINE - 1);
-                    if (full > cap) full = cap;
-                    const uint32_t gl = line[d];
-                    for (uint32_t j = rep * WC_LINE; j < full; j += nrep * WC_LINE) {
-                        if (ln < (uint32_t)WC_LINE) out_keys[gl + j + s] = bufK[base + j + s];
-                        else out_pays[gl + j + s] = bufP[base + j + s];
-                    }
+            const uint32_t lsl = wv * 32 + (ln & 31u);
+            const uint32_t wq = h[lsl >> kshift];
+            uint32_t fullq_n = ((wq >> 16) + (wq & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
+            fullq_n = (fullq_n < capS ? fullq_n : capS) >> 5; // full lines of that digit
+            const bool fullq = (ln < 32u) && ((lsl & (K - 1)) < fullq_n);
+            const uint64_t m = __ballot(fullq);
+            const uint32_t nfull = (uint32_t)__popcll(m);
+            if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = lsl;
+            __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
+            const uint32_t c4 = (ln & 7u) * 4;
+            for (uint32_t t = 0; t < nfull; t += 8) {
+                const uint32_t idx = t + (ln >> 3);
+                if (idx < nfull) {
+                    const uint32_t ls = wlist[idx];
+                    const uint32_t gpos = line[ls >> kshift] + (ls & (K - 1)) * WC_LINE + c4;
+                    const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
+                    const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
+                    *reinterpret_cast<int4 *>(out_keys + gpos) = make_int4(x.x, x.z, y.x, y.z);
+                    *reinterpret_cast<int4 *>(out_pays + gpos) = make_int4(x.y, x.w, y.y, y.w);
                 }
             }
         }
         __syncthreads();
+        if (stop) return; // workgroup-uniform: every thread read the same LDS word between the same barriers
     }
     // ---- epilogue: phase A of the last round, the partially filled last line of every digit, the slot ranges ----
-    {
-        uint32_t *hprev = hh + (par ^ 1) * WC_HSTRIDE;
+    uint32_t *hlast = hh + (par ^ 1) * WC_HSTRIDE;
 #pragma unroll
-        for (int u = 0; u < U; u++)
+    for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
-                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
-                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
-                }
-        if (tid < P) {
-            const uint32_t total = cur[tid] + hprev[tid];
-            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
-            if (full) {
-                uint32_t nl = line[tid] + full;
-                if (nl + K * WC_LINE > my_lim) { *ovf = 1u; nl = my_base; }
-                line[tid] = nl;
-            }
-            cur[tid] = total - full;
+        for (int e = 0; e < 4; e++)
+            if (keep[u * 4 + e] != WF_NONE) buf[keep[u * 4 + e]] = make_int2(elem(kk[u], e), elem(pp[u], e));
+    if (tid < P) {
+        const uint32_t w = hlast[tid];
+        const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
+        if (full) {
+            uint32_t nl = line[tid] + full;
+            if (nl + capS > my_lim) { *ovf = 1u; nl = my_base; }
+            line[tid] = nl;
         }
     }
     __syncthreads();
     for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
         const uint32_t s = ln & (WC_LINE - 1);
-        const uint32_t base = d * K * WC_LINE;
-        if (s < cur[d]) {
-            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[base + s];
-            else out_pays[line[d] + s] = bufP[base + s];
+        const uint32_t w = hlast[d];
+        const uint32_t cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
+        if (s < cur) {
+            const int2 v = buf[d * capS + s];
+            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = v.x;
+            else out_pays[line[d] + s] = v.y;
         }
     }
     if (tid < P) {
         const uint32_t slot = g.slotA + tid * g.slotB;
+        const uint32_t w = hlast[tid];
         obeg[slot] = my_base;
-        oend[slot] = (uint64_t)line[tid] + cur[tid];
+        oend[slot] = (uint64_t)line[tid] + (((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1));
     }
 }
 
 __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
-    L_.bufK = reinterpret_cast<int32_t *>(smem);
-    L_.bufP = L_.bufK + WF_LINES * WC_LINE;
-    L_.hh = reinterpret_cast<uint32_t *>(L_.bufP + WF_LINES * WC_LINE);
-    L_.cur = L_.hh + 2 * WC_HSTRIDE;
-    L_.line = L_.cur + MAX_PARTS;
+    L_.buf = reinterpret_cast<int2 *>(smem);
+    L_.hh = reinterpret_cast<uint32_t *>(L_.buf + WF_LINES * WC_LINE);
+    L_.line = L_.hh + 2 * WC_HSTRIDE;
     L_.wlist = L_.line + MAX_PARTS;
-    L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32;
+    L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32 + 4; // + the "stop" word
     L_.sb = L_.pc4 + WF_MAXSEG + 4;
 }
 size_t fast_lds_bytes() {
-    return (size_t)WF_LINES * WC_LINE * 4 * 2 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 * 2 +
-           (WC_THREADS / 64) * 32 * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4;
+    return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
+           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4;
 }
 
 // pass 1: one workgroup per span of the contiguous input
@@ -1130,16 +1074,17 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
     wf_carve(L_, smem);
+    if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // an earlier workgroup gave up already
     const uint32_t tid = threadIdx.x, s = blockIdx.x;
     const uint64_t lo = (uint64_t)s * a.span;
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
-    const uint32_t K = (uint32_t)MAX_PARTS / a.P;
     FastGeom g{s, a.nspans, a.cap};
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) { L_.cur[tid] = 0; L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap; }
+    if (tid < a.P) L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap;
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    if (K == 1) wc_fast<U, 1, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
 // pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
@@ -1150,7 +1095,6 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     WfLds L_;
     wf_carve(L_, smem);
     const uint32_t tid = threadIdx.x, parent = blockIdx.x;
-    const uint32_t K = (uint32_t)MAX_PARTS / a.P;
     FastGeom g{parent * a.P, 1u, a.cap};
     uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
     // segment table of this parent: 4-tuple units per segment, scanned
@@ -1167,10 +1111,65 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     if (tid == 0) L_.pc4[a.spp] = total;
     __syncthreads();
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) { L_.cur[tid] = 0; L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap; }
+    if (tid < a.P) L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap;
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    if (K == 1) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, K, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// ---- on-box ceilings for the roofline (bench.py): what the HBM system gives the two access patterns of a radix
+// pass, with no partitioning work at all.  KIND 0: stream copy of a column pair, 16 bytes per lane.  KIND 1: the same
+// streaming reads, but every 128-byte line (8 lanes x 16 bytes) is stored at a pseudo-random line position of the
+// output (bijection on the line index: odd multiplier modulo a power of two) — aligned whole-line scatter, the
+// write pattern of the write-combining flush. ----
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_nt(const int4 *p) { v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_nt(int4 *p, int4 a) { v4i_t v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<v4i_t *>(p)); }
+
+template <int KIND, int UNR>
+__global__ __launch_bounds__(256) void k_ubench(const int4 *__restrict__ ik, const int4 *__restrict__ ip, int4 *__restrict__ ok,
+                                                int4 *__restrict__ op, uint64_t n16, uint64_t line_mask, uint64_t mul, int nt) {
+    // a workgroup owns contiguous chunks of 256*UNR units; every thread issues its UNR loads of both columns before
+    // the first store, so 2*UNR 16-byte loads per lane are in flight
+    const uint64_t chunk = (uint64_t)256 * UNR;
+    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n16; base += (uint64_t)gridDim.x * chunk) {
+        int4 a[UNR], b[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u < n16) { if (nt & 2) { a[j] = ld_nt(ik + u); b[j] = ld_nt(ip + u); } else { a[j] = ik[u]; b[j] = ip[u]; } }
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u < n16) {
+                uint64_t o = u;
+                if (KIND == 1) o = ((((u >> (3 + (nt >> 4))) * mul) & (line_mask >> (nt >> 4))) << (3 + (nt >> 4))) | (u & ((8u << (nt >> 4)) - 1)); // nt >> 4: log2 lines per scattered chunk (experiments)
+                if (nt & 1) { st_nt(ok + o, a[j]); st_nt(op + o, b[j]); } else { ok[o] = a[j]; op[o] = b[j]; }
+            }
+        }
+    }
+}
+
+hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n) {
+    const uint64_t n16 = n / 4;
+    uint64_t lines = n16 / 8, pow2 = 1;
+    while (pow2 * 2 <= lines) pow2 *= 2;
+    const uint64_t used16 = kind == 1 ? pow2 * 8 : n16; // the scatter covers the largest power-of-two number of lines
+    static int blocks = 0, unr = 0, nt = 0;
+    if (!blocks) {
+        const char *e = getenv("HJ_UB_BLOCKS"); blocks = e ? atoi(e) : 16384;
+        const char *f = getenv("HJ_UB_UNROLL"); unr = f ? atoi(f) : 2;
+        const char *h = getenv("HJ_UB_NT"); nt = h ? atoi(h) : 0;
+    }
+    dim3 g(blocks), b(256);
+    const uint64_t mul = 0x9E3779B97F4A7C15ULL | 1;
+#define UB(K_, U_) hipLaunchKernelGGL((k_ubench<K_, U_>), g, b, 0, st, (const int4 *)ik, (const int4 *)ip, (int4 *)ok, (int4 *)op, used16, K_ ? pow2 - 1 : (uint64_t)0, mul, nt)
+    if (kind == 0) { if (unr == 1) UB(0, 1); else if (unr == 2) UB(0, 2); else if (unr == 8) UB(0, 8); else UB(0, 4); }
+    else { if (unr == 1) UB(1, 1); else if (unr == 2) UB(1, 2); else if (unr == 8) UB(1, 8); else UB(1, 4); }
+#undef UB
+    return hipGetLastError();
 }
 
 // partition ranges from an offsets array (single-pass / unpartitioned layouts): beg[i] = off[i], end[i] = off[i+1]

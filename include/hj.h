@@ -187,6 +187,13 @@ int hj_digest_triples(hj_ctx *ctx, const int32_t *d_key, const int32_t *d_payR, 
  * (key >> 0) & (nparts-1), plus per-partition (key,pay) digests into d_digests[nparts] if non-NULL.  [sync] */
 int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_digests);
 
+/* ---- measurement: on-box HBM ceilings of the two access patterns of a radix pass, no partitioning work.
+ *      kind 0 = stream copy of a (key, payload) column pair, 16 bytes per lane; kind 1 = same streaming reads, every
+ *      128-byte line stored at a pseudo-random aligned line position (the write pattern of the write-combining
+ *      flush).  avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
+int hj_ubench(hj_ctx *ctx, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p,
+              uint64_t n, uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch);
+
 /* ---- generator_ETHZ drop-in (host side; src/generator_ETHZ.cuh:11-23) ----
  * Same generators, same raw-int32 .bin cache format; the time(NULL)/rand() global state of the
  * reference is replaced by an explicit seed (0 = take time(NULL) like the reference). */

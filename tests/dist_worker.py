@@ -64,12 +64,32 @@ def main():
         engine = OracleEngine(pkg)
     from importlib import import_module
     dj = import_module(pkg.__name__ + ".dist").ShardedJoin(engine, pkg, dev)
+    dj.force_exchange = os.environ.get("HJ_DIST_FORCE_EXCHANGE") == "1"
     if "HJ_DIST_CHUNK" in os.environ:       # force several point-to-point chunks per peer
         dj.CHUNK = int(os.environ["HJ_DIST_CHUNK"])
+
+    if os.environ.get("HJ_DIST_BIG") and gpu:
+        # full-size exchange: 2^30 tuples per relation per rank generated on the device (at world size 2 a peer's share of
+        # a column is 2^29 elements = 2 GiB, the size at which a single RCCL message was seen corrupted: the chunked
+        # point-to-point path must carry it).  Keys = two permutations of [0, world * 2^30): closed-form count.
+        n = 1 << int(os.environ["HJ_DIST_BIG"])
+        cols = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
+        engine.gen_unique(cols[0], n, rank * n, world * n, 1)
+        engine.gen_unique(cols[2], n, rank * n, world * n, 2)
+        engine.fill_payload(cols[1], n, "ones")
+        engine.fill_payload(cols[3], n, "ones")
+        engine.sync()
+        res = [dj.join(cols[0], cols[1], cols[2], cols[3], verify=True) for _ in range(2)]
+        if rank == 0:
+            print("RESULT " + json.dumps({"got": res, "expect": [[world * n, world * n]] * 2}))
+        dist.destroy_process_group()
+        return
 
     # every rank generates the same global relations and keeps its own slice
     rng = np.random.default_rng(123)
     nR, nS = 20_000, 50_001
+    if "HJ_DIST_N" in os.environ:           # GPU runs: large enough for several chunks per peer
+        nR, nS = (int(x) for x in os.environ["HJ_DIST_N"].split(","))
     R = rng.integers(-5000, 5000, nR).astype(np.int32)
     S = rng.integers(-5000, 5000, nS).astype(np.int32)
     Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)

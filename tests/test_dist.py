@@ -43,8 +43,35 @@ def test_shard_function_is_balanced_and_total():
 
 @pytest.mark.gpu
 def test_sharded_join_rccl_world1():
-    """The same driver on the real engine over RCCL (one rank: what a 1-GPU box can run)."""
+    """The same driver on the real engine over RCCL (one rank: what a 1-GPU box can run): once on the world-1
+    short cut (no split, no exchange), once with the split + exchange machinery forced."""
     res = _run(1, {"HJ_DIST_GPU": "1"}, 29642)
+    assert res["got"] == res["expect"]
+    res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_CHUNK": "4096"}, 29644)
+    assert res["got"] == res["expect"]
+    res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_BIG": "26"}, 29645)   # device-generated inputs
+    assert res["got"] == res["expect"]
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs on one node")
+def test_sharded_join_rccl_world2():
+    """Two real ranks: HIP engine + RCCL all-to-all over xGMI (stream ordering between the join stream and the
+    RCCL work, the overlap of partition(R) with the in-flight S exchange, several point-to-point chunks per peer)."""
+    res = _run(2, {"HJ_DIST_GPU": "1", "HJ_DIST_N": "3000000,7000001", "HJ_DIST_CHUNK": "300000"}, 29646)
+    assert res["got"] == res["expect"]
+    res = _run(2, {"HJ_DIST_GPU": "1"}, 29648)
+    assert res["got"] == res["expect"]
+    # 2^30 tuples per relation per rank: a peer's share of a column is 2^29 elements (2 GiB) → several 512-MiB chunks
+    res = _run(2, {"HJ_DIST_GPU": "1", "HJ_DIST_BIG": "30"}, 29650)
     assert res["got"] == res["expect"]
 
 
