@@ -310,7 +310,7 @@ int pass_hist(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa, uint64_t 
 int pass_scatter(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa) {
     // wide fan-out: LDS write-combining lines (aligned 128-B stores); narrow fan-out (shard split, small
     // inputs): the sorted-tile kernel, whose runs are long anyway.  HJ_SCATTER_VARIANT overrides (experiments).
-    const int variant = c->scatter_variant >= 0 ? c->scatter_variant : (pa.P >= 64 ? 4 : 1);
+    const int variant = c->scatter_variant >= 0 ? c->scatter_variant : ((mode == 0 && pa.P >= 64) ? 4 : 1);
     { Timed t(c, variant >= 4 ? "k_scatter_wc" : "k_scatter", st, true); HIPCHK(c, launch_scatter(st, mode, variant, pa)); }
     return 0;
 }
@@ -556,8 +556,6 @@ int hj_create(hj_ctx **out, int device) {
     const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
     if (sv) c->scatter_variant = atoi(sv);
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
-    const char *ab = getenv("HJ_WC_ABLATE"); // timing-only experiments: results are wrong when set
-    if (ab) (void)set_wc_ablate((uint32_t)atoi(ab));
     *out = c;
     return HJ_OK;
 }

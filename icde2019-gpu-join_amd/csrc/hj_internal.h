@@ -97,7 +97,6 @@ hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
 size_t scatter_lds_bytes(int threads, int u);
-hipError_t set_wc_ablate(uint32_t v);
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, uint2 *items);

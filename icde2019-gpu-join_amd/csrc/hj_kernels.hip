@@ -431,369 +431,16 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
     }
 }
 
-// Scatter one span through per-digit LDS WRITE-COMBINING buffers (the software write-combining idea
-// of the reference's CPU partitioner, partition-primitives.cu:40-125, re-expressed in LDS): every
-// digit owns 128-byte lines of keys and of payloads (32 tuples each) in LDS; tuples are appended to
-// their digit's line, and a line leaves the CU only when it is full — as one aligned 128-B store of
-// 32 lanes.  On MI355X aligned full-line scatter stores run at ~5 TB/s while the same bytes in
-// unaligned runs run at 1-2.5 TB/s (scratch/ubench_store.hip), and that is the whole point.
-//
-// The span's private output run of digit d starts at g0 = hist-scan position (any alignment).  The
-// LDS lines of d mirror the 128-B lines of the output that are currently being filled: slot s is
-// output position line[d] + s, line[d] % 32 == 0.  Per round of 8192 tuples (1024 threads x two
-// 16-byte loads): (A) rank every tuple inside its digit with one returning LDS atomic; (B) tuples
-// that fall into lines that fill up this round are stored to LDS, the remainder is kept in registers
-// and opens the next line one phase later; (C) every full line is flushed by one wave (lanes 0-31 the
-// key line, lanes 32-63 the payload line).  3 barriers per round, no retry loops.
-//
-// Lines per digit: K = 512 / fan-out, i.e. room for twice the expected arrivals of a round at any
-// fan-out.  Skew: the span's own histogram (already in HBM from k_hist) tells which digits expect
-// more than that; at span start up to WC_EXTRA spare lines are handed to them in proportion, and a
-// span dominated by one digit switches the rank atomic to its wave-aggregated form.  Such spans take
-// the general code path (SKEW=true); all others take a lean path with no per-digit line table, and
-// the 512-way case (K = 1) is additionally compiled with its constants folded — the kernel is
-// instruction-sensitive (1 workgroup per CU), measured +33 % when every span ran the general path.
-// What still exceeds a digit's lines goes straight to HBM (correct, just slower).
-// Algorithmic traffic: 8 B read + 8 B written per tuple.
-// timing-only ablation mask for experiments (HJ_WC_ABLATE; results are wrong when non-zero)
-__device__ uint32_t g_wc_ablate = 0;
-
+// Write-combining scatter (k_scatter_wc, k_part1_fast, k_part2_fast): the software write-combining idea of the
+// reference's CPU partitioner (partition-primitives.cu:40-125) re-expressed in LDS.  Every digit owns 128-byte
+// lines in LDS (32 tuples); tuples are appended to their digit's line and a line leaves the CU only when it is
+// full, as one aligned 128-byte store per column.  On MI355X a two-column stream copy runs at ~5.2 TB/s and the
+// same copy with every 128-byte line scattered to a random aligned position at ~5.1 TB/s (hj_ubench), while
+// unaligned 16-tuple runs reach 1-2.5 TB/s: whole aligned lines are the point.  The round machinery is wc_fast
+// below; the exact (histogram-backed) kernel k_scatter_wc follows it.
 constexpr int WC_THREADS = 1024;
 constexpr int WC_LINE = 32;   // tuples per 128-byte line
-constexpr int WC_EXTRA = 64;  // spare lines for heavy digits
-constexpr int WC_LINES = MAX_PARTS + WC_EXTRA;
 constexpr int WC_HSTRIDE = MAX_PARTS + 64; // arrival counters per parity + 64 per-lane trash counters (branch-free ranking)
-
-struct WcLds {
-    int32_t *bufK, *bufP;                   // [WC_LINES][32] each
-    uint32_t *hh, *cur, *line, *lo, *capb;  // see k_scatter_wc
-    uint32_t *wlist;                        // [16 waves][32]: full digits of each wave (flush work list)
-};
-
-template <int MODE, int U, bool SKEW, int KFIX>
-__device__ __forceinline__ void wc_span(const WcLds &L_, const SpanInfo &si, const int32_t *__restrict__ keys,
-                                        const int32_t *__restrict__ pays, uint64_t nalloc, uint32_t shift, uint32_t P,
-                                        uint32_t mask_or_n, int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                        bool heavy_span, uint32_t K_rt) {
-    int32_t *bufK = L_.bufK, *bufP = L_.bufP;
-    uint32_t *hh = L_.hh, *cur = L_.cur, *line = L_.line, *lo = L_.lo, *capb = L_.capb;
-    (void)capb; (void)heavy_span;
-    const uint32_t K = KFIX ? (uint32_t)KFIX : K_rt; // KFIX = 1: the 512-way case with constants folded
-    const uint32_t abl = __builtin_amdgcn_readfirstlane(g_wc_ablate);
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
-    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
-    const uint64_t a0 = si.lo & ~(uint64_t)3;
-    // 32-bit positions relative to a0 (a span is < 2^32 tuples)
-    const uint32_t rlo = (uint32_t)(si.lo - a0), rhi = (uint32_t)(si.hi - a0);
-    const int32_t *kin = keys + a0, *pin = pays + a0;
-    const uint64_t navail = nalloc - a0;
-    int4 kv[U], pv[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        uint32_t r = (u * WC_THREADS + tid) * 4;
-        kv[u] = (r < rhi) ? load4(kin, r, navail) : make_int4(0, 0, 0, 0);
-        pv[u] = (r < rhi) ? load4(pin, r, navail) : make_int4(0, 0, 0, 0);
-    }
-    int4 kk[U], pp[U];     // the previous round's tuples: the kept ones are stored one phase later
-    uint32_t keep[U * 4];  // LDS word index of a kept tuple, 0xFFFFFFFF = none
-#pragma unroll
-    for (int j = 0; j < U * 4; j++) keep[j] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
-    uint32_t par = 0;
-    for (uint32_t r0 = 0; r0 < rhi; r0 += ROUND, par ^= 1) {
-        uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
-        // ---- A: finish the previous round (kept tuples open the next line, digit owners advance
-        //         their state), and rank this round's tuples (arrival counters alternate by parity) ----
-        // Lean 512-way path: BRANCH-FREE.  Operations that must not happen (nothing kept, not a tuple of
-        // this span) are redirected to per-thread trash slots/counters instead of being jumped over, so
-        // the compiler issues the 8 LDS operations of a phase back to back — one LDS round trip, not 8.
-        constexpr bool BF = (KFIX == 1 && !SKEW);
-        const uint32_t trash = MAX_PARTS * WC_LINE + tid; // a slot in the (unused on this path) spare lines
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (BF) {
-                    const uint32_t k = keep[u * 4 + e];
-                    const uint32_t idx = k != 0xFFFFFFFFu ? k : trash;
-                    bufK[idx] = elem(kk[u], e);
-                    bufP[idx] = elem(pp[u], e);
-                } else if (keep[u * 4 + e] != 0xFFFFFFFFu) {
-                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
-                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
-                }
-            }
-        if (tid < P) {
-            const uint32_t total = cur[tid] + hprev[tid];
-            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
-            if (full) { line[tid] += full; lo[tid] = 0; }
-            cur[tid] = total - full;
-            hprev[tid] = 0;
-        }
-        uint32_t code[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t r = r0 + (u * WC_THREADS + tid) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const bool valid = r + e >= rlo && r + e < rhi;
-                const uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
-                uint32_t rk = 0;
-                if (BF) rk = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
-                else if (SKEW && heavy_span) rk = rank_in_digit(h, d, valid); // workgroup-uniform branch
-                else if (valid) { if (abl & 8u) rk = 0; else rk = atomicAdd(&h[d], 1u); }
-                code[u * 4 + e] = valid ? ((d << 16) | rk) : 0xFFFFFFFFu;
-            }
-        }
-        __syncthreads();
-        // ---- B: place: lines that fill this round / keep for the next line / straight to HBM ----
-        if (BF) {
-            uint32_t cdv[U * 4], hdv[U * 4];
-#pragma unroll
-            for (int j = 0; j < U * 4; j++) { // all 16 LDS reads first
-                const uint32_t dj = code[j] != 0xFFFFFFFFu ? code[j] >> 16 : 0u;
-                cdv[j] = cur[dj];
-                hdv[j] = h[dj];
-            }
-            bool any_bypass = false;
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int j = u * 4 + e;
-                    const uint32_t c = code[j];
-                    const bool valid = c != 0xFFFFFFFFu;
-                    const uint32_t d = valid ? c >> 16 : 0u;
-                    const uint32_t q = cdv[j] + (c & 0xFFFFu);
-                    const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
-                    // one line per digit: slots < 32 are stored now (they either leave this round or nothing
-                    // leaves); beyond the lines that leave → kept; in between (>= 2 lines in a round) → bypass
-                    const bool now = valid && q < (uint32_t)WC_LINE;
-                    const bool kept = valid && !now && q >= full;
-                    any_bypass |= valid && !now && q < full;
-                    const uint32_t idx = now ? d * WC_LINE + q : trash;
-                    bufK[idx] = elem(kv[u], e);
-                    bufP[idx] = elem(pv[u], e);
-                    keep[j] = kept ? d * WC_LINE + (q - full) : 0xFFFFFFFFu;
-                }
-            if (any_bypass) { // rare (a digit received more than a line in one round)
-#pragma unroll
-                for (int u = 0; u < U; u++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int j = u * 4 + e;
-                        const uint32_t c = code[j];
-                        if (c != 0xFFFFFFFFu) {
-                            const uint32_t q = cdv[j] + (c & 0xFFFFu);
-                            const uint32_t full = (cdv[j] + hdv[j]) & ~(uint32_t)(WC_LINE - 1);
-                            if (q >= (uint32_t)WC_LINE && q < full) {
-                                out_keys[line[c >> 16] + q] = elem(kv[u], e);
-                                out_pays[line[c >> 16] + q] = elem(pv[u], e);
-                            }
-                        }
-                    }
-            }
-        } else if (!(abl & 4u))
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t c = code[u * 4 + e];
-                keep[u * 4 + e] = 0xFFFFFFFFu;
-                if (c != 0xFFFFFFFFu) {
-                    const uint32_t d = c >> 16;
-                    const uint32_t cd = cur[d];
-                    const uint32_t q = cd + (c & 0xFFFFu);
-                    const uint32_t full = (cd + h[d]) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
-                    uint32_t cap = K * WC_LINE, base = d * cap;                   // lean path: K lines per digit
-                    if (SKEW) { const uint32_t cb = capb[d]; cap = (cb >> 16) * WC_LINE; base = (cb & 0xFFFFu) * WC_LINE; }
-                    if (q >= full) {             // remainder: stays in LDS after this round's flush
-                        if (full == 0) {         // nothing is flushed: append in place
-                            bufK[base + q] = elem(kv[u], e);
-                            bufP[base + q] = elem(pv[u], e);
-                        } else {
-                            keep[u * 4 + e] = base + (q - full);
-                        }
-                    } else if (q < cap) {        // a line that fills up this round
-                        bufK[base + q] = elem(kv[u], e);
-                        bufP[base + q] = elem(pv[u], e);
-                    } else {                     // beyond the digit's lines (extreme skew): bypass the buffer
-                        out_keys[line[d] + q] = elem(kv[u], e);
-                        out_pays[line[d] + q] = elem(pv[u], e);
-                    }
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            kk[u] = kv[u]; pp[u] = pv[u];
-            // next round's loads fly while the lines are flushed
-            const uint32_t r1 = r0 + ROUND + (u * WC_THREADS + tid) * 4;
-            const bool in = r1 < rhi && r1 >= ROUND && !(abl & 16u); // r1 >= ROUND: no wrap of the 32-bit position
-            kv[u] = in ? load4(kin, r1, navail) : make_int4(0, 0, 0, 0);
-            pv[u] = in ? load4(pin, r1, navail) : make_int4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        // ---- C: flush every line that filled up: one aligned 128-B store per column.  A wave owns 32
-        //         digits: a ballot picks the ones with full lines, the wave walks only those ----
-        if (abl & 2u) {
-        } else if (KFIX == 1 && !SKEW) {
-            // The wave's full digits are compacted into a small LDS list; then 8 lanes move one 128-B
-            // line with 16-byte LDS reads and 16-byte stores, i.e. one iteration flushes the key and the
-            // payload lines of EIGHT digits — no per-line chain of dependent LDS round trips.
-            uint32_t *wlist = L_.wlist + wv * 32;
-            for (uint32_t dbase = wv * 32; dbase < P; dbase += (WC_THREADS / 64) * 32) {
-                const uint32_t dl = dbase + (ln & 31u);
-                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-                const uint64_t m = __ballot(fullq);
-                const uint32_t nfull = (uint32_t)__popcll(m);
-                if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = dl;
-                __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
-                const uint32_t c4 = (ln & 7u) * 4;
-                for (uint32_t t = 0; t < nfull; t += 8) {
-                    const uint32_t idx = t + (ln >> 3);
-                    if (idx < nfull) {
-                        const uint32_t d = wlist[idx];
-                        const uint32_t first_valid = lo[d], gpos = line[d] + c4;
-                        const int4 kq = *reinterpret_cast<const int4 *>(bufK + d * WC_LINE + c4);
-                        const int4 pq = *reinterpret_cast<const int4 *>(bufP + d * WC_LINE + c4);
-                        if (abl & 1u) {
-                            asm volatile("" ::"v"(kq.x), "v"(pq.x));
-                        } else if (first_valid == 0) {
-                            *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
-                            *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
-                        } else { // the span's first line of this digit starts mid-line: element-wise
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                                if (c4 + e >= first_valid) {
-                                    out_keys[gpos + e] = elem(kq, e);
-                                    out_pays[gpos + e] = elem(pq, e);
-                                }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            // At narrow fan-out (fewer than 16 groups of 32 digits) the lines of one digit are dealt to
-            // several waves (rep), so that all 16 waves flush.
-            const uint32_t groups = (P + 31) / 32;
-            const uint32_t nrep = groups >= (uint32_t)(WC_THREADS / 64) ? 1u : (uint32_t)(WC_THREADS / 64) / groups;
-            const uint32_t rep = wv / groups;
-            for (uint32_t dbase = (wv % groups) * 32; dbase < P && rep < nrep; dbase += (WC_THREADS / 64) * 32) {
-                const uint32_t dl = dbase + (ln & 31u);
-                const bool fullq = (ln < 32u) && (dl < P) && (cur[dl] + h[dl] >= (uint32_t)WC_LINE);
-                uint64_t m = __ballot(fullq);
-                const uint32_t s = ln & (WC_LINE - 1);
-                while (m) {
-                    const uint32_t d = dbase + (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1;
-                    uint32_t cap = K * WC_LINE, base = d * cap;
-                    if (SKEW) { const uint32_t cb = capb[d]; cap = (cb >> 16) * WC_LINE; base = (cb & 0xFFFFu) * WC_LINE; }
-                    uint32_t full = (cur[d] + h[d]) & ~(uint32_t)(WC_LINE - 1);
-                    if (full > cap) full = cap;
-                    const uint32_t first_valid = lo[d], g = line[d];
-                    for (uint32_t j = rep * WC_LINE; j < full; j += nrep * WC_LINE) {
-                        if (j + s >= first_valid) {
-                            if (ln < (uint32_t)WC_LINE) out_keys[g + j + s] = bufK[base + j + s];
-                            else out_pays[g + j + s] = bufP[base + j + s];
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- epilogue: phase A of the last round, then the partially filled last line of every digit ----
-    {
-        uint32_t *hprev = hh + (par ^ 1) * WC_HSTRIDE;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (keep[u * 4 + e] != 0xFFFFFFFFu) {
-                    bufK[keep[u * 4 + e]] = elem(kk[u], e);
-                    bufP[keep[u * 4 + e]] = elem(pp[u], e);
-                }
-        if (tid < P) {
-            const uint32_t total = cur[tid] + hprev[tid];
-            const uint32_t full = total & ~(uint32_t)(WC_LINE - 1);
-            if (full) { line[tid] += full; lo[tid] = 0; }
-            cur[tid] = total - full;
-        }
-    }
-    __syncthreads();
-    for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
-        const uint32_t s = ln & (WC_LINE - 1);
-        const uint32_t base = SKEW ? (capb[d] & 0xFFFFu) * WC_LINE : d * K * WC_LINE;
-        if (s >= lo[d] && s < cur[d]) {
-            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = bufK[base + s];
-            else out_pays[line[d] + s] = bufP[base + s];
-        }
-    }
-}
-
-template <int MODE, int U>
-__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                           uint64_t nalloc, const uint64_t *__restrict__ sbeg,
-                                                           const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
-                                                           const uint32_t *__restrict__ span_start,
-                                                           uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                           const uint32_t *__restrict__ hist,
-                                                           const uint64_t *__restrict__ chunk_prefix,
-                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                           uint64_t n_out, const uint32_t *__restrict__ run_if) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (run_if && !*run_if) return;
-    WcLds L_;
-    L_.bufK = reinterpret_cast<int32_t *>(smem);
-    L_.bufP = L_.bufK + WC_LINES * WC_LINE;
-    L_.hh = reinterpret_cast<uint32_t *>(L_.bufP + WC_LINES * WC_LINE); // [2][MAX_PARTS] arrivals, by round parity
-    L_.cur = L_.hh + 2 * WC_HSTRIDE;  // occupied slots of the digit's lines
-    L_.line = L_.cur + MAX_PARTS;     // output position of slot 0 (multiple of 32)
-    L_.lo = L_.line + MAX_PARTS;      // first valid slot (non-zero only for the first line)
-    L_.capb = L_.lo + MAX_PARTS;      // (number of lines << 16) | first line of the digit   (SKEW path)
-    L_.wlist = L_.capb + MAX_PARTS;
-    SpanInfo si;
-    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
-    const uint32_t tid = threadIdx.x;
-    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
-    // ---- span start: output cursors, and spare lines for the digits this span's histogram marks heavy ----
-    uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
-    const uint32_t K = (uint32_t)MAX_PARTS / P; // lines per digit: 2x the expected arrivals of a round
-    const uint64_t L = (uint64_t)span_start[nseg] * P;
-    uint32_t extra = 0, cnt = 0;
-    if (tid < P) {
-        const uint64_t idx = (uint64_t)si.first * P + (uint64_t)tid * si.nsp + si.s;
-        const uint64_t g0 = (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG];
-        const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : n_out;
-        cnt = (uint32_t)(g1 - g0);
-        L_.line[tid] = (uint32_t)g0 & ~(uint32_t)(WC_LINE - 1);
-        L_.cur[tid] = L_.lo[tid] = (uint32_t)g0 & (WC_LINE - 1);
-        // lines needed for the expected arrivals per round with 30 % headroom, beyond the K every digit has
-        const uint64_t len = si.hi - si.lo;
-        const uint32_t need = (uint32_t)(((uint64_t)cnt * ROUND * 13 / 10) / (len ? len : 1)) / WC_LINE + 1;
-        extra = need > K ? need - K : 0;
-    }
-    uint32_t total_extra, any_heavy, dummy;
-    (void)block_excl_scan<uint32_t>(extra, scratch, &total_extra);
-    if (total_extra > (uint32_t)WC_EXTRA) extra = extra * WC_EXTRA / total_extra;
-    const uint32_t ex = block_excl_scan<uint32_t>(extra, scratch, &dummy);
-    // a span whose tuples mostly share one digit: same-address LDS atomics would serialise per lane
-    const uint32_t heavy = (tid < P && (uint64_t)cnt * 4 > (si.hi - si.lo)) ? 1u : 0u;
-    (void)block_excl_scan<uint32_t>(heavy, scratch, &any_heavy);
-    if (tid < P) L_.capb[tid] = ((K + extra) << 16) | (tid * K + ex);
-    __syncthreads();                     // scratch (aliases hh) is no longer read
-    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    __syncthreads();
-    // block_excl_scan hands the workgroup totals to every thread: the branch is workgroup-uniform
-    if (total_extra == 0 && any_heavy == 0) {
-        if (K == 1) wc_span<MODE, U, false, 1>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, false, K);
-        else wc_span<MODE, U, false, 0>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, false, K);
-    } else {
-        wc_span<MODE, U, true, 0>(L_, si, keys, pays, nalloc, shift, P, mask_or_n, out_keys, out_pays, any_heavy != 0, K);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // histogram-free ("optimistic") passes
@@ -822,6 +469,7 @@ struct WfLds {
     uint32_t *hh, *line;         // per digit and round parity: (line fill at round start << 16) | arrivals; output position of slot 0
     uint32_t *wlist;             // [16 waves][32] flush work lists
     uint32_t *pc4, *sb;          // pass 2: prefix of 4-tuple units per segment [nseg+1]; segment start | padding
+    uint32_t *lo;                // exact pass: first valid slot of a digit's first line (aliases pc4: never both)
 };
 
 struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slotA + d*slotB, at slot*cap
@@ -836,7 +484,11 @@ struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slot
 //   C  every full line leaves: 8 lanes move one line (two 16-byte LDS reads, a 16-byte store to each column).
 // All LDS traffic of a phase is issued back to back: operations that must not happen are pointed at per-thread
 // trash slots / per-lane trash counters instead of being branched around.
-template <int U, int KFIX, int SRC>
+// EXACT = true: the histogram-backed pass (k_scatter_wc): every digit's output run starts at an exact, arbitrarily
+// aligned position (lo[d] = first valid slot of the run's first line), nothing can overflow, no slot ranges are
+// written.  HEAVY: the span's histogram says one digit holds more than a quarter of it — ranks are taken with the
+// wave-aggregated atomic (same-address LDS atomics serialise per lane).
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
@@ -921,14 +573,15 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             }
         // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
         // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
-        if (tid == 0 && (round & 3u) == 0) L_.wlist[(WC_THREADS / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!EXACT && tid == 0 && (round & 3u) == 0) L_.wlist[(WC_THREADS / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < P) { // the lines flushed last round move this digit's output position
             const uint32_t w = hprev[tid];
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
             if (full) {
                 uint32_t nl = line[tid] + full;
-                if (nl + capS > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
+                if (!EXACT && nl + capS > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
                 line[tid] = nl;
+                if (EXACT) L_.lo[tid] = 0; // only the run's first line starts mid-line
             }
         }
         uint32_t code[U * 4]; // digit << 16 | slot in the digit's lines ; WF_NONE = not a tuple
@@ -938,12 +591,13 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             for (int e = 0; e < 4; e++) {
                 const bool valid = (vm[u] >> e) & 1u;
                 const uint32_t d = ((uint32_t)elem(kv[u], e) >> shift) & mask;
-                const uint32_t old = atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
+                const uint32_t old = HEAVY ? rank_in_digit(h, d, valid)
+                                           : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
         __syncthreads();
         // ---- B ----
-        const uint32_t stop = L_.wlist[(WC_THREADS / 64) * 32];
+        const uint32_t stop = EXACT ? 0u : L_.wlist[(WC_THREADS / 64) * 32];
         uint32_t hw[U * 4];
 #pragma unroll
         for (int j = 0; j < U * 4; j++) hw[j] = h[code[j] != WF_NONE ? code[j] >> 16 : 0u]; // all LDS reads first
@@ -979,7 +633,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
                         if (q < full && q >= capS) {
                             const uint32_t o = line[d] + q;
-                            if (o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
+                            if (EXACT || o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
                             else *ovf = 1u;
                         }
                     }
@@ -1012,8 +666,16 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     const uint32_t gpos = line[ls >> kshift] + (ls & (K - 1)) * WC_LINE + c4;
                     const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
                     const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
-                    *reinterpret_cast<int4 *>(out_keys + gpos) = make_int4(x.x, x.z, y.x, y.z);
-                    *reinterpret_cast<int4 *>(out_pays + gpos) = make_int4(x.y, x.w, y.y, y.w);
+                    const int4 kq = make_int4(x.x, x.z, y.x, y.z), pq = make_int4(x.y, x.w, y.y, y.w);
+                    const uint32_t first_valid = (EXACT && (ls & (K - 1)) == 0) ? L_.lo[ls >> kshift] : 0u;
+                    if (first_valid == 0) {
+                        *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
+                        *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
+                    } else { // the span's first line of this digit starts mid-line: element-wise
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (c4 + e >= first_valid) { out_keys[gpos + e] = elem(kq, e); out_pays[gpos + e] = elem(pq, e); }
+                    }
                 }
             }
         }
@@ -1032,8 +694,9 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
         if (full) {
             uint32_t nl = line[tid] + full;
-            if (nl + capS > my_lim) { *ovf = 1u; nl = my_base; }
+            if (!EXACT && nl + capS > my_lim) { *ovf = 1u; nl = my_base; }
             line[tid] = nl;
+            if (EXACT) L_.lo[tid] = 0;
         }
     }
     __syncthreads();
@@ -1041,13 +704,13 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t s = ln & (WC_LINE - 1);
         const uint32_t w = hlast[d];
         const uint32_t cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
-        if (s < cur) {
+        if (s < cur && (!EXACT || s >= L_.lo[d])) {
             const int2 v = buf[d * capS + s];
             if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = v.x;
             else out_pays[line[d] + s] = v.y;
         }
     }
-    if (tid < P) {
+    if (!EXACT && tid < P) {
         const uint32_t slot = g.slotA + tid * g.slotB;
         const uint32_t w = hlast[tid];
         obeg[slot] = my_base;
@@ -1062,10 +725,58 @@ __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.wlist = L_.line + MAX_PARTS;
     L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32 + 4; // + the "stop" word
     L_.sb = L_.pc4 + WF_MAXSEG + 4;
+    L_.lo = L_.pc4;
 }
-size_t fast_lds_bytes() {
+size_t fast_lds_bytes_impl() {
     return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
            ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4;
+}
+
+// The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
+// digit d starts at g0 (any alignment); the LDS lines of d mirror the 128-byte output lines being filled.
+// Algorithmic traffic: 8 B read + 8 B written per tuple.
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
+                                                           uint64_t nalloc, const uint64_t *__restrict__ sbeg,
+                                                           const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
+                                                           const uint32_t *__restrict__ span_start,
+                                                           uint32_t span, uint32_t shift, uint32_t P,
+                                                           const uint32_t *__restrict__ hist,
+                                                           const uint64_t *__restrict__ chunk_prefix,
+                                                           int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
+                                                           uint64_t n_out, const uint32_t *__restrict__ run_if) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (run_if && !*run_if) return;
+    WfLds L_;
+    wf_carve(L_, smem);
+    SpanInfo si;
+    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
+    const uint64_t L = (uint64_t)span_start[nseg] * P;
+    uint32_t cnt = 0, lo0 = 0;
+    if (tid < P) {
+        const uint64_t idx = (uint64_t)si.first * P + (uint64_t)tid * si.nsp + si.s;
+        const uint64_t g0 = (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG];
+        const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : n_out;
+        cnt = (uint32_t)(g1 - g0);
+        L_.line[tid] = (uint32_t)g0 & ~(uint32_t)(WC_LINE - 1);
+        lo0 = (uint32_t)g0 & (WC_LINE - 1);
+        L_.lo[tid] = lo0;
+    }
+    // a span whose tuples mostly share one digit: same-address LDS atomics would serialise per lane
+    uint32_t any_heavy;
+    const uint32_t heavy = (tid < P && (uint64_t)cnt * 4 > (si.hi - si.lo)) ? 1u : 0u;
+    (void)block_excl_scan<uint32_t>(heavy, scratch, &any_heavy);
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
+    __syncthreads();
+    if (tid < P) L_.hh[tid] = lo0 << 16; // round 0 starts at the fill the run's first line already has
+    __syncthreads();
+    const FastGeom g{0, 0, 0};
+    // block_excl_scan hands the workgroup total to every thread: the branch is workgroup-uniform
+    if (any_heavy) wc_fast<U, 0, 0, true, true>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
+    else if (P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, true, false>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
+    else wc_fast<U, 0, 0, true, false>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
 }
 
 // pass 1: one workgroup per span of the contiguous input
@@ -1584,34 +1295,34 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     return hipGetLastError();
 }
 
-hipError_t set_wc_ablate(uint32_t v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wc_ablate), &v, sizeof v); }
+size_t fast_lds_bytes() { return fast_lds_bytes_impl(); }
 
-size_t scatter_wc_lds_bytes() { return (size_t)WC_LINES * WC_LINE * 4 * 2 + (size_t)MAX_PARTS * 4 * 4 + (size_t)WC_HSTRIDE * 4 * 2 + (WC_THREADS / 64) * 32 * 4; }
-
-template <int MODE, int U>
+template <int U>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
     static bool attr_set[64] = {}; // per device
-    const size_t lds = scatter_wc_lds_bytes();
-    auto fn = k_scatter_wc<MODE, U>;
+    const size_t lds = fast_lds_bytes();
+    auto fn = k_scatter_wc<U>;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_attr_mutex);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
-                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
+                       pa.span_start, pa.span, pa.shift, pa.P, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
                        pa.n_out, pa.run_if);
     return hipGetLastError();
 }
 
 // variant: 0 = 512 threads x 8192-tuple sorted tiles (2 workgroups/CU), 1 = 1024 x 16384 (1/CU),
-//          2 = 512 x 4096, 3 = 1024 x 8192, 4/5 = LDS write-combining lines (k_scatter_wc, 8192/4096 per round)
+//          2 = 512 x 4096, 3 = 1024 x 8192, 4 = LDS write-combining lines (k_scatter_wc; radix digits, power-of-two fan-out)
 hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa) {
-    if (variant == 4) return mode == 0 ? launch_scatter_wc_t<0, 2>(st, pa) : launch_scatter_wc_t<1, 2>(st, pa);
-    if (variant == 5) return mode == 0 ? launch_scatter_wc_t<0, 1>(st, pa) : launch_scatter_wc_t<1, 1>(st, pa);
+    if (variant >= 4 && mode == 0 && (pa.P & (pa.P - 1)) == 0) return launch_scatter_wc_t<2>(st, pa);
+    if (variant >= 4) variant = 1;
     if (mode == 0) {
         switch (variant) {
         case 1: return launch_scatter_t<0, 1024, 4>(st, pa);
