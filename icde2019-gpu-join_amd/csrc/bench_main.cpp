@@ -4,6 +4,10 @@
 //   ./bench -b 7 -a HJC -R <n> -S <m> [-s theta] [--non-unique] [--full-range] [--file -k R.bin -l S.bin]
 //           [-x mult] [-y mult] [-t -v -m -p -w: accepted, echoed, ignored by HJC like the reference]
 //           [--seed N]   (new: reproducible generation; default = time(NULL) like the reference)
+//           [--gpus N]   (new: N > 1 = host level-0 split into N shards, one context + one host thread per GPU,
+//                         independent joins, counts summed — the structure of hjcp.cu:1503-1618 across GPUs)
+//           [--cpu-baseline]  (new: also time a CPU chained-hash join on the same columns, as a reported baseline)
+//           [--json]     (new: one machine-readable line with the counts and timings at the end)
 //
 // Differences by design: `-a` is validated (D8: the reference walks an
 // unterminated table and calls an uninitialised pointer when -a is omitted); the skew cache file
@@ -16,6 +20,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <sys/time.h>
+
+#include <chrono>
+#include <thread>
+#include <vector>
 
 #include "hj.h"
 #include "hj_reference_abi.h"
@@ -40,6 +50,7 @@ struct Input {
     int R_mult = 1, S_mult = 1;
     const char *R_file = nullptr, *S_file = nullptr;
     uint64_t seed = 0;
+    int gpus = 1, json = 0, cpu_baseline = 0;
 };
 
 [[noreturn]] void usage_exit() { // main.cu:68-73
@@ -54,6 +65,9 @@ void parse(int argc, char **argv, Input *in) {
                                    {"non-unique", no_argument, nullptr, 1001},
                                    {"full-range", no_argument, nullptr, 1002},
                                    {"seed", required_argument, nullptr, 1003},
+                                   {"gpus", required_argument, nullptr, 1004},
+                                   {"json", no_argument, nullptr, 1005},
+                                   {"cpu-baseline", no_argument, nullptr, 1006},
                                    {"benchmark", required_argument, nullptr, 'b'},
                                    {"alg", required_argument, nullptr, 'a'},
                                    {"SelsNum", required_argument, nullptr, 'S'},
@@ -77,6 +91,9 @@ void parse(int argc, char **argv, Input *in) {
         case 1001: unique_flag = 0; printf("non-unique\t"); break;
         case 1002: range_flag = 1; printf("full-range\t"); break;
         case 1003: in->seed = strtoull(optarg, nullptr, 10); printf("seed = %lu\t", (unsigned long)in->seed); break;
+        case 1004: in->gpus = atoi(optarg); printf("gpus = %d\t", in->gpus); break;
+        case 1005: in->json = 1; printf("json\t"); break;
+        case 1006: in->cpu_baseline = 1; printf("cpu-baseline\t"); break;
         case 'b': in->option = atoi(optarg); printf("option = %d\t", in->option); break;
         case 'a':
             for (const JoinAlg *a = kAlgs; a->name; a++)
@@ -114,7 +131,91 @@ void parse(int argc, char **argv, Input *in) {
     printf("\n");
     // main.cu:556 accepts 1..9,100,101 and then rejects everything but 7/8 in main's switch
     if (in->option != 7 && in->option != 8) usage_exit();
-    if (in->R_mult < 1 || in->S_mult < 1) usage_exit();
+    if (in->R_mult < 1 || in->S_mult < 1 || in->gpus < 1 || in->gpus > 64) usage_exit();
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// --cpu-baseline: a non-partitioned chained hash join on the host, the shape of the reference's (never called)
+// joinCpu (hjcp.cu:2013-2059: murmur3 finaliser, LIFO chains, serial build, parallel probe) with the table sized to
+// the build side instead of a fixed 2^20 slots.  A reported baseline next to the GPU numbers, never a fallback.
+struct CpuJoin { unsigned long long matches = 0; double seconds = 0; unsigned threads = 0; };
+inline uint32_t murmur_fin(uint32_t x) { x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; return x; }
+CpuJoin cpu_join(const int32_t *R, uint64_t nR, const int32_t *S, uint64_t nS) {
+    CpuJoin out;
+    uint32_t lg = 10;
+    while (((uint64_t)1 << lg) < nR && lg < 31) lg++;
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << lg) - 1);
+    const double t0 = now_s();
+    std::vector<int64_t> head((size_t)mask + 1, -1), next(nR ? nR : 1);
+    for (uint64_t j = 0; j < nR; j++) { const uint32_t b = murmur_fin((uint32_t)R[j]) & mask; next[j] = head[b]; head[b] = (int64_t)j; }
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // containers: honour the CPU quota
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long cpus = (atol(q) + period - 1) / period;
+            if (cpus >= 1 && (unsigned long)cpus < nt) nt = (unsigned)cpus;
+        }
+        fclose(f);
+    }
+    std::vector<unsigned long long> part(nt, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            unsigned long long m = 0;
+            for (uint64_t j = nS * t / nt; j < nS * (t + 1) / nt; j++) {
+                const int32_t key = S[j];
+                for (int64_t cur = head[murmur_fin((uint32_t)key) & mask]; cur >= 0; cur = next[cur]) m += R[cur] == key;
+            }
+            part[t] = m;
+        });
+    for (auto &x : th) x.join();
+    for (auto m : part) out.matches += m;
+    out.seconds = now_s() - t0;
+    out.threads = nt;
+    return out;
+}
+
+// --gpus N (N > 1): the reference joins level-0 partitions independently (hjcp.cu:1503-1618); here each of N GPUs gets
+// one level-0 shard of R and S (host split, hj_host_split), its own context and host thread, and the counts add up.
+struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0, split_gbs = 0; int status = 0; };
+MultiResult multi_gpu_join(const args &ja, int gpus) {
+    MultiResult out;
+    std::vector<int32_t> rk(ja.R_els + 32), sk(ja.S_els + 32);
+    std::vector<uint64_t> roff(gpus + 1), soff(gpus + 1);
+    double g1 = 0, g2 = 0;
+    int32_t *rka = rk.data() + ((64 - ((uintptr_t)rk.data() & 63)) & 63) / 4, *ska = sk.data() + ((64 - ((uintptr_t)sk.data() & 63)) & 63) / 4;
+    if (hj_host_split(ja.R, nullptr, ja.R_els, (uint32_t)gpus, 0, rka, nullptr, roff.data(), &g1) ||
+        hj_host_split(ja.S, nullptr, ja.S_els, (uint32_t)gpus, 0, ska, nullptr, soff.data(), &g2)) { out.status = -1; return out; }
+    out.split_gbs = (g1 + g2) / 2;
+    std::vector<unsigned long long> m(gpus, 0), a(gpus, 0);
+    std::vector<int> rc(gpus, 0);
+    std::vector<hj_ctx *> ctx(gpus, nullptr);
+    for (int g = 0; g < gpus; g++) { // untimed: contexts and H2D, like the reference (hjcp.cu:874-879)
+        rc[g] = hj_create(&ctx[g], g);
+        if (!rc[g]) rc[g] = hj_load_host(ctx[g], HJ_REL_R, rka + roff[g], nullptr, roff[g + 1] - roff[g], HJ_PAYLOAD_ONES);
+        if (!rc[g]) rc[g] = hj_load_host(ctx[g], HJ_REL_S, ska + soff[g], nullptr, soff[g + 1] - soff[g], HJ_PAYLOAD_ONES);
+        if (rc[g]) fprintf(stderr, "GPU Error: device %d: %s (code %d)\n", g, ctx[g] ? hj_error(ctx[g]) : "hj_create failed", rc[g]);
+    }
+    const double t0 = now_s();
+    std::vector<std::thread> th;
+    for (int g = 0; g < gpus; g++)
+        th.emplace_back([&, g] {
+            if (rc[g]) return;
+            uint64_t mm = 0, aa = 0;
+            rc[g] = hj_join(ctx[g], &mm, &aa);
+            m[g] = mm; a[g] = aa;
+        });
+    for (auto &x : th) x.join();
+    out.seconds = now_s() - t0;
+    for (int g = 0; g < gpus; g++) {
+        if (rc[g]) out.status = rc[g];
+        out.matches += m[g]; out.agg += a[g];
+        if (ctx[g]) hj_destroy(ctx[g]);
+    }
+    return out;
 }
 
 int32_t *alloc_col(uint64_t n, bool *pinned) {
@@ -231,6 +332,22 @@ int main(int argc, char **argv) {
     if (rc) { fprintf(stderr, "ERROR: relation generation failed\n"); return 1; }
 
     int status = 0;
+    hj_last_result res;
+    memset(&res, 0, sizeof res);
+    MultiResult multi;
+    if (in.option == 7 && in.gpus > 1) {
+        printf("%s : %d GPUs, one level-0 shard each\n", in.alg->name, in.gpus);
+        fflush(stdout);
+        multi = multi_gpu_join(ja, in.gpus);
+        status = multi.status ? 10 : 0;
+        if (!multi.status) {
+            const double bytes = 2.0 * (double)(ja.R_els + ja.S_els) * sizeof(int);
+            printf("Host split Throughput %.1f GB/s\n", multi.split_gbs);
+            printf("Total Throughput (%d GPUs) %f\n", in.gpus, bytes / multi.seconds / 1000 / 1000);
+            printf("%llu results\n", multi.agg);
+        }
+        res.matches = multi.matches; res.agg = multi.agg; res.status = multi.status; res.join_ms[1] = multi.seconds * 1e3;
+    } else
     if (in.option == 7) { // main.cu:264-298
         ja.sharedMem = (unsigned)in.shared_mem;
         ja.threadsNum = in.threads;
@@ -243,9 +360,24 @@ int main(int argc, char **argv) {
         gettimeofday(&time.start[time.n - 1], nullptr);
         in.alg->fn(&ja, &time);
         gettimeofday(&time.end[time.n - 1], nullptr);
-        hj_last_result res;
         hj_reference_last_result(&res);
         status = res.status ? 10 : 0; // CHK_ERROR's print-and-exit (common.h:132-141) lives here, not in the library
+    }
+    CpuJoin cpu;
+    if (in.option == 7 && in.cpu_baseline) {
+        cpu = cpu_join(ja.R, ja.R_els, ja.S, ja.S_els);
+        printf("CPU baseline (chained hash join, %u threads): %.3f s, %.1f Mtuples/s, %llu results%s\n", cpu.threads, cpu.seconds,
+               (double)(ja.R_els + ja.S_els) / cpu.seconds / 1e6, cpu.matches,
+               (!status && cpu.matches != res.matches) ? "  ** differs from the GPU count **" : "");
+        if (!status && cpu.matches != res.matches) status = 11;
+    }
+    if (in.option == 7 && in.json) {
+        printf("{\"alg\": \"%s\", \"R\": %lu, \"S\": %lu, \"gpus\": %d, \"status\": %d, \"matches\": %llu, \"agg\": %llu, "
+               "\"materialized\": %llu, \"partition_ms\": [%.3f, %.3f], \"join_ms\": [%.3f, %.3f]",
+               in.alg->name, (unsigned long)ja.R_els, (unsigned long)ja.S_els, in.gpus, res.status, res.matches, res.agg, res.materialized,
+               res.partition_ms[0], res.partition_ms[1], res.join_ms[0], res.join_ms[1]);
+        if (in.cpu_baseline) printf(", \"cpu_baseline\": {\"seconds\": %.4f, \"threads\": %u, \"matches\": %llu}", cpu.seconds, cpu.threads, cpu.matches);
+        printf("}\n");
     }
     if (pin_r) (void)hipHostFree(ja.R); else free(ja.R);
     if (pin_s) (void)hipHostFree(ja.S); else free(ja.S);

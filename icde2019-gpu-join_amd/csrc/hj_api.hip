@@ -10,7 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -86,6 +89,12 @@ struct hj_ctx {
     uint64_t *h_shard_off = nullptr;
     Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
     Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
+    int32_t *host_k[2] = {nullptr, nullptr}, *host_p[2] = {nullptr, nullptr}; // pinned staging of the host split (R, S): kept across calls
+    size_t host_cap[2] = {0, 0};    // elements
+    double host_split_gbs = 0;      // throughput of the last host level-0 split (bytes read + written per second)
+    Buf out_k[2], out_p1[2], out_p2[2]; // streamed materialisation: double-buffered device output columns
+    hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
+    hipEvent_t out_ready[2] = {}, out_free[2] = {};
     hipEvent_t seg_ready[2] = {};
     // timing
     int events = 1;                 // 0 none, 1 main kernels (hist / scatter / join), 2 every launch (HJ_KERNEL_EVENTS)
@@ -576,6 +585,14 @@ int hj_destroy(hj_ctx *c) {
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
     if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->d2h) (void)hipStreamDestroy(c->d2h);
+    for (int i = 0; i < 2; i++) {
+        release(c->out_k[i]); release(c->out_p1[i]); release(c->out_p2[i]);
+        if (c->out_ready[i]) (void)hipEventDestroy(c->out_ready[i]);
+        if (c->out_free[i]) (void)hipEventDestroy(c->out_free[i]);
+        if (c->host_k[i]) (void)hipHostFree(c->host_k[i]);
+        if (c->host_p[i]) (void)hipHostFree(c->host_p[i]);
+    }
     release(c->shard_root); release(c->shard_off);
     if (c->h_shard_off) (void)hipHostFree(c->h_shard_off);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
@@ -808,8 +825,15 @@ int hj_join_nonpartitioned(hj_ctx *c, int kind, uint64_t *matches, uint64_t *agg
     return HJ_OK;
 }
 
-int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64_t n, uint64_t segment_tuples,
-                         int payload_mode, uint64_t *matches, uint64_t *agg) {
+} // extern "C"
+
+namespace {
+
+// S streamed from host memory against a resident R (outOfGPU_Join3_payload, hjcp.cu:1684-1984).  With output columns
+// (h_out != nullptr) every segment's join also materialises (key,payR,payS) into double-buffered device columns that a
+// third stream copies back to the host while the next segment is partitioned and joined (hjcp.cu:1917-1961).
+int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64_t n, uint64_t segment_tuples,
+                 int payload_mode, uint64_t *matches, uint64_t *agg, int32_t *const h_out[3], uint64_t out_cap) {
     if (!c) return HJ_EINVAL;
     if (n && !h_keys) return fail(c, HJ_EINVAL, "keys == NULL");
     if (payload_mode == HJ_PAYLOAD_GIVEN && n && !h_pays) return fail(c, HJ_EINVAL, "payload_mode GIVEN needs a payload column");
@@ -828,6 +852,14 @@ int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays
         RET(ensure(c, c->seg_k[i], (size_t)(seg + PAD) * 4));
         RET(ensure(c, c->seg_p[i], (size_t)(seg + PAD) * 4));
     }
+    if (h_out) {
+        if (!c->d2h) HIPCHK(c, hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            if (!c->out_ready[i]) HIPCHK(c, hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming));
+            if (!c->out_free[i]) HIPCHK(c, hipEventCreateWithFlags(&c->out_free[i], hipEventDisableTiming));
+        }
+    }
+    bool out_used[2] = {false, false};
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
@@ -867,10 +899,37 @@ int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays
         if ((rc = partition_rel(c, HJ_REL_S))) break;
         uint64_t m = 0, a = 0;
         if ((rc = hj_join_count(c, &m, &a))) break; // [sync]: the next copy is already in flight
+        if (h_out && m) {
+            // the device output buffers of this parity were last read by the D2H copies of segment i-2
+            if (out_used[b] && hipStreamWaitEvent(c->stream, c->out_free[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
+            if ((rc = ensure(c, c->out_k[b], (size_t)(m + PAD) * 4)) || (rc = ensure(c, c->out_p1[b], (size_t)(m + PAD) * 4)) ||
+                (rc = ensure(c, c->out_p2[b], (size_t)(m + PAD) * 4))) break;
+            JoinArgs ja = c->last_args; // item list + scanned per-wave counts of this segment are on the device
+            ja.wave_scanned = (const uint64_t *)c->wave_counts.p;
+            ja.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
+            ja.out_key = (int32_t *)c->out_k[b].p;
+            ja.out_bpay = (int32_t *)c->out_p1[b].p; // R builds: build payload = payR
+            ja.out_ppay = (int32_t *)c->out_p2[b].p;
+            ja.out_cap = m;
+            { Timed t(c, "k_join_materialize");
+              if (launch_join(c->stream, ja, c->max_items, c->last_tag16, 1) != hipSuccess) { rc = fail(c, HJ_EHIP, "materialise launch"); break; } }
+            c->join_planned = false;
+            if (hipEventRecord(c->out_ready[b], c->stream) != hipSuccess || hipStreamWaitEvent(c->d2h, c->out_ready[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); break; }
+            const uint64_t room = tot_m < out_cap ? out_cap - tot_m : 0, take = m < room ? m : room;
+            if (take) {
+                const void *src[3] = {c->out_k[b].p, c->out_p1[b].p, c->out_p2[b].p};
+                for (int q = 0; q < 3 && !rc; q++)
+                    if (hipMemcpyAsync(h_out[q] + tot_m, src[q], take * 4, hipMemcpyDeviceToHost, c->d2h) != hipSuccess) rc = fail(c, HJ_EHIP, "D2H of the output");
+                if (rc) break;
+            }
+            if (hipEventRecord(c->out_free[b], c->d2h) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); break; }
+            out_used[b] = true;
+        }
         tot_m += m; tot_a += a;
     }
     // on every exit path: the H2D copy of the next segment may still be reading the caller's columns
     (void)hipStreamSynchronize(c->copy);
+    if (c->d2h) (void)hipStreamSynchronize(c->d2h);
     c->force_build_r = saved_force;
     c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation: S is unbound afterwards (hj.h)
     c->rel[HJ_REL_S].n = 0;
@@ -878,14 +937,82 @@ int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays
     if (rc) return rc;
     if (matches) *matches = tot_m;
     if (agg) *agg = tot_a;
+    if (h_out && tot_m > out_cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu",
+                                              (unsigned long long)tot_m, (unsigned long long)out_cap);
     return HJ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hj_join_stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64_t n, uint64_t segment_tuples,
+                         int payload_mode, uint64_t *matches, uint64_t *agg) {
+    return stream_probe(c, h_keys, h_pays, n, segment_tuples, payload_mode, matches, agg, nullptr, 0);
+}
+
+int hj_join_stream_probe_materialize(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64_t n, uint64_t segment_tuples,
+                                     int payload_mode, int32_t *h_out_key, int32_t *h_out_payR, int32_t *h_out_payS,
+                                     uint64_t cap, uint64_t *n_out, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    if (cap && (!h_out_key || !h_out_payR || !h_out_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
+    int32_t *const out[3] = {h_out_key, h_out_payR, h_out_payS};
+    return stream_probe(c, h_keys, h_pays, n, segment_tuples, payload_mode, n_out, agg, out, cap);
 }
 
 namespace {
 
-// Host-side level-0 radix split (the role of partitions_host_omp_nontemporal_payload,
-// partition-primitives.cu:40-125, and partition_prepare/do_payload :129-232): per-thread histograms over
-// contiguous chunks, prefix, scatter.  Partition id = hj_shard_of(key, parts) (hash: balanced for dense keys).
+// Host-side level-0 split (the role of partitions_host_omp_nontemporal_payload, partition-primitives.cu:40-125, and
+// partition_prepare/do_payload :129-232): per-thread histograms over contiguous chunks, prefix, then a scatter through
+// per-thread SOFTWARE WRITE-COMBINING buffers — one 64-byte line of keys and one of payloads per partition, mirroring
+// the 64-byte-aligned destination line being filled — flushed with non-temporal AVX2 stores, so the output lines are
+// never read into the cache (the reference's scheme; it keeps 256-tuple batches per partition, LOG_BATCH, and assumes
+// aligned outputs; here a run may start anywhere: its first line is written with plain stores).
+// Partition id = hj_shard_of(key, parts) (hash: balanced for dense keys).
+constexpr uint32_t HWC = 16; // tuples per 64-byte line
+
+__attribute__((target("avx2"))) void wc_flush_line(int32_t *dst, const int32_t *src) {
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), _mm256_load_si256(reinterpret_cast<const __m256i *>(src)));
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 8), _mm256_load_si256(reinterpret_cast<const __m256i *>(src + 8)));
+}
+
+__attribute__((target("avx2"))) void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
+                                                      const uint64_t *start, int32_t *oK, int32_t *oP, bool stream) {
+    // line[p]: 64-byte-aligned output position of the line being filled; fill[p]: next slot; first[p]: first valid slot
+    std::vector<uint64_t> line(parts);
+    std::vector<uint8_t> fill(parts), first(parts);
+    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4);
+    for (uint32_t p = 0; p < parts; p++) {
+        line[p] = start[p] & ~(uint64_t)(HWC - 1);
+        fill[p] = first[p] = (uint8_t)(start[p] & (HWC - 1));
+    }
+    for (uint64_t i = lo; i < hi; i++) {
+        const int32_t key = K[i];
+        const uint32_t p = host_shard_of(key, parts);
+        uint32_t s = fill[p];
+        bufK[p * HWC + s] = key;
+        if (oP) bufP[p * HWC + s] = Pv ? Pv[i] : 1;
+        if (++s == HWC) { // the line is complete: it leaves with streaming stores (no read-for-ownership of the destination)
+            const uint64_t o = line[p];
+            if (first[p] == 0 && stream) {
+                wc_flush_line(oK + o, bufK + p * HWC);
+                if (oP) wc_flush_line(oP + o, bufP + p * HWC);
+            } else {
+                for (uint32_t j = first[p]; j < HWC; j++) { oK[o + j] = bufK[p * HWC + j]; if (oP) oP[o + j] = bufP[p * HWC + j]; }
+                first[p] = 0;
+            }
+            line[p] = o + HWC;
+            s = 0;
+        }
+        fill[p] = (uint8_t)s;
+    }
+    for (uint32_t p = 0; p < parts; p++) // half-full lines
+        for (uint32_t j = first[p]; j < fill[p]; j++) { oK[line[p] + j] = bufK[p * HWC + j]; if (oP) oP[line[p] + j] = bufP[p * HWC + j]; }
+    _mm_sfence();
+    free(bufK);
+    free(bufP);
+}
+
 void host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
                        int32_t *oK, int32_t *oP, std::vector<uint64_t> &off) {
     if (threads < 1) threads = 1;
@@ -907,15 +1034,13 @@ void host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
         for (uint32_t t = 0; t < threads; t++) { uint64_t cnt = hist[(size_t)t * parts + p]; hist[(size_t)t * parts + p] = sum; sum += cnt; }
     }
     off[parts] = sum;
+    // 64-byte streaming stores need 64-byte-aligned columns (pinned staging is page-aligned); two threads may share the
+    // destination line where their runs of a partition meet: both write their own slots with plain stores (first/last line)
+    const bool stream = (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
     for (uint32_t t = 0; t < threads; t++)
         th.emplace_back([&, t] {
             uint64_t lo, hi; chunk(t, lo, hi);
-            uint64_t *h = hist.data() + (size_t)t * parts;
-            for (uint64_t i = lo; i < hi; i++) {
-                uint64_t d = h[host_shard_of(K[i], parts)]++;
-                oK[d] = K[i];
-                if (oP) oP[d] = Pv ? Pv[i] : 1;
-            }
+            wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream);
         });
     for (auto &x : th) x.join();
 }
@@ -948,18 +1073,33 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    // host split; the partitioned copies are pinned so that the uploads are asynchronous
+    // host split; the partitioned copies are pinned so that the uploads are asynchronous.  The staging buffers belong
+    // to the context and only ever grow: a caller that joins in a loop pins host memory once.
     int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
     const uint64_t nn[2] = {nR, nS};
     const int32_t *srcK[2] = {h_R, h_S}, *srcP[2] = {h_Pr, h_Ps};
     std::vector<uint64_t> off[2];
     int rc = 0;
+    const auto t_split0 = std::chrono::steady_clock::now();
     for (int r = 0; r < 2 && !rc; r++) {
-        if (hipHostMalloc((void **)&pk[r], (size_t)(nn[r] + 4) * 4, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&pp[r], (size_t)(nn[r] + 4) * 4, hipHostMallocDefault) != hipSuccess)
-            rc = fail(c, HJ_ENOMEM, "pinned host buffers for the level-0 split");
-        else
+        if (c->host_cap[r] < nn[r] + 16) {
+            if (c->host_k[r]) (void)hipHostFree(c->host_k[r]);
+            if (c->host_p[r]) (void)hipHostFree(c->host_p[r]);
+            c->host_k[r] = c->host_p[r] = nullptr; c->host_cap[r] = 0;
+            if (hipHostMalloc((void **)&c->host_k[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&c->host_p[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess)
+                rc = fail(c, HJ_ENOMEM, "pinned host buffers for the level-0 split");
+            else c->host_cap[r] = nn[r] + 16;
+        }
+        if (!rc) {
+            pk[r] = c->host_k[r]; pp[r] = c->host_p[r];
             host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r]);
+        }
+    }
+    {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split0).count();
+        // bytes read + written by the scatter (keys + payloads), like partition-primitives.cu:218
+        c->host_split_gbs = dt > 0 ? 16.0 * (double)(nR + nS) / dt / 1e9 : 0;
     }
     uint64_t maxp[2] = {0, 0};
     if (!rc)
@@ -998,12 +1138,30 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         tot_m += m; tot_a += a;
     }
     (void)hipStreamSynchronize(c->copy);
-    for (int r = 0; r < 2; r++) { if (pk[r]) (void)hipHostFree(pk[r]); if (pp[r]) (void)hipHostFree(pp[r]); }
     c->rel[0].bound = c->rel[1].bound = false; // the staging buffers are not user relations
     invalidate(c);
     if (rc) return rc;
     if (matches) *matches = tot_m;
     if (agg) *agg = tot_a;
+    return HJ_OK;
+}
+
+int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads, int32_t *out_keys,
+                  int32_t *out_pays, uint64_t *offsets, double *gbs) {
+    if ((n && (!keys || !out_keys)) || !offsets || parts == 0 || parts > 4096) return HJ_EINVAL;
+    if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::vector<uint64_t> off;
+    const auto t0 = std::chrono::steady_clock::now();
+    host_level0_split(keys, pays, n, parts, threads, out_keys, out_pays, off);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t p = 0; p <= parts; p++) offsets[p] = off[p];
+    if (gbs) *gbs = dt > 0 ? (out_pays ? 16.0 : 8.0) * (double)n / dt / 1e9 : 0;
+    return HJ_OK;
+}
+
+int hj_host_split_throughput(const hj_ctx *c, double *gbs) {
+    if (!c || !gbs) return HJ_EINVAL;
+    *gbs = c->host_split_gbs;
     return HJ_OK;
 }
 

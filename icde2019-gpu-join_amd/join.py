@@ -156,6 +156,24 @@ class HashJoin:
         self._ck(self._L.hj_join_stream_probe(self._h, kp, pp, len(S), segment_tuples, mode, C.byref(m), C.byref(a)))
         return m.value, a.value
 
+    def join_stream_probe_materialize(self, S, Ps=None, payload="ones", segment_tuples=0, cap=None, out=None):
+        """Streaming probe side with materialisation (hjcp.cu:1917-1961): returns host columns (key, payR, payS).
+        out = three preallocated host int32 arrays (e.g. views of pinned torch tensors) of at least cap elements."""
+        S, kp = _host_i32(S)
+        mode = _PAYLOAD[payload] if Ps is None else PAYLOAD_GIVEN
+        pp = None
+        if Ps is not None:
+            Ps, pp = _host_i32(Ps)
+        if cap is None:
+            cap = self.join_stream_probe(S, Ps, payload, segment_tuples)[0]
+        if out is None:
+            out = [np.empty(max(cap, 1), np.int32) for _ in range(3)]
+        n, a = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.hj_join_stream_probe_materialize(self._h, kp, pp, len(S), segment_tuples, mode,
+                                                          out[0].ctypes.data_as(C.c_void_p), out[1].ctypes.data_as(C.c_void_p),
+                                                          out[2].ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(a)))
+        return tuple(o[:n.value] for o in out), a.value
+
     def join_coprocess(self, R, Pr, S, Ps, level0_parts=0, host_threads=0):
         """Both relations host-resident: host level-0 split + per-partition GPU joins (hjcp.cu:1000-1680)."""
         R, rk = _host_i32(R)
@@ -169,6 +187,11 @@ class HashJoin:
         self._ck(self._L.hj_join_coprocess(self._h, rk, rp, len(R), sk, sp, len(S), level0_parts, host_threads,
                                            C.byref(m), C.byref(a)))
         return m.value, a.value
+
+    def host_split_throughput(self):
+        v = C.c_double()
+        self._ck(self._L.hj_host_split_throughput(self._h, C.byref(v)))
+        return v.value
 
     def join_materialize_into(self, d_key, d_payR, d_payS, cap):
         n = C.c_uint64()
@@ -278,6 +301,27 @@ class HashJoin:
         d = C.c_uint64()
         self._ck(self._L.hj_digest_triples(self._h, _dev_ptr(d_key), _dev_ptr(d_pr), _dev_ptr(d_ps), n, C.byref(d)))
         return d.value
+
+
+def host_split(keys, pays, parts, threads=0):
+    """The host level-0 split on its own (no GPU): (out_keys, out_pays, offsets[parts+1], GB/s)."""
+    keys, kp = _host_i32(keys)
+    pp = None
+    if pays is not None:
+        pays, pp = _host_i32(pays)
+    ok, op = np.empty(len(keys) + 16, np.int32), np.empty(len(keys) + 16, np.int32)
+    # 64-byte-aligned views so that the non-temporal line stores are taken
+    def aligned(a):
+        sh = (-a.ctypes.data) % 64 // 4
+        return a[sh:sh + len(keys)]
+    ok, op = aligned(ok), aligned(op)
+    off = np.zeros(parts + 1, np.uint64)
+    gbs = C.c_double()
+    rc = _lib.lib().hj_host_split(kp, pp, len(keys), parts, threads, ok.ctypes.data_as(C.c_void_p), op.ctypes.data_as(C.c_void_p),
+                                  off.ctypes.data_as(_lib.u64p), C.byref(gbs))
+    if rc:
+        raise HJError(rc, "hj_host_split")
+    return ok, op, off, gbs.value
 
 
 def shard_of(key, nshards):

@@ -133,6 +133,15 @@ int hj_join_nonpartitioned(hj_ctx *ctx, int kind, uint64_t *matches, uint64_t *a
 int hj_join_stream_probe(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pays, uint64_t n,
                          uint64_t segment_tuples, int payload_mode, uint64_t *matches, uint64_t *agg);
 
+/* The same with materialisation, as the reference's Join3 does it (join_partitioned_results per segment, then a copy of
+ * the segment's output to the host on a third stream, hjcp.cu:1917-1961): every segment's (key,payR,payS) tuples are
+ * written to double-buffered HBM columns and copied into the caller's HOST columns (pinned memory makes the copies
+ * asynchronous) while the next segment is partitioned and joined.  cap = capacity of each host column in tuples;
+ * *n_out = tuples produced; HJ_ECAPACITY if n_out > cap (nothing beyond cap is written).  [sync] */
+int hj_join_stream_probe_materialize(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pays, uint64_t n,
+                                     uint64_t segment_tuples, int payload_mode, int32_t *h_out_key, int32_t *h_out_payR,
+                                     int32_t *h_out_payS, uint64_t cap, uint64_t *n_out, uint64_t *agg);
+
 /* ---- CPU-GPU co-processing (outOfGPU_Join2_payload, hjcp.cu:1000-1680): BOTH relations stay in host
  *      memory.  The host splits them into level0_parts partitions on host_threads threads (16 and 16 in the
  *      reference, hjcp.cu:1256-1266, pp.cuh:38-39; 0 = those defaults / all cores up to 64); each partition
@@ -141,6 +150,16 @@ int hj_join_stream_probe(hj_ctx *ctx, const int32_t *h_keys, const int32_t *h_pa
 int hj_join_coprocess(hj_ctx *ctx, const int32_t *h_R, const int32_t *h_Pr, uint64_t nR, const int32_t *h_S,
                       const int32_t *h_Ps, uint64_t nS, uint32_t level0_parts, uint32_t host_threads,
                       uint64_t *matches, uint64_t *agg);
+
+/* The host level-0 split on its own (partitions_host_omp_nontemporal_payload, partition-primitives.cu:40-125, with
+ * partition_prepare/do_payload :129-232): per-thread histograms, prefix, scatter through per-thread software
+ * write-combining lines flushed with non-temporal AVX2 stores.  Partition of a key = hj_shard_of(key, parts).
+ * offsets[parts+1]; out_pays may be NULL (keys only); pays may be NULL (= ones).  *gbs = bytes read + written per
+ * second by the whole split (the reference prints its partition throughput, pp.cu:218).  No GPU involved. */
+int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
+                  int32_t *out_keys, int32_t *out_pays, uint64_t *offsets, double *gbs);
+/* GB/s of the host split inside the last hj_join_coprocess call of this context. */
+int hj_host_split_throughput(const hj_ctx *ctx, double *gbs);
 
 /* ---- plain device-memory helpers for callers without a HIP runtime binding of their own ---- */
 int hj_device_malloc(hj_ctx *ctx, void **d_ptr, uint64_t bytes);

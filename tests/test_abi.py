@@ -85,3 +85,52 @@ def test_c_client_on_gpu(tmp_path):
     r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_abi_client ok: 150000 matches" in r.stdout
+
+
+def test_host_write_combining_split_parity():
+    """hj_host_split (the co-processing path's host level-0 partitioner: per-thread software write-combining lines,
+    non-temporal AVX2 stores — partition-primitives.cu:40-125,129-232) against numpy: offsets, and per partition the
+    exact (key,payload) multiset.  Pure host code: runs without a GPU."""
+    import numpy as np
+    p = pkg()
+    rng = np.random.default_rng(17)
+    for n, parts, threads in ((0, 4, 2), (1, 1, 1), (15, 16, 3), (1000, 7, 4), (100_003, 16, 8), (250_000, 64, 5), (60_000, 1000, 2)):
+        keys = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+        keys[: n // 3] = rng.integers(0, 40, n // 3)            # a skewed third
+        pays = np.arange(n, dtype=np.int32)
+        ok, op, off, gbs = p.host_split(keys, pays, parts, threads)
+        owner = np.array([p.shard_of(int(k), parts) for k in keys], dtype=np.int64) if n else np.empty(0, np.int64)
+        cnt = np.bincount(owner, minlength=parts)
+        assert off[0] == 0 and np.array_equal(np.diff(off.astype(np.int64)), cnt)
+        assert np.array_equal(keys[op], ok)                         # payload travels with its key
+        assert sorted(op.tolist()) == list(range(n))                # a permutation: nothing lost, nothing duplicated
+        for q in range(parts):
+            seg = op[int(off[q]):int(off[q + 1])]
+            assert np.all(owner[seg] == q)
+        # keys-only / payload = ones variants
+        ok2, op2, off2, _ = p.host_split(keys, None, parts, threads)
+        assert np.array_equal(off2, off) and np.all(op2 == 1) and np.array_equal(np.sort(ok2), np.sort(keys))
+
+
+def test_timinginfo_layout_matches_reference(tmp_path):
+    """struct timingInfo (src/common.h:101-119): unsigned n; timeval start[5], end[5]; 8 doubles; 4 unsigned counters.
+    Offsets on x86-64 (timeval = 16 bytes): the header a maintainer links against must agree field by field."""
+    import subprocess
+    fields = ["n", "start", "end", "greaterTime", "reduce_usecs", "fixPositions_usecs", "scatter_usecs", "copy_usecs",
+              "bitonic_usecs", "total_usecs", "greaterEventTime", "greaterCallsNum", "bitonicCallsNum", "reduceCallsNum",
+              "fixPositionsCallsNum"]
+    expect = [0, 8, 88, 168, 176, 184, 192, 200, 208, 216, 224, 232, 236, 240, 244]
+    src = tmp_path / "ti.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hj_reference_abi.h"\nint main(void){\n' +
+                   "".join('printf("%%zu\\n", offsetof(timingInfo, %s));\n' % f for f in fields) +
+                   'printf("%zu\\n", sizeof(timingInfo)); printf("%zu\\n", sizeof(args)); return 0; }\n')
+    exe = tmp_path / "ti"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[:-2] == expect and got[-2] == 248 and got[-1] == 152
+    ref = "/root/reference/src/common.h"
+    if os.path.exists(ref):   # build container: the reference's own declaration order, field by field
+        text = open(ref).read()
+        body = text[text.index("typedef struct timingInfo {"):text.index("} timingInfo;")]
+        names = re.findall(r"\b(\w+)(?:\[5\])?(?:\s*=\s*\d+)?;", body)
+        assert names == fields, names

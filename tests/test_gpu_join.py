@@ -297,6 +297,28 @@ def test_bench_cli_join(P, tmp_path):
     assert "%d results" % (200000 - (200000 - 1) // 65536) in r.stdout
 
 
+def test_bench_cli_json_cpu_baseline_gpus(P, tmp_path):
+    """The flags SURVEY §8(b) adds beside main.cu:445-457: --json, --cpu-baseline, --gpus N."""
+    import json
+    import subprocess
+    import torch
+    expect = 200000 - (200000 - 1) // 65536
+    base = [P._lib.BENCH_PATH, "-b", "7", "-a", "HJC", "-R", "65536", "-S", "200000", "--seed", "3"]
+    r = subprocess.run(base + ["--json", "--cpu-baseline"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "%d results" % expect in r.stdout and "CPU baseline (chained hash join" in r.stdout
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["status"] == 0 and line["matches"] == line["materialized"] == expect and line["gpus"] == 1
+    assert line["cpu_baseline"]["matches"] == expect
+    r = subprocess.run(base + ["--json", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["matches"] == expect and line["gpus"] == 2 and "Total Throughput (2 GPUs)" in r.stdout
+    else:
+        assert r.returncode != 0 and "GPU Error" in r.stderr     # one device only: fails loudly, no fallback
+
+
 # ---- BASELINE sizes through size-independent properties --------------------------------------------------
 def test_config2_single_pass_as_stated(P):
     """BASELINE config 2 as stated: 2^27 x 2^27, ONE radix pass of 9 bits (2^18-tuple partitions, far beyond the
@@ -384,6 +406,34 @@ def test_stream_probe_segments(P, seg):
         # the resident path still works afterwards and agrees
         hj.load_host(P.REL_S, S, Ps)
         assert hj.join() == (em, eagg)
+
+
+@pytest.mark.parametrize("seg", [0, 7000, 60_000])
+def test_stream_probe_materialize(P, seg):
+    """Join3 with its materialisation: per segment join_partitioned_results + copy of the output to the host on a
+    third stream (hjcp.cu:1917-1961).  The multiset of (key,payR,payS) over all segments must equal the oracle's."""
+    rng = np.random.default_rng(78)
+    nR, nS = 30_000, 200_003
+    R = rng.integers(0, 25_000, nR).astype(np.int32)                 # duplicates on the build side too
+    S = rng.integers(-100, 26_000, nS).astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = np.arange(nS, dtype=np.int32)
+    ek, epr, eps = o.join_materialize(R, Pr, S, Ps)
+    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R, Pr)
+        (k, pr, ps), agg = hj.join_stream_probe_materialize(S, Ps, segment_tuples=seg)
+        assert len(k) == em and agg == eagg
+        for a, b in zip(sorted_triples(k, pr, ps), sorted_triples(ek, epr, eps)):
+            assert np.array_equal(a, b)
+        (k2, pr2, ps2), _ = hj.join_stream_probe_materialize(S, None, "rowid", segment_tuples=seg)   # global row ids
+        for a, b in zip(sorted_triples(k2, pr2, ps2), sorted_triples(ek, epr, eps)):
+            assert np.array_equal(a, b)
+        # capacity: nothing beyond cap is written, HJ_ECAPACITY reports the true size
+        out = [np.full(em, -7, np.int32) for _ in range(3)]
+        with pytest.raises(P.HJError) as ei:
+            hj.join_stream_probe_materialize(S, Ps, segment_tuples=seg, cap=em // 2, out=out)
+        assert ei.value.code == -4 and all(np.all(x[em // 2:] == -7) for x in out)
 
 
 def test_stream_probe_edge_cases(P):
@@ -474,6 +524,7 @@ def test_coprocess(P, parts, threads):
     with P.HashJoin(0) as hj:
         assert hj.join_coprocess(R, Pr, S, Ps, parts, threads) == (em, eagg)
         assert hj.join_coprocess(R, None, S, None, parts, threads) == o.join_count(R, None, S, None, checksum=False)[:2]
+        assert hj.host_split_throughput() > 0                       # the host split reports its GB/s (pp.cu:218)
         e = np.empty(0, np.int32)
         assert hj.join_coprocess(e, None, S, None, parts, threads) == (0, 0)
         # the resident path is usable afterwards
