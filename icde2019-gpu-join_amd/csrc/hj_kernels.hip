@@ -9,12 +9,17 @@
 //   join_partitioned_aggregate / _results  jp.cu:885-1095, 1107-1416   LDS chained hash build+probe
 //
 // What this file does instead (MI355X-first):
-//   * partitions are CONTIGUOUS (64-bit offsets), not bucket chains: a keys-only histogram kernel,
-//     a device-side scan, and a scatter kernel whose workgroups own long contiguous spans, so each
-//     (span, digit) output run is a private, contiguous HBM region.  The workgroup (1024 threads,
-//     wave64) appends tuples to per-digit 128-byte LDS write-combining lines and flushes only whole,
-//     128-byte-aligned lines with 16-byte stores (k_scatter_wc); a sorted-tile variant (k_scatter)
-//     serves narrow fan-out (the multi-GPU shard split).
+//   * a partitioned relation is two columns + per-partition ranges [beg, end).  Two ways to get there:
+//       - histogram-free passes (k_part1_fast, k_part2_fast; default for two-pass partitioning): every workgroup owns
+//         a span of the input (pass 1) or one pass-1 digit (pass 2) and writes each digit into a fixed-capacity slot
+//         of its own — the reference's bump-allocated fixed-size buckets (jp.cu:138-192) with one owner per bucket, so
+//         no histogram, no scan, no global atomic.  A slot that would overflow (skew) raises a device flag;
+//       - exact passes (k_plan, k_hist, k_scan_*, k_offsets, k_scatter_wc): keys-only histogram, device-side scan,
+//         scatter to gap-free positions.  Queued behind the histogram-free passes, every kernel returns at once unless
+//         the flag is up (run_if) — the fallback needs no host round trip.
+//     All three scatter kernels share one round machinery (wc_fast): a 1024-thread workgroup (wave64) appends
+//     (key,payload) pairs to per-digit 128-byte LDS write-combining lines and flushes only whole, 128-byte-aligned
+//     lines with 16-byte stores; a sorted-tile variant (k_scatter) serves narrow fan-out (the multi-GPU shard split).
 //     Nothing is read back to the host between kernels; grids are launched at their upper bound.
 //   * the join kernel builds a chained hash table in LDS per build partition (16-bit tags when the
 //     radix bits leave <= 16 key bits, full keys otherwise) and probes it with coalesced 16-byte

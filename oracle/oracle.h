@@ -10,14 +10,19 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The
  * product (icde2019-gpu-join_amd/) never links, imports or calls it.
  *
- * Pinning: the reference holds no tests or golden vectors for this path.  The
- * generator half of this oracle is pinned against the reference generator itself: oracle/_ref/refgen
- * is built from /root/reference/src/generator_ETHZ.cu (unmodified, g++ -x c++) by oracle/Makefile,
- * and tests/golden/ holds its outputs (tests/golden/make_golden.py regenerates them).  The join half
- * follows the reference's join semantics (jp.cu:1056-1079, hjcp.cu:2044-2053) and is pinned by the
- * closed-form match counts the generator construction implies and by two
- * independent restatements agreeing (sort-merge o_join_* vs. the chained-hash o_joinCpu).  The GPU
- * kernels of the reference cannot be built here (nvcc absent, CUDA-only) — see DESIGN.md.
+ * Pinning: the reference holds no tests or golden vectors for this path; both halves of this oracle
+ * are pinned to the reference itself, compiled here from where it lies by oracle/Makefile (`ref` target, outputs
+ * only into oracle/_ref/, git-ignored):
+ *   - generator half: oracle/_ref/refgen = /root/reference/src/generator_ETHZ.cu (unmodified, g++ -x c++);
+ *     tests/golden/*.bin are its outputs (tests/golden/make_golden.py), replayed bit for bit;
+ *   - join half: oracle/_ref/refjoin = the reference's own CPU join, joinCpu + h_hashMurmur
+ *     (/root/reference/src/hash_join_clustered_probe.cu:2013-2059: the span is cut out of the file at build time and
+ *     compiled next to the reference's common-host.h, no stand-in headers); tests/golden/join_answers.json holds the
+ *     match count s and key sum g it printed for 15 pairs of golden relations (OMP_NUM_THREADS=1: `s` is missing from
+ *     its reduction clause).  tests/test_oracle_join.py requires every restatement here (sort-merge o_join_*,
+ *     chained-hash o_joinCpu, OpenMP radix join) to reproduce s and g, and in the build container also runs refjoin
+ *     live on fresh inputs.  The closed-form counts implied by the generator construction are
+ *     checked on top.  The GPU kernels of the reference cannot be built here (nvcc absent, CUDA-only) — see DESIGN.md.
  */
 #ifndef HJ_ORACLE_H_
 #define HJ_ORACLE_H_

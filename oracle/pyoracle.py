@@ -22,7 +22,8 @@ def build(force=False):
     if force or not os.path.exists(_SO):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref = os.environ.get("HJ_REFERENCE", "/root/reference")
-    if os.path.isdir(ref) and (force or not os.path.exists(os.path.join(_HERE, "_ref", "refgen"))):
+    if os.path.isdir(ref) and (force or not os.path.exists(os.path.join(_HERE, "_ref", "refgen"))
+                               or not os.path.exists(os.path.join(_HERE, "_ref", "refjoin"))):
         subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + ref], stdout=subprocess.DEVNULL)
 
 
