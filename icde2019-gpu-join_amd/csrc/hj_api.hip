@@ -374,7 +374,11 @@ int partition_rel(hj_ctx *c, int r) {
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));
     { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n)); }
-    const uint32_t b1 = c->bits1, b2 = c->bits2;
+    uint32_t b1 = c->bits1, b2 = c->bits2;
+    // A relation known to be skewed (its histogram-free attempt overflowed) is split as evenly as possible between
+    // the two exact passes: fewer than 512 digits per pass leave LDS lines to deal to the heavy digits (k_scatter_wc).
+    // The final partition id is the same low b1+b2 key bits whatever the split, so the other relation is unaffected.
+    if (R.prefer_exact && b2 && !c->cfg.force_bits && !c->cfg.bits1 && b1 + b2 <= 16) { const uint32_t t = b1 + b2; b1 = (t + 1) / 2; b2 = t - b1; }
     R.fast_tried = false;
     R.part_off = nullptr;
     if (b1 == 0) { // nothing to partition: one partition = the input itself
@@ -464,7 +468,7 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
-    if (B.nparts != Pb.nparts || B.pb1 != Pb.pb1 || B.pb2 != Pb.pb2)
+    if (B.nparts != Pb.nparts || B.pb1 + B.pb2 != Pb.pb1 + Pb.pb2)
         return fail(c, HJ_EINVAL, "relations were partitioned with different radix bits (%u+%u vs %u+%u): partition both after loading both",
                     B.pb1, B.pb2, Pb.pb1, Pb.pb2);
     hipStream_t st = c->stream;
@@ -475,7 +479,7 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
     RET(ensure(c, c->items_cnt, (size_t)nparts * 4));
-    RET(ensure(c, c->items, (size_t)c->max_items * 8));
+    RET(ensure(c, c->items, (size_t)c->max_items * sizeof(JoinItem)));
     const uint64_t nwave = (uint64_t)c->max_items * JOIN_WAVES;
     RET(ensure(c, c->wave_counts, (size_t)nwave * 8));
     RET(ensure(c, c->wave_agg, (size_t)nwave * 8));
@@ -492,14 +496,14 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     a = JoinArgs{};
     a.bk = B.part_k; a.bp = B.part_p; a.bbeg = B.part_beg; a.bend = B.part_end; a.b_nalloc = B.n_alloc;
     a.pk = Pb.part_k; a.pp = Pb.part_p; a.pbeg = Pb.part_beg; a.pend = Pb.part_end; a.p_nalloc = Pb.n_alloc;
-    a.items = (const uint2 *)c->items.p;
+    a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
-                                                                (const uint64_t *)c->jchunk_prefix.p, (uint2 *)c->items.p)); }
+                                                                (const uint64_t *)c->jchunk_prefix.p, (JoinItem *)c->items.p)); }
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
     if (late) {
@@ -869,7 +873,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
     invalidate(c, HJ_REL_S);
     int rc = 0;
     choose_bits(c);
-    if (!R.partitioned || R.pb1 != c->bits1 || R.pb2 != c->bits2) rc = partition_rel(c, HJ_REL_R);
+    if (!R.partitioned || R.pb1 + R.pb2 != c->bits1 + c->bits2) rc = partition_rel(c, HJ_REL_R);
     uint64_t tot_m = 0, tot_a = 0;
     const uint64_t nseg = n ? (n + seg - 1) / seg : 0;
     auto issue_copy = [&](uint64_t i) -> int {

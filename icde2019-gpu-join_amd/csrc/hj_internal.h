@@ -61,6 +61,12 @@ struct FastArgs {
     uint32_t *ovf;               // overflow flag (also read: a set flag makes the kernel return at once)
 };
 
+// one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
+struct JoinItem {
+    uint64_t b0, q0, q1;
+    uint32_t nb, p;
+};
+
 struct JoinArgs {
     const int32_t *bk, *bp;  // build side, partitioned
     const uint64_t *bbeg, *bend; // partition p = [bbeg[p], bend[p])
@@ -68,7 +74,7 @@ struct JoinArgs {
     const int32_t *pk, *pp;  // probe side, partitioned
     const uint64_t *pbeg, *pend;
     uint64_t p_nalloc;
-    const uint2 *items;      // (partition, probe chunk)
+    const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
     uint64_t *wave_counts, *wave_agg;                     // count kernel outputs [items * JOIN_WAVES]
@@ -99,7 +105,7 @@ hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, co
 size_t scatter_lds_bytes(int threads, int u);
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
-                              const uint64_t *chunk_prefix, uint2 *items);
+                              const uint64_t *chunk_prefix, JoinItem *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(int device, size_t bytes);
 hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise, 2 late materialisation

@@ -475,6 +475,7 @@ struct WfLds {
     uint32_t *wlist;             // [16 waves][32] flush work lists
     uint32_t *pc4, *sb;          // pass 2: prefix of 4-tuple units per segment [nseg+1]; segment start | padding
     uint32_t *lo;                // exact pass: first valid slot of a digit's first line (aliases pc4: never both)
+    uint32_t *lt, *own;          // exact pass under skew: lines << 16 | first line per digit; owner digit per line
 };
 
 struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slotA + d*slotB, at slot*cap
@@ -493,7 +494,9 @@ struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slot
 // aligned position (lo[d] = first valid slot of the run's first line), nothing can overflow, no slot ranges are
 // written.  HEAVY: the span's histogram says one digit holds more than a quarter of it — ranks are taken with the
 // wave-aggregated atomic (same-address LDS atomics serialise per lane).
-template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false>
+// VAR (exact pass under skew): the 512 LDS lines are dealt to the digits in proportion to what the span's histogram
+// says each will receive per round (L_.lt[d] = lines << 16 | first line, L_.own[line] = digit), instead of K each.
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
@@ -621,10 +624,12 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t d = valid ? c >> 16 : 0u, q = c & 0xFFFFu;
                 const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1); // slots that leave this round
                 const bool leaves = q < full;
-                const bool now = valid && (leaves ? q < capS : full == 0);
-                any_bypass |= valid && leaves && q >= capS;
-                buf[now ? d * capS + q : trash] = make_int2(elem(kv[u], e), elem(pv[u], e));
-                keep[j] = (valid && !leaves && full != 0) ? d * capS + (q - full) : WF_NONE;
+                const uint32_t lt = VAR ? L_.lt[d] : 0u;
+                const uint32_t capd = VAR ? (lt >> 16) * WC_LINE : capS, based = VAR ? (lt & 0xFFFFu) * WC_LINE : d * capS;
+                const bool now = valid && (leaves ? q < capd : full == 0);
+                any_bypass |= valid && leaves && q >= capd;
+                buf[now ? based + q : trash] = make_int2(elem(kv[u], e), elem(pv[u], e));
+                keep[j] = (valid && !leaves && full != 0) ? based + (q - full) : WF_NONE;
             }
         if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
 #pragma unroll
@@ -636,7 +641,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     if (c != WF_NONE) {
                         const uint32_t d = c >> 16, q = c & 0xFFFFu;
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
-                        if (q < full && q >= capS) {
+                        if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
                             const uint32_t o = line[d] + q;
                             if (EXACT || o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
                             else *ovf = 1u;
@@ -655,10 +660,13 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         {
             uint32_t *wlist = L_.wlist + wv * 32;
             const uint32_t lsl = wv * 32 + (ln & 31u);
-            const uint32_t wq = h[lsl >> kshift];
+            const uint32_t dq = VAR ? L_.own[lsl] : lsl >> kshift;          // VAR: 0xFFFF = a line nobody owns
+            const uint32_t ltq = (VAR && dq < P) ? L_.lt[dq] : 0u;
+            const uint32_t wq = dq < P ? h[dq] : 0u;
             uint32_t fullq_n = ((wq >> 16) + (wq & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
-            fullq_n = (fullq_n < capS ? fullq_n : capS) >> 5; // full lines of that digit
-            const bool fullq = (ln < 32u) && ((lsl & (K - 1)) < fullq_n);
+            const uint32_t capq = VAR ? (ltq >> 16) * WC_LINE : capS;
+            fullq_n = (fullq_n < capq ? fullq_n : capq) >> 5; // full lines of that digit
+            const bool fullq = (ln < 32u) && ((VAR ? lsl - (ltq & 0xFFFFu) : (lsl & (K - 1))) < fullq_n);
             const uint64_t m = __ballot(fullq);
             const uint32_t nfull = (uint32_t)__popcll(m);
             if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = lsl;
@@ -668,11 +676,13 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t idx = t + (ln >> 3);
                 if (idx < nfull) {
                     const uint32_t ls = wlist[idx];
-                    const uint32_t gpos = line[ls >> kshift] + (ls & (K - 1)) * WC_LINE + c4;
+                    const uint32_t df = VAR ? L_.own[ls] : ls >> kshift;
+                    const uint32_t jf = VAR ? ls - (L_.lt[df] & 0xFFFFu) : (ls & (K - 1));
+                    const uint32_t gpos = line[df] + jf * WC_LINE + c4;
                     const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
                     const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
                     const int4 kq = make_int4(x.x, x.z, y.x, y.z), pq = make_int4(x.y, x.w, y.y, y.w);
-                    const uint32_t first_valid = (EXACT && (ls & (K - 1)) == 0) ? L_.lo[ls >> kshift] : 0u;
+                    const uint32_t first_valid = (EXACT && jf == 0) ? L_.lo[df] : 0u;
                     if (first_valid == 0) {
                         *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
                         *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
@@ -710,7 +720,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t w = hlast[d];
         const uint32_t cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
         if (s < cur && (!EXACT || s >= L_.lo[d])) {
-            const int2 v = buf[d * capS + s];
+            const int2 v = buf[(VAR ? (L_.lt[d] & 0xFFFFu) * WC_LINE : d * capS) + s];
             if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = v.x;
             else out_pays[line[d] + s] = v.y;
         }
@@ -731,6 +741,8 @@ __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32 + 4; // + the "stop" word
     L_.sb = L_.pc4 + WF_MAXSEG + 4;
     L_.lo = L_.pc4;
+    L_.lt = L_.pc4 + MAX_PARTS;
+    L_.own = L_.pc4 + 2 * MAX_PARTS;
 }
 size_t fast_lds_bytes_impl() {
     return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
@@ -769,19 +781,51 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
         lo0 = (uint32_t)g0 & (WC_LINE - 1);
         L_.lo[tid] = lo0;
     }
-    // a span whose tuples mostly share one digit: same-address LDS atomics would serialise per lane
-    uint32_t any_heavy;
-    const uint32_t heavy = (tid < P && (uint64_t)cnt * 4 > (si.hi - si.lo)) ? 1u : 0u;
-    (void)block_excl_scan<uint32_t>(heavy, scratch, &any_heavy);
+    // One workgroup reduction tells every thread three things about the span's histogram:
+    //  - does one digit hold more than a quarter of the span (same-address LDS atomics would serialise per lane: HEAVY);
+    //  - how many lines the digits want in total, a digit wanting its expected arrivals per round with 30 % headroom;
+    //  - does some digit want more than the K = 512/P lines every digit has by default (then the lines are dealt by need).
+    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
+    const uint32_t K = (uint32_t)MAX_PARTS / P;
+    const uint64_t len = si.hi - si.lo;
+    uint32_t need = 0;
+    uint64_t packed = 0;
+    if (tid < P) {
+        need = (uint32_t)(((uint64_t)cnt * ROUND * 13 / 10) / (len ? len : 1)) / WC_LINE + 1;
+        if (need > (uint32_t)MAX_PARTS) need = MAX_PARTS;
+        packed = (uint64_t)need | ((uint64_t)((uint64_t)cnt * 4 > len ? 1 : 0) << 32) | ((uint64_t)(need > K ? 1 : 0) << 48);
+    }
+    uint64_t tot64;
+    (void)block_excl_scan<uint64_t>(packed, reinterpret_cast<uint64_t *>(scratch), &tot64);
+    const uint32_t total_need = (uint32_t)tot64, any_heavy = (uint32_t)(tot64 >> 32) & 0xFFFFu, any_over = (uint32_t)(tot64 >> 48);
+    const bool var = any_over != 0 && P < (uint32_t)MAX_PARTS; // 512 digits leave no line to deal
+    if (var) {
+        uint32_t nl = need;
+        if (total_need > (uint32_t)MAX_PARTS) // not enough lines: one each, the rest in proportion to the wish beyond one
+            nl = 1 + (uint32_t)((uint64_t)(need - (tid < P ? 1u : 0u)) * ((uint32_t)MAX_PARTS - P) / (total_need - P));
+        if (tid >= P) nl = 0;
+        uint32_t dummy;
+        const uint32_t first = block_excl_scan<uint32_t>(nl, scratch, &dummy);
+        if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = 0xFFFFu;
+        __syncthreads();
+        if (tid < P) {
+            L_.lt[tid] = (nl << 16) | first;
+            for (uint32_t j = 0; j < nl; j++) L_.own[first + j] = tid;
+        }
+    }
+    __syncthreads();
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     __syncthreads();
     if (tid < P) L_.hh[tid] = lo0 << 16; // round 0 starts at the fill the run's first line already has
     __syncthreads();
     const FastGeom g{0, 0, 0};
-    // block_excl_scan hands the workgroup total to every thread: the branch is workgroup-uniform
-    if (any_heavy) wc_fast<U, 0, 0, true, true>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
-    else if (P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, true, false>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
-    else wc_fast<U, 0, 0, true, false>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr);
+    // block_excl_scan hands the workgroup totals to every thread: the branches are workgroup-uniform
+#define HJ_WC(KF, HV, VR) wc_fast<U, KF, 0, true, HV, VR>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr)
+    if (var) { if (any_heavy) HJ_WC(0, true, true); else HJ_WC(0, false, true); }
+    else if (any_heavy) HJ_WC(0, true, false);
+    else if (P == (uint32_t)MAX_PARTS) HJ_WC(1, false, false);
+    else HJ_WC(0, false, false);
+#undef HJ_WC
 }
 
 // pass 1: one workgroup per span of the contiguous input
@@ -923,13 +967,21 @@ __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *_
 __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
                               const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                               uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
-                              const uint64_t *__restrict__ chunk_prefix, uint2 *__restrict__ items) {
+                              const uint64_t *__restrict__ chunk_prefix, JoinItem *__restrict__ items) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nparts) return;
     uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
     uint64_t at = (uint64_t)items_scanned[p] + chunk_prefix[p >> SCAN_CHUNK_LOG];
-    for (uint32_t j = 0; j < c; j++) items[at + j] = make_uint2(p, j);
+    // a self-contained descriptor per item: the join workgroup reads ONE 32-byte record and goes straight to the data
+    // (not item -> partition -> four range loads: every dependent global load is ~2 us under load)
+    for (uint32_t j = 0; j < c; j++) {
+        JoinItem it;
+        it.b0 = bbeg[p]; it.nb = (uint32_t)nb; it.p = p;
+        it.q0 = pbeg[p] + (uint64_t)j * chunk;
+        it.q1 = it.q0 + chunk < pend[p] ? it.q0 + chunk : pend[p];
+        items[at + j] = it;
+    }
 }
 
 // LDS layout (dynamic): head[nh] u32 | pay[cap] i32 | key[cap] (u16 tag or u32 key) | next[cap] u16
@@ -948,12 +1000,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     uint16_t *lnext = reinterpret_cast<uint16_t *>(kbase + (size_t)a.cap * (TAG16 ? 2 : 4));
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint2 it = a.items[item];
-    const uint32_t p = it.x;
-    const uint64_t b0 = a.bbeg[p], nb = a.bend[p] - b0;
-    const uint64_t q0 = a.pbeg[p] + (uint64_t)it.y * a.chunk;
-    const uint64_t pend = a.pend[p];
-    const uint64_t q1 = q0 + a.chunk < pend ? q0 + a.chunk : pend;
+    const JoinItem it = a.items[item];
+    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
 
     uint64_t my_matches = 0, my_agg = 0;
@@ -967,32 +1015,56 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     for (uint64_t bc = 0; bc < nb; bc += a.cap) {
         const uint64_t gb = b0 + bc;
         const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+        // the first probe iteration's loads are issued before the table is built: they fly during the build
+        const uint64_t wfirst = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256;
+        int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
+        if (wfirst + (uint64_t)lane_id() * 4 < q1) {
+            nk = load4(a.pk, wfirst + (uint64_t)lane_id() * 4, a.p_nalloc);
+            np = load4(a.pp, wfirst + (uint64_t)lane_id() * 4, a.p_nalloc);
+        }
         for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
         __syncthreads();
         // ---- build: tuple j of the chunk lives in slot j; LIFO chain insert by atomic exchange on
-        // the bucket head (jp.cu:1021-1048) ----
-        for (uint64_t i = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i < gb + nbc; i += (uint64_t)JOIN_THREADS * 4) {
-            int4 kv = load4(a.bk, i, a.b_nalloc), pv = load4(a.bp, i, a.b_nalloc);
+        // the bucket head (jp.cu:1021-1048).  Loads of three iterations (6144 tuples: a whole default-size table) are
+        // issued before the first insert ----
+        for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 3) {
+            int4 bkv[3], bpv[3];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                uint64_t idx = i + e;
-                if (idx >= gb && idx < gb + nbc) {
-                    uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(kv, e);
-                    if (TAG16) ltag[slot] = (uint16_t)(key >> bits); else lkey[slot] = key;
-                    lpay[slot] = elem(pv, e);
-                    uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
-                    lnext[slot] = (uint16_t)old;
+            for (int r = 0; r < 3; r++) {
+                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                if (i < gb + nbc) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        uint64_t idx = i + e;
+                        if (idx >= gb && idx < gb + nbc) {
+                            uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                            if (TAG16) ltag[slot] = (uint16_t)(key >> bits); else lkey[slot] = key;
+                            lpay[slot] = elem(bpv[r], e);
+                            uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                            lnext[slot] = (uint16_t)old;
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
         // ---- probe ----
         // the loop bound is wave-uniform (w0), so every lane of a wave stays in the loop together:
-        // the ballot ranks and the wave's output cursor depend on it
-        for (uint64_t w0 = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256; w0 < q1; w0 += (uint64_t)JOIN_THREADS * 4) {
+        // the ballot ranks and the wave's output cursor depend on it.  The next iteration's loads are issued before
+        // this iteration's chains are walked.
+        for (uint64_t w0 = wfirst; w0 < q1; w0 += (uint64_t)JOIN_THREADS * 4) {
             const uint64_t i = w0 + (uint64_t)lane_id() * 4;
-            int4 kv = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
-            if (i < q1) { kv = load4(a.pk, i, a.p_nalloc); pv = load4(a.pp, i, a.p_nalloc); }
+            const int4 kv = nk, pv = np;
+            {
+                const uint64_t inext = i + (uint64_t)JOIN_THREADS * 4;
+                nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
+                if (inext < q1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
+            }
             if (JM == 0) {
                 // count-only: the four bucket heads of this lane's four tuples are fetched first and the four
                 // chains are walked in lockstep, so their LDS reads overlap instead of completing one by one
@@ -1351,7 +1423,7 @@ hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, 
 }
 
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
-                              const uint64_t *chunk_prefix, uint2 *items) {
+                              const uint64_t *chunk_prefix, JoinItem *items) {
     hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
                        items_scanned, chunk_prefix, items);
     HJ_LAUNCH_CHECK();
