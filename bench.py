@@ -189,6 +189,36 @@ def bench_stream(a, pkg, torch, dev, local):
                       "config": {"workload": "PK-FK 2^27 x 2^30, S streamed from pinned host memory in segments of max(|R|/4, 2^24)"}}))
 
 
+def bench_coprocess(a, pkg, torch, dev, local):
+    """SURVEY §8(f) rank 2 (outOfGPU_Join2_payload): both relations in HOST memory; host level-0 split (software
+    write-combining, non-temporal stores) + per-partition upload and GPU join.  Host- and PCIe-bound by construction."""
+    n = 1 << min(a.log2n, 28)
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    k = torch.empty(n, dtype=torch.int32, device=dev)
+    hj.gen_unique(k, n, 0, n, 1)
+    hj.sync()
+    R = k.cpu().numpy()
+    hj.gen_unique(k, n, 0, n, 2)
+    hj.sync()
+    S = k.cpu().numpy()
+    del k
+    times, gbs = [], []
+    for i in range(a.warmup + a.steps):
+        t0 = time.perf_counter()
+        m, _ = hj.join_coprocess(R, None, S, None)
+        dt = time.perf_counter() - t0
+        assert m == n, (m, n)
+        if i >= a.warmup:
+            times.append(dt)
+            gbs.append(hj.host_split_throughput())
+    dt = sum(times) / len(times)
+    print(json.dumps({"metric": "billion tuples/sec, CPU-GPU co-processing: R and S (2^%d each) in host memory" % (n.bit_length() - 1),
+                      "value": round(2 * n / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2),
+                      "host_split_GBs": round(sum(gbs) / len(gbs), 2), "cpu_model": cpu_model(),
+                      "config": {"workload": "unique uniform int32, 16 level-0 partitions, host split on the box's CPU quota, "
+                                             "double-buffered upload + GPU join per partition"}}))
+
+
 def launch_ranks(n):
     """Re-run this script under torch.distributed.run with n ranks on this node (child process, never an exec:
     this process has not touched the GPU and stays alive to forward the result)."""
@@ -250,7 +280,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
-    ap.add_argument("--workload", choices=["uniform", "zipf", "stream", "baselines"], default="uniform",
+    ap.add_argument("--workload", choices=["uniform", "zipf", "stream", "coprocess", "baselines"], default="uniform",
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
@@ -295,6 +325,8 @@ def main():
         return bench_stream(a, pkg, torch, dev, local)
     if a.workload == "baselines":
         return bench_baselines(a, pkg, torch, dev, local)
+    if a.workload == "coprocess":
+        return bench_coprocess(a, pkg, torch, dev, local)
 
     if use_dist:
         # a stream of our own for N>1: the all-to-alls run asynchronously next to local kernels, and HIP's

@@ -93,3 +93,41 @@ def test_config4_full_size_properties(P):
         assert bad == 0
         k, p, off, nparts = hj.partition_pointers(P.REL_S)
         assert hj.digest_pairs(k, p, nS) == before
+        # the first join found S skewed (its histogram-free attempt overflowed); the second goes straight to the exact
+        # passes, splits the radix bits evenly and deals the LDS lines by need — same partitions, same result
+        assert hj.partition_layout(P.REL_S) == "exact" and hj.partition_layout(P.REL_R) == "slotted"
+        assert hj.join() == (m, agg)
+        bad, _ = hj.verify_partitions(P.REL_S)
+        assert bad == 0
+        k, p, off, nparts = hj.partition_pointers(P.REL_S)
+        assert hj.digest_pairs(k, p, nS) == before
+
+
+@pytest.mark.parametrize("cfg", [dict(bits1=8, bits2=8, exact_only=True), dict(bits1=6, bits2=6, exact_only=True),
+                                 dict(bits1=9, bits2=7, exact_only=True), dict(bits1=4, bits2=9, exact_only=True), None])
+def test_skewed_exact_passes_deal_lines_by_need(P, cfg):
+    """Exact passes under skew: the 512 LDS lines are dealt to the digits by what the span's histogram says they will
+    receive (one digit wanting more than all of them: scaled), heavy spans rank with the wave-aggregated atomic.
+    Partition boundaries and contents must equal the oracle's, whatever the line allocation."""
+    rng = np.random.default_rng(91)
+    n = 1 << 20
+    u = rng.random(n)
+    keys = np.where(u < 0.55, 0x00ABCDEF, np.where(u < 0.75, 0x00ABCD11, np.where(u < 0.80, 77, rng.integers(0, 1 << 24, n)))).astype(np.int32)
+    pays = np.arange(n, dtype=np.int32)
+    R = rng.permutation(1 << 16).astype(np.int32)
+    Rp = np.arange(len(R), dtype=np.int32)
+    em, eagg, _ = o.join_count(R, Rp, keys, pays, checksum=False)
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.load_host(P.REL_R, R, Rp)
+        hj.load_host(P.REL_S, keys, pays)
+        for _ in range(2):   # the second round of the default configuration runs with what the first learned
+            assert hj.join() == (em, eagg)
+            c = hj.config()
+            bits = c["bits1"] + c["bits2"]
+            gk, gp, goff = hj.partitions(P.REL_S, n)
+            ok, op, ooff = o.radix_partition(keys, pays, 0, bits)
+            assert np.array_equal(goff, ooff)
+            assert np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+            assert hj.partition_layout(P.REL_S) == "exact"
