@@ -260,12 +260,11 @@ void choose_bits(hj_ctx *c) {
     if (total <= 9) {
         c->bits1 = total; c->bits2 = 0;
     } else {
-        // two passes: the first is always 9 bits (512-way is the fan-out k_scatter_wc is fastest at: one
-        // LDS line per digit, fewest same-digit collisions in the rank atomics); a 7-bit second pass
-        // measured faster than 5-6 bits at 2^27 (bit-split sweep, profiles/r1_bits_sweep_2p27.txt)
+        // two passes: the first is always 9 bits (512-way: one LDS line per digit), the second takes the rest, so that
+        // a build partition averages 2048-4096 tuples — the join kernel's sweet spot (bit sweep at 2^26-2^28,
+        // profiles/r2_bits_sweep.txt: a 7-bit floor for the second pass, round 1's rule, now costs 5-11 %)
         c->bits1 = 9;
         c->bits2 = total - 9;
-        if (c->bits2 < 7 && nb >= ((uint64_t)1 << 25)) c->bits2 = 7;
     }
     if (!g.lds_heads) { // hash-table heads ~ 2x the average build partition, power of two in [256, 4096]
         uint64_t avg = nb >> (c->bits1 + c->bits2);
