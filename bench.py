@@ -96,6 +96,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     not the headline line."""
     nR, nS = 1 << 27, 1 << 31
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    hj.enable_timings(1)   # per-kernel HIP events: the roofline fields come from them
     if a.probe_chunk:
         hj.configure(probe_chunk=a.probe_chunk)
     Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
@@ -333,6 +334,7 @@ def main():
         # legacy default stream would add implicit synchronisation with other blocking streams
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    hj.enable_timings(1)   # per-kernel HIP events: the roofline fields come from them
     if a.bits or a.probe_chunk or a.lds or a.exact_only:
         hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
                      lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0, exact_only=a.exact_only)

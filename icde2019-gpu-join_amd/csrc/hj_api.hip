@@ -58,6 +58,7 @@ struct Rel {
     bool partitioned = false;
     bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
     bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
+    bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
 };
 
 } // namespace
@@ -75,11 +76,13 @@ struct hj_ctx {
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
     Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
-    bool join_planned = false;     // scanned per-wave counts + item list of the current partitions are on the device
+    bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
+    bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
     JoinArgs last_args{};
     bool last_tag16 = false;
     uint64_t last_matches = 0, last_agg = 0;
     uint32_t max_items = 0;
+    uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
     int scatter_variant = -1;
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
@@ -97,7 +100,7 @@ struct hj_ctx {
     hipEvent_t out_ready[2] = {}, out_free[2] = {};
     hipEvent_t seg_ready[2] = {};
     // timing
-    int events = 1;                 // 0 none, 1 main kernels (hist / scatter / join), 2 every launch (HJ_KERNEL_EVENTS)
+    int events = 0;                 // 0 none (default), 1 main kernels (partition passes / join), 2 every launch: hj_enable_timings, HJ_KERNEL_EVENTS
     std::vector<KStat> kstats;
     std::vector<Stamp> stamps;
     std::vector<hipEvent_t> pool;
@@ -310,7 +313,7 @@ int pass_hist(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa, uint64_t 
     const uint64_t max_len = (uint64_t)pa.max_spans * pa.P;
     { Timed t(c, "k_plan", st, true); HIPCHK(c, launch_plan(st, pa)); }
     { Timed t(c, "k_hist", st, true); HIPCHK(c, launch_hist(st, mode, pa)); }
-    { Timed t(c, "k_scan", st, true); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + pa.nseg, pa.P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr, pa.run_if)); }
+    { Timed t(c, "k_scan", st, true); HIPCHK(c, launch_scan_u32(st, pa.hist, pa.span_start + pa.nseg, pa.P, max_len, pa.chunk_sums, pa.chunk_prefix, nullptr)); }
     { Timed t(c, "k_offsets", st, true); HIPCHK(c, launch_offsets(st, pa, n, coff)); }
     return 0;
 }
@@ -323,14 +326,13 @@ int pass_scatter(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa) {
     return 0;
 }
 
-// run_if: optional device flag; the whole pass is skipped on the device when it reads 0.  beg/end: optional
-// ranges of the child partitions for the join.
+// beg/end: optional ranges of the child partitions for the join.
 int run_pass(hj_ctx *c, int wsid, int mode, const int32_t *in_k, const int32_t *in_p, uint64_t n, const uint64_t *poff,
              uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
-             uint64_t *coff, const uint32_t *run_if = nullptr, uint64_t *beg = nullptr, uint64_t *end = nullptr) {
+             uint64_t *coff, uint64_t *beg = nullptr, uint64_t *end = nullptr) {
     PassArgs pa;
     RET(pass_prep(c, wsid, in_k, in_p, n, poff, nparents, shift, P, mask_or_n, out_k, out_p, pa));
-    pa.run_if = run_if; pa.beg = beg; pa.end = end;
+    pa.beg = beg; pa.end = end;
     RET(pass_hist(c, c->stream, mode, pa, n, coff));
     return pass_scatter(c, c->stream, mode, pa);
 }
@@ -372,13 +374,15 @@ int partition_rel(hj_ctx *c, int r) {
     choose_bits(c);
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));
-    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n)); }
+    RET(ensure(c, R.flag, 64));
+    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, (uint32_t *)R.flag.p)); }
     uint32_t b1 = c->bits1, b2 = c->bits2;
     // A relation known to be skewed (its histogram-free attempt overflowed) is split as evenly as possible between
     // the two exact passes: fewer than 512 digits per pass leave LDS lines to deal to the heavy digits (k_scatter_wc).
     // The final partition id is the same low b1+b2 key bits whatever the split, so the other relation is unaffected.
     if (R.prefer_exact && b2 && !c->cfg.force_bits && !c->cfg.bits1 && b1 + b2 <= 16) { const uint32_t t = b1 + b2; b1 = (t + 1) / 2; b2 = t - b1; }
     R.fast_tried = false;
+    R.flag_known_good = false;
     R.part_off = nullptr;
     if (b1 == 0) { // nothing to partition: one partition = the input itself
         R.part_k = R.in_k; R.part_p = R.in_p; R.nparts = 1; R.n_alloc = R.n;
@@ -402,21 +406,17 @@ int partition_rel(hj_ctx *c, int r) {
     if (b2 == 0) {
         RET(ensure(c, R.off2, (size_t)(P1 + 1) * 8));
         RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, 0, P1, P1 - 1, (int32_t *)R.b_k.p,
-                     (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, nullptr, beg, end));
+                     (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, beg, end));
     } else {
         RET(ensure(c, R.a_k, (size_t)(elemsA + PAD) * 4));
         RET(ensure(c, R.a_p, (size_t)(elemsA + PAD) * 4));
-        RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
-        RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
-        const uint32_t *run_if = nullptr;
         if (fast) {
-            // ---- histogram-free passes first; the exact passes below are queued behind them and run (on the
-            //      device's say-so, no host round trip) only if a slot overflowed ----
-            RET(ensure(c, R.flag, 64));
+            // ---- histogram-free passes.  Optimistic: if a slot overflows, the kernels raise the relation's flag, the
+            //      join's planning kernel then produces no work, and the host — which reads the flag with the next result
+            //      block — redoes this relation with the exact passes (retry_overflowed) ----
             RET(ensure(c, R.s1beg, (size_t)P1 * f.nspans * 8));
             RET(ensure(c, R.s1end, (size_t)P1 * f.nspans * 8));
             uint32_t *ovf = (uint32_t *)R.flag.p;
-            HIPCHK(c, hipMemsetAsync(ovf, 0, 4, st));
             FastArgs fa{};
             fa.keys = R.in_k; fa.pays = R.in_p; fa.n = R.n; fa.span = f.span; fa.nspans = f.nspans;
             fa.shift = b2; fa.P = P1; fa.cap = f.cap1;
@@ -430,15 +430,17 @@ int partition_rel(hj_ctx *c, int r) {
             fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
             fb.obeg = beg; fb.oend = end; fb.ovf = ovf;
             { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(st, fb)); }
-            run_if = ovf;
             R.fast_tried = true;
+        } else {
+            RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
+            RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
+            // pass 1 on key bits [b2, b2+b1), pass 2 on bits [0, b2): final partition id = low b1+b2 key
+            // bits, pass-1 digit major — the order of jp.cu:402 ((pid << log_parts2) + j)
+            RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, (int32_t *)R.a_k.p,
+                         (int32_t *)R.a_p.p, (uint64_t *)R.off1.p));
+            RET(run_pass(c, r, 0, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
+                         P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, beg, end));
         }
-        // pass 1 on key bits [b2, b2+b1), pass 2 on bits [0, b2): final partition id = low b1+b2 key
-        // bits, pass-1 digit major — the order of jp.cu:402 ((pid << log_parts2) + j)
-        RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, (int32_t *)R.a_k.p,
-                     (int32_t *)R.a_p.p, (uint64_t *)R.off1.p, run_if));
-        RET(run_pass(c, r, 0, (const int32_t *)R.a_k.p, (const int32_t *)R.a_p.p, R.n, (const uint64_t *)R.off1.p, P1, 0, P2,
-                     P2 - 1, (int32_t *)R.b_k.p, (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, run_if, beg, end));
     }
     R.nparts = nparts;
     R.part_k = (const int32_t *)R.b_k.p;
@@ -452,13 +454,19 @@ int partition_rel(hj_ctx *c, int r) {
     return 0;
 }
 
-// Which layout does a relation whose histogram-free passes were queued have?  Reads the device flag.  [sync]
+// A relation whose histogram-free passes were queued is only known good once its flag has been read.  [sync]
+// If the flag is up the relation is re-partitioned with the exact passes (asynchronously, on the context stream).
 int resolve_layout(hj_ctx *c, Rel &R) {
     if (!R.fast_tried) return 0;
     uint32_t ovf = 0;
     HIPCHK(c, hipMemcpyAsync(&ovf, R.flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ovf) { R.part_off = (const uint64_t *)R.off2.p; R.fast_tried = false; R.prefer_exact = true; } // the exact passes ran: contiguous
+    if (ovf) {
+        R.prefer_exact = true;
+        RET(partition_rel(c, (int)(&R - c->rel)));
+    } else {
+        R.flag_known_good = true;
+    }
     return 0;
 }
 
@@ -498,7 +506,9 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
-    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p)); }
+    a.bflag = (B.fast_tried && !B.flag_known_good) ? (const uint32_t *)B.flag.p : nullptr;
+    a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? (const uint32_t *)Pb.flag.p : nullptr;
+    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
@@ -513,27 +523,58 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
         Timed t(c, "k_join_count");
         HIPCHK(c, launch_join(st, a, c->max_items, tag16, 0));
     }
-    HIPCHK(c, hipMemsetAsync(sc + 2, 0, 8, st));
-    // n_items is a uint64 on the device; the scans take its low word as their length (little endian)
+    // n_items is a uint64 on the device; the reductions take its low word as their length (little endian)
     const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
-    { Timed t(c, "k_reduce"); HIPCHK(c, launch_reduce64(st, a.wave_agg, len, JOIN_WAVES, sc + 2)); }
-    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u64(st, a.wave_counts, len, JOIN_WAVES, nwave, (uint64_t *)c->jchunk_sums.p,
-                                                      (uint64_t *)c->jchunk_prefix.p, sc + 1)); }
+    // matches and aggregate in one launch into sc[1], sc[2] (zeroed by k_join_plan); the exclusive scan of the per-wave
+    // counts — the output offsets — is only run when a materialising call follows (scan_wave_counts)
+    { Timed t(c, "k_sum2"); HIPCHK(c, launch_sum2(st, a.wave_counts, a.wave_agg, len, JOIN_WAVES, sc + 1)); }
+    c->waves_scanned = false;
+    return 0;
+}
+
+// exclusive scan of the per-wave match counts of the last run_count, in place: the materialising kernel's offsets
+int scan_wave_counts(hj_ctx *c) {
+    if (c->waves_scanned) return 0;
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
+    const uint64_t nwave = (uint64_t)c->max_items * JOIN_WAVES;
+    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u64(c->stream, (uint64_t *)c->wave_counts.p, len, JOIN_WAVES, nwave, (uint64_t *)c->jchunk_sums.p,
+                                                      (uint64_t *)c->jchunk_prefix.p, sc + 3)); }
+    c->waves_scanned = true;
     return 0;
 }
 
 int fetch_scalars(hj_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 8 * 8, hipMemcpyDeviceToHost, c->stream));
-    // the same round trip brings back the overflow flags of relations whose histogram-free passes were queued: the host
-    // learns which layout holds, and a binding that overflowed goes straight to the exact passes next time
+    // the same round trip brings back the overflow flags of relations whose histogram-free passes were queued
     for (int r = 0; r < 2; r++)
-        if (c->rel[r].fast_tried) HIPCHK(c, hipMemcpyAsync(c->h_scalars + 8 + r, c->rel[r].flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        if (c->rel[r].fast_tried && !c->rel[r].flag_known_good)
+            HIPCHK(c, hipMemcpyAsync(c->h_scalars + 8 + r, c->rel[r].flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->redo_mask = 0;
     for (int r = 0; r < 2; r++) {
         Rel &R = c->rel[r];
-        if (R.fast_tried && (uint32_t)c->h_scalars[8 + r]) { R.fast_tried = false; R.part_off = (const uint64_t *)R.off2.p; R.prefer_exact = true; }
+        if (!R.fast_tried || R.flag_known_good) continue;
+        if ((uint32_t)c->h_scalars[8 + r]) { R.prefer_exact = true; c->redo_mask |= 1u << r; } // slots overflowed: ranges invalid
+        else R.flag_known_good = true;
     }
     resolve_completed(c); // every [sync] entry point folds finished stamps: the event backlog stays bounded
+    return 0;
+}
+
+// run_count + result read-back; relations whose histogram-free partitions turn out to have overflowed (skew) are
+// re-partitioned with the exact passes and the join runs again — once: the exact passes cannot overflow.
+int count_and_fetch(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullptr) {
+    RET(run_count(c, a, tag16, late));
+    RET(fetch_scalars(c));
+    if (c->redo_mask) {
+        const uint32_t m = c->redo_mask;
+        for (int r = 0; r < 2; r++)
+            if (m & (1u << r)) RET(partition_rel(c, r));
+        RET(run_count(c, a, tag16, late));
+        RET(fetch_scalars(c));
+        if (c->redo_mask) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+    }
     return 0;
 }
 
@@ -563,7 +604,6 @@ int hj_create(hj_ctx **out, int device) {
     if (hipHostMalloc((void **)&c->h_scalars, 128, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
     memset(c->h_scalars, 0, 128);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
-    if (const char *ev = getenv("HJ_NO_KERNEL_EVENTS")) { if (ev[0] == '1') c->events = 0; }
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
     if (sv) c->scatter_variant = atoi(sv);
@@ -692,11 +732,10 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     HIPCHK(c, hipSetDevice(c->device));
     JoinArgs a;
     bool tag16;
-    RET(run_count(c, a, tag16));
-    RET(fetch_scalars(c));
+    RET(count_and_fetch(c, a, tag16));
     if (matches) *matches = c->h_scalars[1];
     if (agg) *agg = c->h_scalars[2];
-    // a materialising call on the same partitions can skip the count (item list + scanned counts are in HBM)
+    // a materialising call on the same partitions can skip the count (item list + per-wave counts are in HBM)
     c->last_args = a; c->last_tag16 = tag16; c->last_matches = c->h_scalars[1]; c->last_agg = c->h_scalars[2];
     c->join_planned = true;
     return HJ_OK;
@@ -710,7 +749,11 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     bool tag16;
     const bool reuse = c->join_planned;
     if (reuse) { a = c->last_args; tag16 = c->last_tag16; }
-    else RET(run_count(c, a, tag16));
+    else {
+        RET(count_and_fetch(c, a, tag16)); // the count also proves the partitions valid (overflow flags)
+        c->last_matches = c->h_scalars[1]; c->last_agg = c->h_scalars[2];
+    }
+    RET(scan_wave_counts(c));
     a.wave_scanned = (const uint64_t *)c->wave_counts.p;
     a.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
     a.out_key = d_key;
@@ -719,8 +762,8 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     a.out_cap = cap;
     { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, 1)); }
     c->join_planned = false; // conservative: one reuse per count
-    RET(fetch_scalars(c));
-    if (reuse) { c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg; }
+    RET(fetch_scalars(c));   // [sync]: the output columns are complete when this returns
+    c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg;
     if (n_out) *n_out = c->h_scalars[1];
     if (c->h_scalars[1] > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu",
                                            (unsigned long long)c->h_scalars[1], (unsigned long long)cap);
@@ -776,8 +819,7 @@ int hj_join_late_materialize(hj_ctx *c, const int32_t *d_Dr, uint32_t ncolR, uin
     late.Dp = r_builds ? d_Ds : d_Dr; late.ncp = r_builds ? ncolS : ncolR; late.sp = r_builds ? strideS : strideR;
     JoinArgs a;
     bool tag16;
-    RET(run_count(c, a, tag16, &late));
-    RET(fetch_scalars(c));
+    RET(count_and_fetch(c, a, tag16, &late));
     if (matches) *matches = c->h_scalars[1];
     if (sum) *sum = c->h_scalars[2];
     return HJ_OK;
@@ -907,7 +949,8 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
             if (out_used[b] && hipStreamWaitEvent(c->stream, c->out_free[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
             if ((rc = ensure(c, c->out_k[b], (size_t)(m + PAD) * 4)) || (rc = ensure(c, c->out_p1[b], (size_t)(m + PAD) * 4)) ||
                 (rc = ensure(c, c->out_p2[b], (size_t)(m + PAD) * 4))) break;
-            JoinArgs ja = c->last_args; // item list + scanned per-wave counts of this segment are on the device
+            JoinArgs ja = c->last_args; // item list + per-wave counts of this segment are on the device
+            if ((rc = scan_wave_counts(c))) break;
             ja.wave_scanned = (const uint64_t *)c->wave_counts.p;
             ja.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
             ja.out_key = (int32_t *)c->out_k[b].p;
@@ -1216,6 +1259,14 @@ int hj_partition_layout(hj_ctx *c, int rel, int *slotted) {
     return HJ_OK;
 }
 
+int hj_enable_timings(hj_ctx *c, int level) {
+    if (!c || level < 0 || level > 2) return HJ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_stamps(c);
+    c->events = level;
+    return HJ_OK;
+}
+
 int hj_timings_reset(hj_ctx *c) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1337,6 +1388,7 @@ int hj_verify_partitions(hj_ctx *c, int rel, uint64_t *misplaced, uint64_t *d_di
     Rel &R = c->rel[rel];
     if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
     HIPCHK(c, hipSetDevice(c->device));
+    RET(resolve_layout(c, R));
     uint64_t *sc = (uint64_t *)c->scalars.p;
     HIPCHK(c, hipMemsetAsync(sc + 4, 0, 8, c->stream));
     HIPCHK(c, launch_verify_partitions(c->stream, R.part_k, R.part_p, R.part_beg, R.part_end, R.nparts, 0, 0, sc + 4, d_digests, nullptr));

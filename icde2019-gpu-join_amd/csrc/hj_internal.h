@@ -42,7 +42,6 @@ struct PassArgs {
     int32_t *out_keys, *out_pays;
     uint64_t n_out;             // tuples of the pass (end of the last child partition)
     uint64_t *beg, *end;        // optional: child partition ranges for the join [nparents * P]
-    const uint32_t *run_if;     // optional device flag: every kernel of the pass returns at once when it is 0
 };
 
 // The histogram-free ("optimistic") passes.  Output slots have a fixed capacity: pass 1 gives every
@@ -74,6 +73,7 @@ struct JoinArgs {
     const int32_t *pk, *pp;  // probe side, partitioned
     const uint64_t *pbeg, *pend;
     uint64_t p_nalloc;
+    const uint32_t *bflag, *pflag; // overflow flags of histogram-free partitions (nullptr: ranges known good)
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
@@ -87,11 +87,11 @@ struct JoinArgs {
     uint64_t sb, sp;         // column stride (elements)
 };
 
-hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n);
+hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n, uint32_t *flag = nullptr);
 hipError_t launch_plan(hipStream_t st, const PassArgs &pa);
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out, const uint32_t *run_if = nullptr);
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
@@ -103,7 +103,8 @@ hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
 size_t scatter_lds_bytes(int threads, int u);
-hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt);
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2);
+hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);

@@ -15,8 +15,8 @@
 //         of its own — the reference's bump-allocated fixed-size buckets (jp.cu:138-192) with one owner per bucket, so
 //         no histogram, no scan, no global atomic.  A slot that would overflow (skew) raises a device flag;
 //       - exact passes (k_plan, k_hist, k_scan_*, k_offsets, k_scatter_wc): keys-only histogram, device-side scan,
-//         scatter to gap-free positions.  Queued behind the histogram-free passes, every kernel returns at once unless
-//         the flag is up (run_if) — the fallback needs no host round trip.
+//         scatter to gap-free positions.  The host queues them for a relation whose flag came back raised (the flag
+//         travels with the join's result block; the join kernels do nothing on flagged partitions).
 //     All three scatter kernels share one round machinery (wc_fast): a 1024-thread workgroup (wave64) appends
 //     (key,payload) pairs to per-digit 128-byte LDS write-combining lines and flushes only whole, 128-byte-aligned
 //     lines with 16-byte stores; a sorted-tile variant (k_scatter) serves narrow fan-out (the multi-GPU shard split).
@@ -159,10 +159,8 @@ __device__ __forceinline__ uint32_t rank_in_digit(uint32_t *cnt, uint32_t d, boo
 // One thread per segment: number of spans (<= span tuples each) it is cut into, and the exclusive prefix
 // of that.  span_start has nseg+1 entries.  Single workgroup, any nseg (chunks of 1024 with a carry).
 __global__ __launch_bounds__(1024) void k_plan(const uint64_t *__restrict__ sbeg, const uint64_t *__restrict__ send,
-                                               uint32_t nseg, uint32_t span, uint32_t *__restrict__ span_start,
-                                               const uint32_t *__restrict__ run_if) {
+                                               uint32_t nseg, uint32_t span, uint32_t *__restrict__ span_start) {
     __shared__ uint32_t scratch[17];
-    if (run_if && !*run_if) return;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nseg; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -214,9 +212,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
                                                        uint32_t nseg, uint32_t spp,
                                                        const uint32_t *__restrict__ span_start, uint32_t span,
                                                        uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                       uint32_t *__restrict__ hist, const uint32_t *__restrict__ run_if) {
+                                                       uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[MAX_PARTS];
-    if (run_if && !*run_if) return;
     SpanInfo si;
     if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
     for (uint32_t d = threadIdx.x; d < P; d += PART_THREADS) h[d] = 0;
@@ -243,10 +240,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
 // The value of entry i is then data[i] + chunk_prefix[i >> 12].  L = (*len_ptr) * mul, or mul. ----
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ data, const uint32_t *__restrict__ len_ptr,
-                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums,
-                                                             const uint32_t *__restrict__ run_if) {
+                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums) {
     __shared__ T scratch[17];
-    if (run_if && !*run_if) return;
     const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
     const uint64_t start = (uint64_t)blockIdx.x * SCAN_CHUNK;
     if (start >= L) return;
@@ -271,9 +266,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ dat
 // Single workgroup: exclusive scan of the chunk sums; chunk_prefix[nchunks] and *total_out = total.
 __global__ __launch_bounds__(1024) void k_scan_top(const uint64_t *__restrict__ chunk_sums, const uint32_t *__restrict__ len_ptr,
                                                    uint64_t mul, uint64_t *__restrict__ chunk_prefix,
-                                                   uint64_t *__restrict__ total_out, const uint32_t *__restrict__ run_if) {
+                                                   uint64_t *__restrict__ total_out) {
     __shared__ uint64_t scratch[17];
-    if (run_if && !*run_if) return;
     const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
     const uint64_t nchunks = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
     uint64_t carry = 0;
@@ -295,9 +289,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(const uint64_t *__restrict__ 
 // The same values go to beg[]/end[] (partition p = [beg[p], end[p])), the form the join reads.
 __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__restrict__ chunk_prefix,
                           const uint32_t *__restrict__ span_start, uint32_t nparents, uint32_t spp, uint32_t P,
-                          uint64_t n, uint64_t *__restrict__ coff, uint64_t *__restrict__ beg, uint64_t *__restrict__ end,
-                          const uint32_t *__restrict__ run_if) {
-    if (run_if && !*run_if) return;
+                          uint64_t n, uint64_t *__restrict__ coff, uint64_t *__restrict__ beg, uint64_t *__restrict__ end) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nchild = (uint64_t)nparents * P;
     if (t > nchild) return;
@@ -331,8 +323,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
                                                      const uint32_t *__restrict__ hist,
                                                      const uint64_t *__restrict__ chunk_prefix,
                                                      int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                     uint64_t n_out, const uint32_t *__restrict__ run_if) {
-    if (run_if && !*run_if) return;
+                                                     uint64_t n_out) {
     constexpr uint32_t TILE_T = THREADS * 4 * U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t *bufK = reinterpret_cast<int32_t *>(smem);
@@ -460,8 +451,9 @@ constexpr int WC_HSTRIDE = MAX_PARTS + 64; // arrival counters per parity + 64 p
 //   pass 2: workgroup d owns pass-1 digit d = the nspans slots (d, *) and splits them again; child c goes to slot
 //           (d, c) = out[(d*P + c)*cap ...] — the final partition.
 // Each pass writes the ranges [beg, end) of its slots; the join reads partitions as ranges.  A slot that would
-// overflow (skewed keys) raises *ovf, nothing is written past a slot, and the host side has the exact passes
-// queued behind, which run only when the flag is set (run_if).  Uniform and near-uniform inputs never overflow.
+// overflow (skewed keys) raises *ovf and nothing is written past a slot; the join's planning kernel reads the flags
+// and produces no work items, the host sees them with the result block and redoes that relation with the exact passes
+// (hj_api.hip).  Uniform and near-uniform inputs never overflow.
 // The per-round machinery (rank by one LDS atomic, per-digit write-combining lines, full lines leave as aligned
 // 128-byte stores) is that of k_scatter_wc; all lines are aligned here, so there is no first-line masking.
 constexpr int WF_TRASH_LINES = WC_THREADS / WC_LINE;   // one trash slot per thread (branch-free placement)
@@ -761,9 +753,8 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
                                                            const uint32_t *__restrict__ hist,
                                                            const uint64_t *__restrict__ chunk_prefix,
                                                            int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                           uint64_t n_out, const uint32_t *__restrict__ run_if) {
+                                                           uint64_t n_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (run_if && !*run_if) return;
     WfLds L_;
     wf_carve(L_, smem);
     SpanInfo si;
@@ -954,11 +945,18 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, 
 
 // items per partition: probe partition cut into chunks of <= chunk tuples (decompose_chains,
 // jp.cu:843-874, threshold = 2*bucket_size at hjcp.cu:904); no item when either side is empty.
+// bflag / pflag: overflow flags of relations whose histogram-free passes were queued (nullptr otherwise).  A raised
+// flag means the ranges are not valid: no items, the join kernels then do nothing and the host redoes the relation.
+// Thread 0 also zeroes the two result accumulators of k_sum2.
 __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
                             const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
-                            uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt) {
+                            uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt,
+                            const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
+                            uint64_t *__restrict__ zero2) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) { zero2[0] = 0; zero2[1] = 0; }
     if (p >= nparts) return;
+    if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[p] = 0; return; }
     uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
     items_cnt[p] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
 }
@@ -967,9 +965,11 @@ __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *_
 __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
                               const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                               uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
-                              const uint64_t *__restrict__ chunk_prefix, JoinItem *__restrict__ items) {
+                              const uint64_t *__restrict__ chunk_prefix, JoinItem *__restrict__ items,
+                              const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nparts) return;
+    if ((bflag && *bflag) || (pflag && *pflag)) return; // ranges not valid (k_join_plan counted no items)
     uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
     uint64_t at = (uint64_t)items_scanned[p] + chunk_prefix[p >> SCAN_CHUNK_LOG];
@@ -1156,6 +1156,17 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     }
 }
 
+// count-only result: sums of the per-wave match counts and aggregates into out[0], out[1] (zeroed by k_join_plan)
+__global__ __launch_bounds__(256) void k_sum2(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ agg,
+                                              const uint32_t *__restrict__ len_ptr, uint64_t mul, unsigned long long *__restrict__ out) {
+    const uint64_t L = (uint64_t)(*len_ptr) * mul;
+    uint64_t s = 0, t = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (uint64_t)gridDim.x * blockDim.x) { s += cnt[i]; t += agg[i]; }
+    s = wave_sum64(s);
+    t = wave_sum64(t);
+    if (lane_id() == 0) { if (s) atomicAdd(out, (unsigned long long)s); if (t) atomicAdd(out + 1, (unsigned long long)t); }
+}
+
 // sum of a device-sized uint64 array (per-wave aggregates) into *out (zeroed by the caller)
 __global__ __launch_bounds__(256) void k_reduce64(const uint64_t *__restrict__ data, const uint32_t *__restrict__ len_ptr,
                                                   uint64_t mul, unsigned long long *__restrict__ out) {
@@ -1174,7 +1185,7 @@ __global__ void k_fill(int32_t *__restrict__ p, uint64_t n, int mode, uint64_t f
         p[i] = mode == 1 ? (int32_t)(uint32_t)(first + i) : 1;
 }
 
-__global__ void k_set_root(uint64_t *poff, uint64_t n) { poff[0] = 0; poff[1] = n; }
+__global__ void k_set_root(uint64_t *poff, uint64_t n, uint32_t *flag) { poff[0] = 0; poff[1] = n; if (flag) *flag = 0; }
 
 // bijection on [0, 2^k): odd multiply, xorshift, add — four rounds keyed by the seed; cycle-walked
 // down to [0, domain).
@@ -1297,14 +1308,14 @@ static std::mutex g_attr_mutex;
 
 #define HJ_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n) {
-    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, st, poff, n);
+hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n, uint32_t *flag) {
+    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, st, poff, n, flag);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_plan(hipStream_t st, const PassArgs &pa) {
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, pa.sbeg, pa.send, pa.nseg, pa.span, pa.span_start, pa.run_if);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, pa.sbeg, pa.send, pa.nseg, pa.span, pa.span_start);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1312,20 +1323,20 @@ hipError_t launch_plan(hipStream_t st, const PassArgs &pa) {
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa) {
     dim3 g(pa.max_spans), b(PART_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.run_if);
+        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
     else
-        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.run_if);
+        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out, const uint32_t *run_if) {
+                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, run_if);
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
     HJ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out, run_if);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1334,9 +1345,9 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
     HJ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1344,7 +1355,7 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff) {
     uint64_t nthreads = (uint64_t)pa.nparents * pa.P + 1;
     hipLaunchKernelGGL(k_offsets, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, st, pa.hist, pa.chunk_prefix,
-                       pa.span_start, pa.nparents, pa.spp, pa.P, n, coff, pa.beg, pa.end, pa.run_if);
+                       pa.span_start, pa.nparents, pa.spp, pa.P, n, coff, pa.beg, pa.end);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1368,7 +1379,7 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
-                       pa.n_out, pa.run_if);
+                       pa.n_out);
     return hipGetLastError();
 }
 
@@ -1391,7 +1402,7 @@ static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
-                       pa.n_out, pa.run_if);
+                       pa.n_out);
     return hipGetLastError();
 }
 
@@ -1416,8 +1427,9 @@ hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs 
     }
 }
 
-hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt) {
-    hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt);
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2) {
+    hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt,
+                       a.bflag, a.pflag, zero2);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1425,7 +1437,7 @@ hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, 
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items) {
     hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
-                       items_scanned, chunk_prefix, items);
+                       items_scanned, chunk_prefix, items, a.bflag, a.pflag);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1555,6 +1567,12 @@ hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *b
     HJ_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_np_probe_chains, dim3(np_grid(np)), dim3(256), 0, st, pk, pp, np, mask, head, next, bk, bp,
                        reinterpret_cast<unsigned long long *>(out2));
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2) {
+    hipLaunchKernelGGL(k_sum2, dim3(512), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2));
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -258,6 +258,10 @@ class HashJoin:
                 self.device_free(dg)
         return bad.value, digests
 
+    def enable_timings(self, level=1):
+        """Per-kernel HIP-event timing: 0 off (default), 1 the data-moving kernels, 2 every launch."""
+        self._ck(self._L.hj_enable_timings(self._h, level))
+
     def timings_reset(self):
         self._ck(self._L.hj_timings_reset(self._h))
 

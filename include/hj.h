@@ -54,14 +54,17 @@ typedef struct hj_config {
     uint32_t exact_only;   /* 1: always run the histogram + scan + scatter passes (gap-free partitions).  0: two-pass
                             * partitioning first tries the histogram-free passes (fixed-capacity slots per partition, the
                             * bump-allocated buckets of jp.cu:138-192 without their atomics) and falls back to the exact
-                            * passes on the device when skew overflows a slot. */
+                            * passes when skew overflows a slot (the overflow flag travels with the join's result block; a
+                            * flagged relation is re-partitioned and the join re-run inside the same call). */
     uint32_t reserved[8];
 } hj_config;
 
 /* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream).
- * Timing of the data-moving kernels is on by default (HJ_KERNEL_EVENTS=none switches it off); finished
- * measurements are folded into the statistics at every [sync] call and whenever 256 are pending, so the
- * number of live HIP events is bounded whether or not hj_timings is ever called. */
+ * Off by default (two event records per timed launch cost ~0.1 ms per join step, 20-40 % of a 2^22-2^24 step):
+ * hj_enable_timings(ctx, 1) times the data-moving kernels (partition passes, join), 2 every launch; the environment
+ * variable HJ_KERNEL_EVENTS=main|all|none sets the initial level.  Finished measurements are folded into the
+ * statistics at every [sync] call and whenever 256 are pending, so the number of live HIP events is bounded whether
+ * or not hj_timings is ever called. */
 typedef struct hj_kernel_time {
     char name[32];
     uint32_t launches; /* launches since hj_timings_reset */
@@ -175,6 +178,7 @@ int hj_get_partitions(hj_ctx *ctx, int rel, const int32_t **d_keys, const int32_
                       const uint64_t **d_offsets, uint64_t *nparts);
 /* *slotted = 1 if the relation's partitions came from the histogram-free passes, 0 if from the exact passes. [sync] */
 int hj_partition_layout(hj_ctx *ctx, int rel, int *slotted);
+int hj_enable_timings(hj_ctx *ctx, int level); /* 0 off, 1 data-moving kernels, 2 every launch.  [sync] */
 int hj_timings_reset(hj_ctx *ctx);
 /* [sync] fills up to cap entries, returns the number of kernels known in *n. */
 int hj_timings(hj_ctx *ctx, hj_kernel_time *out, uint32_t cap, uint32_t *n);

@@ -7,6 +7,7 @@ pkg = g.load_package()
 dev = torch.device("cuda:0")
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
 hj = pkg.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream)
+hj.enable_timings(1)
 k, p, ok, op = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4))
 hj.gen_unique(k, n, 0, n, 1); hj.fill_payload(p, n, "rowid"); hj.sync()
 for G in (2, 3, 4, 8, 16, 64):
