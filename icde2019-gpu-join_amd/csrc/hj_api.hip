@@ -329,10 +329,10 @@ int pass_scatter(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa) {
 // beg/end: optional ranges of the child partitions for the join.
 int run_pass(hj_ctx *c, int wsid, int mode, const int32_t *in_k, const int32_t *in_p, uint64_t n, const uint64_t *poff,
              uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
-             uint64_t *coff, uint64_t *beg = nullptr, uint64_t *end = nullptr) {
+             uint64_t *coff, uint64_t *beg = nullptr, uint64_t *end = nullptr, const uint32_t *remap = nullptr) {
     PassArgs pa;
     RET(pass_prep(c, wsid, in_k, in_p, n, poff, nparents, shift, P, mask_or_n, out_k, out_p, pa));
-    pa.beg = beg; pa.end = end;
+    pa.beg = beg; pa.end = end; pa.remap = remap;
     RET(pass_hist(c, c->stream, mode, pa, n, coff));
     return pass_scatter(c, c->stream, mode, pa);
 }
@@ -1292,8 +1292,8 @@ int hj_timings(hj_ctx *c, hj_kernel_time *out, uint32_t cap, uint32_t *n) {
     return HJ_OK;
 }
 
-int hj_shard_split(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint32_t nshards,
-                   int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts) {
+int hj_shard_split_ordered(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint32_t nshards,
+                           const uint32_t *h_position, int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts) {
     if (!c) return HJ_EINVAL;
     if (nshards == 0 || nshards > (uint32_t)MAX_PARTS) return fail(c, HJ_EINVAL, "nshards out of range");
     if (n && (!d_keys || !d_pays || !d_out_keys || !d_out_pays)) return fail(c, HJ_EINVAL, "null column");
@@ -1302,14 +1302,46 @@ int hj_shard_split(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint
     // persistent small buffers: no hipMalloc/hipFree in the steady state (hipFree synchronises the whole
     // device and would stall an all-to-all that is in flight on another stream)
     RET(ensure(c, c->shard_root, 16));
-    RET(ensure(c, c->shard_off, (size_t)(MAX_PARTS + 1) * 8));
-    if (!c->h_shard_off) HIPCHK(c, hipHostMalloc((void **)&c->h_shard_off, (size_t)(MAX_PARTS + 1) * 8, hipHostMallocDefault));
+    RET(ensure(c, c->shard_off, (size_t)(MAX_PARTS + 1) * 8 + (size_t)MAX_PARTS * 4));
+    if (!c->h_shard_off) HIPCHK(c, hipHostMalloc((void **)&c->h_shard_off, (size_t)(MAX_PARTS + 1) * 8 + (size_t)MAX_PARTS * 4, hipHostMallocDefault));
+    uint32_t *d_remap = nullptr;
+    if (h_position) { // shard v goes to output position h_position[v] (a permutation of 0..nshards-1)
+        std::vector<uint8_t> seen(nshards, 0);
+        for (uint32_t i = 0; i < nshards; i++) {
+            if (h_position[i] >= nshards || seen[h_position[i]]) return fail(c, HJ_EINVAL, "position table is not a permutation");
+            seen[h_position[i]] = 1;
+        }
+        uint32_t *h_remap = reinterpret_cast<uint32_t *>(c->h_shard_off + MAX_PARTS + 1);
+        memcpy(h_remap, h_position, (size_t)nshards * 4);
+        d_remap = reinterpret_cast<uint32_t *>((uint64_t *)c->shard_off.p + MAX_PARTS + 1);
+        HIPCHK(c, hipMemcpyAsync(d_remap, h_remap, (size_t)nshards * 4, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, launch_set_root(c->stream, (uint64_t *)c->shard_root.p, n));
     RET(run_pass(c, 0, 1, d_keys, d_pays, n, (const uint64_t *)c->shard_root.p, 1, 0, nshards, nshards, d_out_keys, d_out_pays,
-                 (uint64_t *)c->shard_off.p));
+                 (uint64_t *)c->shard_off.p, nullptr, nullptr, d_remap));
     HIPCHK(c, hipMemcpyAsync(c->h_shard_off, c->shard_off.p, (size_t)(nshards + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_counts) for (uint32_t i = 0; i < nshards; i++) h_counts[i] = c->h_shard_off[i + 1] - c->h_shard_off[i];
+    return HJ_OK;
+}
+
+int hj_shard_split(hj_ctx *c, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint32_t nshards,
+                   int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts) {
+    return hj_shard_split_ordered(c, d_keys, d_pays, n, nshards, nullptr, d_out_keys, d_out_pays, h_counts);
+}
+
+int hj_shard_count(hj_ctx *c, const int32_t *d_keys, uint64_t n, uint32_t nshards, uint64_t *h_counts) {
+    if (!c || !h_counts) return HJ_EINVAL;
+    if (nshards == 0 || nshards > (uint32_t)MAX_PARTS) return fail(c, HJ_EINVAL, "nshards out of range");
+    if (n && !d_keys) return fail(c, HJ_EINVAL, "null column");
+    HIPCHK(c, hipSetDevice(c->device));
+    RET(ensure(c, c->shard_off, (size_t)(MAX_PARTS + 1) * 8 + (size_t)MAX_PARTS * 4));
+    if (!c->h_shard_off) HIPCHK(c, hipHostMalloc((void **)&c->h_shard_off, (size_t)(MAX_PARTS + 1) * 8 + (size_t)MAX_PARTS * 4, hipHostMallocDefault));
+    HIPCHK(c, hipMemsetAsync(c->shard_off.p, 0, (size_t)nshards * 8, c->stream));
+    if (n) HIPCHK(c, launch_shard_count(c->stream, d_keys, n, nshards, (uint64_t *)c->shard_off.p));
+    HIPCHK(c, hipMemcpyAsync(c->h_shard_off, c->shard_off.p, (size_t)nshards * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < nshards; i++) h_counts[i] = c->h_shard_off[i];
     return HJ_OK;
 }
 

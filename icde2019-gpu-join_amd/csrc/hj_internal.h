@@ -42,6 +42,7 @@ struct PassArgs {
     int32_t *out_keys, *out_pays;
     uint64_t n_out;             // tuples of the pass (end of the last child partition)
     uint64_t *beg, *end;        // optional: child partition ranges for the join [nparents * P]
+    const uint32_t *remap;      // optional (shard digits): output position of each shard
 };
 
 // The histogram-free ("optimistic") passes.  Output slots have a fixed capacity: pass 1 gives every
@@ -124,6 +125,7 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
                                     const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
+hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts);
 uint32_t host_shard_of(int32_t key, uint32_t nshards);
 
 } // namespace hj

@@ -60,10 +60,12 @@ __device__ __forceinline__ uint64_t mix_triple(int32_t key, int32_t pr, int32_t 
 // Partition function.  MODE 0: the reference's (hasht(key) >> first_bit) & (parts-1) with hasht =
 // identity (common.h:45-47, jp.cu:126).  MODE 1: shard id for the multi-GPU level-0 split, a
 // multiplicative range reduction of a murmur-finalised key (independent of the low radix bits).
+// remap (MODE 1, optional): output position of each shard — the multi-GPU driver orders virtual shards by owner GPU.
 template <int MODE>
-__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t shift, uint32_t mask_or_n) {
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t shift, uint32_t mask_or_n, const uint32_t *__restrict__ remap = nullptr) {
     if (MODE == 0) return (key >> shift) & mask_or_n;
-    return (uint32_t)(((uint64_t)fmix32(key) * mask_or_n) >> 32);
+    const uint32_t d = (uint32_t)(((uint64_t)fmix32(key) * mask_or_n) >> 32);
+    return remap ? remap[d] : d;
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
                                                        uint32_t nseg, uint32_t spp,
                                                        const uint32_t *__restrict__ span_start, uint32_t span,
                                                        uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                       uint32_t *__restrict__ hist) {
+                                                       uint32_t *__restrict__ hist, const uint32_t *__restrict__ remap) {
     __shared__ uint32_t h[MAX_PARTS];
     SpanInfo si;
     if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
         for (int e = 0; e < 4; e++) {
             uint64_t idx = i + e;
             const bool valid = idx >= si.lo && idx < si.hi;
-            (void)rank_in_digit(h, digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n), valid);
+            (void)rank_in_digit(h, digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n, remap), valid);
         }
     }
     __syncthreads();
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
                                                      const uint32_t *__restrict__ hist,
                                                      const uint64_t *__restrict__ chunk_prefix,
                                                      int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                     uint64_t n_out) {
+                                                     uint64_t n_out, const uint32_t *__restrict__ remap) {
     constexpr uint32_t TILE_T = THREADS * 4 * U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t *bufK = reinterpret_cast<int32_t *>(smem);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
                 uint64_t idx = i + e;
                 uint32_t code = 0xFFFFFFFFu;
                 if (idx >= si.lo && idx < si.hi) {
-                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n);
+                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n, remap);
                     code = (d << 16) | atomicAdd(&h[d], 1u);
                 }
                 dr[u * 4 + e] = code;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__
             uint32_t i = j * THREADS + tid;
             if (i < tile_cnt) {
                 int32_t key = bufK[i], pay = bufP[i];
-                uint32_t o = delta[digit_of<MODE>((uint32_t)key, shift, mask_or_n)] + i;
+                uint32_t o = delta[digit_of<MODE>((uint32_t)key, shift, mask_or_n, remap)] + i;
                 out_keys[o] = key;
                 out_pays[o] = pay;
             }
@@ -867,6 +869,30 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     __syncthreads();
     if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// tuples per shard (MODE 1 digit, no remap): per-workgroup LDS histogram, one global atomic per shard per workgroup
+__global__ __launch_bounds__(512) void k_shard_count(const int32_t *__restrict__ keys, uint64_t n, uint32_t nshards,
+                                                     unsigned long long *__restrict__ counts) {
+    __shared__ uint32_t h[MAX_PARTS];
+    for (uint32_t d = threadIdx.x; d < nshards; d += blockDim.x) h[d] = 0;
+    __syncthreads();
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t w0 = lo + (threadIdx.x & ~63u); w0 < hi; w0 += blockDim.x) { // wave-uniform trip count
+        const uint64_t i = w0 + lane_id();
+        const bool valid = i < hi;
+        (void)rank_in_digit(h, valid ? digit_of<1>((uint32_t)keys[i], 0, nshards) : 0u, valid);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nshards; d += blockDim.x)
+        if (h[d]) atomicAdd(&counts[d], (unsigned long long)h[d]);
+}
+
+hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts) {
+    const uint32_t blocks = (uint32_t)(n / 65536 < 1 ? 1 : (n / 65536 > 4096 ? 4096 : n / 65536));
+    hipLaunchKernelGGL(k_shard_count, dim3(blocks), dim3(512), 0, st, keys, n, nshards, reinterpret_cast<unsigned long long *>(counts));
+    return hipGetLastError();
 }
 
 // ---- on-box ceilings for the roofline (bench.py): what the HBM system gives the two access patterns of a radix
@@ -1323,9 +1349,9 @@ hipError_t launch_plan(hipStream_t st, const PassArgs &pa) {
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa) {
     dim3 g(pa.max_spans), b(PART_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+        hipLaunchKernelGGL(k_hist<0>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, (const uint32_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist);
+        hipLaunchKernelGGL(k_hist<1>, g, b, 0, st, pa.keys, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp, pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.remap);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1379,7 +1405,7 @@ static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
-                       pa.n_out);
+                       pa.n_out, pa.remap);
     return hipGetLastError();
 }
 

@@ -15,7 +15,14 @@ import torch.distributed as dist
 
 
 class ShardedJoin:
-    def __init__(self, engine, pkg, device, group=None):
+    VIRTUAL = 8   # balance="size": virtual shards per GPU
+
+    def __init__(self, engine, pkg, device, group=None, balance="hash"):
+        """balance="hash": GPU g owns hash shard g (uniform keys).  balance="size": 8 virtual shards per GPU, assigned to
+        GPUs by their global size (longest-processing-time first over |R|+|S| per shard) so that a heavy hitter's shard
+        shares its GPU with few others — the reference's size-aware placement idea (partition-primitives.cu:307-468)."""
+        assert balance in ("hash", "size")
+        self.balance = balance
         self.e = engine
         self.pkg = pkg
         self.dev = device
@@ -86,6 +93,33 @@ class ShardedJoin:
             w.wait()
         return out, total
 
+    @staticmethod
+    def assign_by_size(sizes, world):
+        """Longest-processing-time-first assignment of shards to GPUs; deterministic (ties by index) so that every
+        rank computes the same map.  Returns (owner[v], position[v]) with shards ordered by (owner, v)."""
+        load = [0] * world
+        owner = [0] * len(sizes)
+        for v in sorted(range(len(sizes)), key=lambda i: (-sizes[i], i)):
+            g = min(range(world), key=lambda j: (load[j], j))
+            owner[v] = g
+            load[g] += sizes[v]
+        order = sorted(range(len(sizes)), key=lambda v: (owner[v], v))
+        position = [0] * len(sizes)
+        for pos, v in enumerate(order):
+            position[v] = pos
+        return owner, position
+
+    def _split(self, k, p, n, out_k, out_p, plan):
+        """Level-0 split of one relation: per-GPU send counts.  plan = None (hash shard g -> GPU g) or (owner, position)."""
+        if plan is None:
+            return self.e.shard_split(k, p, n, self.world, out_k, out_p)
+        owner, position = plan
+        per_pos = self.e.shard_split_ordered(k, p, n, len(owner), position, out_k, out_p)
+        counts = [0] * self.world
+        for v, pos in enumerate(position):
+            counts[owner[v]] += per_pos[pos]
+        return counts
+
     def _allreduce_u64(self, vals):
         """Sum 64-bit values over the ranks mod 2^64 (as 32-bit halves: the int64 SUM cannot overflow)."""
         halves = []
@@ -119,11 +153,21 @@ class ShardedJoin:
             self.last_received = (nR, nS)
             m, agg = e.join_count()
             return tuple(self._allreduce_u64([m, agg]))
+        plan = None
+        if self.balance == "size":
+            # which GPU owns which virtual shard must be the same for R and S: count both first (keys only, no data
+            # movement), add up over the ranks, assign by size
+            ns = w * self.VIRTUAL
+            local = [a + b for a, b in zip(e.shard_count(Rk, nR, ns), e.shard_count(Sk, nS, ns))]
+            t = torch.tensor(local, dtype=torch.int64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
+            plan = self.assign_by_size([int(x) for x in t.tolist()], w)
+            self.last_plan = plan
         okR, opR = self._get("split_kR", nR), self._get("split_pR", nR)
-        cR = e.shard_split(Rk, Rp, nR, w, okR, opR)              # level-0 radix split, contiguous per owner
+        cR = self._split(Rk, Rp, nR, okR, opR, plan)             # level-0 split, one contiguous run per owner
         gotR, totR, workR = self.exchange_async({"kR": okR, "pR": opR}, cR)
         okS, opS = self._get("split_kS", nS), self._get("split_pS", nS)
-        cS = e.shard_split(Sk, Sp, nS, w, okS, opS)              # runs while R is on the links
+        cS = self._split(Sk, Sp, nS, okS, opS, plan)             # runs while R is on the links
         gotS, totS, workS = self.exchange_async({"kS": okS, "pS": opS}, cS)
         for wk in workR:
             wk.wait()

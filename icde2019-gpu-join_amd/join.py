@@ -279,6 +279,19 @@ class HashJoin:
                                         _dev_ptr(out_pays), counts))
         return [int(c) for c in counts]
 
+    def shard_count(self, keys, n, nshards):
+        counts = (C.c_uint64 * nshards)()
+        self._ck(self._L.hj_shard_count(self._h, _dev_ptr(keys), n, nshards, counts))
+        return [int(c) for c in counts]
+
+    def shard_split_ordered(self, keys, pays, n, nshards, position, out_keys, out_pays):
+        """position[v] = output position of shard v; returns the tuple counts per output position."""
+        counts = (C.c_uint64 * nshards)()
+        pos = (C.c_uint32 * nshards)(*[int(x) for x in position])
+        self._ck(self._L.hj_shard_split_ordered(self._h, _dev_ptr(keys), _dev_ptr(pays), n, nshards, pos, _dev_ptr(out_keys),
+                                                _dev_ptr(out_pays), counts))
+        return [int(c) for c in counts]
+
     def gen_unique(self, d_keys, n, first, domain, seed):
         self._ck(self._L.hj_gen_unique(self._h, _dev_ptr(d_keys), n, first, domain, seed))
 

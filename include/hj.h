@@ -189,6 +189,14 @@ int hj_timings(hj_ctx *ctx, hj_kernel_time *out, uint32_t cap, uint32_t *n);
  *      are what an all-to-all over xGMI exchanges.  [sync] ---- */
 int hj_shard_split(hj_ctx *ctx, const int32_t *d_keys, const int32_t *d_pays, uint64_t n,
                    uint32_t nshards, int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts);
+/* The same with more (virtual) shards than GPUs, for size-aware assignment under skew (the reference's knapsack idea,
+ * partition-primitives.cu:307-468): hj_shard_count gives the tuples per shard of one column (no data movement);
+ * the caller decides which GPU owns which shard and passes h_position[v] = output position of shard v (a
+ * permutation of 0..nshards-1, e.g. shards ordered by owner), so that every owner's tuples form ONE contiguous
+ * run.  h_counts[i] = tuples at output position i.  NULL h_position = identity.  [sync] */
+int hj_shard_count(hj_ctx *ctx, const int32_t *d_keys, uint64_t n, uint32_t nshards, uint64_t *h_counts);
+int hj_shard_split_ordered(hj_ctx *ctx, const int32_t *d_keys, const int32_t *d_pays, uint64_t n, uint32_t nshards,
+                           const uint32_t *h_position, int32_t *d_out_keys, int32_t *d_out_pays, uint64_t *h_counts);
 /* destination shard of a key (host-side mirror of the device function, for tests/oracles) */
 uint32_t hj_shard_of(int32_t key, uint32_t nshards);
 

@@ -29,6 +29,20 @@ class OracleEngine:
         out_pays[:n] = torch.from_numpy(p[order])
         return [int((owner == s).sum()) for s in range(nshards)]
 
+    def shard_count(self, keys, n, nshards):
+        k = keys[:n].numpy()
+        owner = np.array([self.pkg.shard_of(int(x), nshards) for x in k], dtype=np.int64) if n else np.empty(0, np.int64)
+        return np.bincount(owner, minlength=nshards).tolist()
+
+    def shard_split_ordered(self, keys, pays, n, nshards, position, out_keys, out_pays):
+        k, p = keys[:n].numpy(), pays[:n].numpy()
+        pos = np.asarray(position, dtype=np.int64)
+        where = pos[np.array([self.pkg.shard_of(int(x), nshards) for x in k], dtype=np.int64)] if n else np.empty(0, np.int64)
+        order = np.argsort(where, kind="stable")
+        out_keys[:n] = torch.from_numpy(k[order])
+        out_pays[:n] = torch.from_numpy(p[order])
+        return np.bincount(where, minlength=nshards).tolist()
+
     def bind_device(self, rel, keys, pays, n):
         self.rel[rel] = (keys, pays, n)      # like the real engine: the data is read at partition time
 
@@ -63,7 +77,7 @@ def main():
         dist.init_process_group("gloo")
         engine = OracleEngine(pkg)
     from importlib import import_module
-    dj = import_module(pkg.__name__ + ".dist").ShardedJoin(engine, pkg, dev)
+    dj = import_module(pkg.__name__ + ".dist").ShardedJoin(engine, pkg, dev, balance=os.environ.get("HJ_DIST_BALANCE", "hash"))
     dj.force_exchange = os.environ.get("HJ_DIST_FORCE_EXCHANGE") == "1"
     if "HJ_DIST_CHUNK" in os.environ:       # force several point-to-point chunks per peer
         dj.CHUNK = int(os.environ["HJ_DIST_CHUNK"])
@@ -92,6 +106,8 @@ def main():
         nR, nS = (int(x) for x in os.environ["HJ_DIST_N"].split(","))
     R = rng.integers(-5000, 5000, nR).astype(np.int32)
     S = rng.integers(-5000, 5000, nS).astype(np.int32)
+    if os.environ.get("HJ_DIST_SKEW"):      # one key holds 30 % of S: the heavy hitter's shard must not drag its GPU down
+        S[rng.random(nS) < 0.3] = 1234
     Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
     Ps = np.arange(nS, dtype=np.int32)
 
@@ -102,6 +118,10 @@ def main():
     res = []
     for i in range(2):  # twice: buffers are reused across steps; the first with the exchange check on
         res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS), verify=(i == 0)))
+    mine = torch.tensor(list(dj.last_received), dtype=torch.int64, device=dev)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    recv = [[int(x) for x in t.tolist()] for t in allr]
     # an empty local slice on one rank must work too
     e = torch.empty(0, dtype=torch.int32, device=dev)
     if rank == 0:
@@ -112,7 +132,7 @@ def main():
         em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
         lo = nR // world
         em3, eagg3, _ = o.join_count(R[lo:], Pr[lo:], S, Ps, checksum=False)
-        print("RESULT " + json.dumps({"got": res, "expect": [[em, eagg], [em, eagg], [em3, eagg3]]}))
+        print("RESULT " + json.dumps({"got": res, "expect": [[em, eagg], [em, eagg], [em3, eagg3]], "received": recv}))
     dist.destroy_process_group()
 
 

@@ -31,6 +31,31 @@ def test_sharded_join_gloo_world2_chunked_messages():
     assert res["got"] == res["expect"]
 
 
+def test_sharded_join_gloo_world2_size_aware_assignment():
+    """balance="size": virtual shards assigned to GPUs by global size.  One key holds 30 % of S; with plain hash
+    sharding its GPU receives ~65 % of S, with size-aware assignment the received tuples are close to even."""
+    res_hash = _run(2, {"HJ_DIST_SKEW": "1"}, 29651)
+    res_size = _run(2, {"HJ_DIST_SKEW": "1", "HJ_DIST_BALANCE": "size"}, 29653)
+    assert res_hash["got"] == res_hash["expect"] and res_size["got"] == res_size["expect"]
+    tot = lambda r: [a + b for a, b in r["received"]]
+    imb = lambda r: max(tot(r)) / (sum(tot(r)) / len(tot(r)))
+    assert imb(res_hash) > 1.15 and imb(res_size) < 1.08, (res_hash["received"], res_size["received"])
+
+
+def test_assign_by_size_is_deterministic_and_balanced():
+    from importlib import import_module
+    SJ = import_module(pkg().__name__ + ".dist").ShardedJoin
+    sizes = [100, 7, 7, 7, 50, 50, 3, 3, 90, 1, 1, 1, 40, 40, 20, 20]
+    owner, position = SJ.assign_by_size(sizes, 4)
+    assert sorted(position) == list(range(16))
+    loads = [sum(s for s, o in zip(sizes, owner) if o == g) for g in range(4)]
+    assert max(loads) - min(loads) <= 10 and max(loads) <= 1.05 * sum(sizes) / 4 + 10
+    # shards of one owner are contiguous in output order
+    by_pos = sorted(range(16), key=lambda v: position[v])
+    assert [owner[v] for v in by_pos] == sorted(owner)
+    assert SJ.assign_by_size(sizes, 4) == (owner, position)
+
+
 def test_shard_function_is_balanced_and_total():
     p = pkg()
     keys = np.arange(-20000, 20000, dtype=np.int32)
@@ -51,6 +76,8 @@ def test_sharded_join_rccl_world1():
     assert res["got"] == res["expect"]
     res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_BIG": "26"}, 29645)   # device-generated inputs
     assert res["got"] == res["expect"]
+    res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_BALANCE": "size", "HJ_DIST_SKEW": "1"}, 29647)
+    assert res["got"] == res["expect"]
 
 
 def _gpu_count():
@@ -69,6 +96,8 @@ def test_sharded_join_rccl_world2():
     res = _run(2, {"HJ_DIST_GPU": "1", "HJ_DIST_N": "3000000,7000001", "HJ_DIST_CHUNK": "300000"}, 29646)
     assert res["got"] == res["expect"]
     res = _run(2, {"HJ_DIST_GPU": "1"}, 29648)
+    assert res["got"] == res["expect"]
+    res = _run(2, {"HJ_DIST_GPU": "1", "HJ_DIST_BALANCE": "size", "HJ_DIST_SKEW": "1"}, 29652)
     assert res["got"] == res["expect"]
     # 2^30 tuples per relation per rank: a peer's share of a column is 2^29 elements (2 GiB) → several 512-MiB chunks
     res = _run(2, {"HJ_DIST_GPU": "1", "HJ_DIST_BIG": "30"}, 29650)
@@ -97,3 +126,16 @@ def test_shard_split_parity():
             seg = gk[off[s]:off[s + 1]]
             assert np.all(np.array([p.shard_of(int(x), w) for x in seg[:2000]]) == s)
         assert sorted(gv.tolist()) == list(range(n))                       # a permutation: nothing lost or duplicated
+        # virtual shards in caller-chosen order (size-aware assignment): counts per shard, then an ordered split
+        ns = w * 8
+        own = np.array([p.shard_of(int(x), ns) for x in k])
+        with p.HashJoin(0) as hj:
+            assert hj.shard_count(dk, n, ns) == np.bincount(own, minlength=ns).tolist()
+            position = rng.permutation(ns).tolist()
+            per_pos = hj.shard_split_ordered(dk, dv, n, ns, position, ok, ov)
+        where = np.asarray(position)[own]
+        assert per_pos == np.bincount(where, minlength=ns).tolist()
+        gk, gv = ok.cpu().numpy(), ov.cpu().numpy()
+        assert np.array_equal(k[gv], gk) and sorted(gv.tolist()) == list(range(n))
+        off = np.concatenate([[0], np.cumsum(per_pos)])
+        assert np.all(np.diff(where[gv]) >= 0)                             # output runs follow the requested positions
