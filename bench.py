@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
     ap.add_argument("--lds", type=int, nargs=2, default=None, help="experiment knob: LDS table capacity and heads of the join kernel")
     ap.add_argument("--exact-only", action="store_true", help="histogram + scan + scatter passes only (no histogram-free passes)")
+    ap.add_argument("--balance", choices=["hash", "size"], default="hash",
+                    help="multi-GPU level-0 assignment: hash shard g -> GPU g, or 8 virtual shards per GPU assigned by size")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even at world size 1 (sanity runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
@@ -356,7 +358,7 @@ def main():
     dj = None
     if use_dist:
         from importlib import import_module
-        dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev)
+        dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev, balance=a.balance)
 
     def step(verify=False):
         if not use_dist:
