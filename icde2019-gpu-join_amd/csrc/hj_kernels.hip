@@ -922,7 +922,11 @@ __global__ __launch_bounds__(256) void k_ubench(const int4 *__restrict__ ik, con
             const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
             if (u < n16) {
                 uint64_t o = u;
-                if (KIND == 1) o = ((((u >> (3 + (nt >> 4))) * mul) & (line_mask >> (nt >> 4))) << (3 + (nt >> 4))) | (u & ((8u << (nt >> 4)) - 1)); // nt >> 4: log2 lines per scattered chunk (experiments)
+                if (KIND == 1) {
+                    const int lg = (nt >> 4) == 15 ? -1 : (nt >> 4); // experiments: log2 lines per scattered chunk; 15 = half lines (64 B)
+                    if (lg >= 0) o = ((((u >> (3 + lg)) * mul) & (line_mask >> lg)) << (3 + lg)) | (u & ((8u << lg) - 1));
+                    else o = ((((u >> 2) * mul) & (line_mask * 2 + 1)) << 2) | (u & 3);
+                }
                 if (nt & 1) { st_nt(ok + o, a[j]); st_nt(op + o, b[j]); } else { ok[o] = a[j]; op[o] = b[j]; }
             }
         }
