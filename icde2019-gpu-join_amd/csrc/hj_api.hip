@@ -83,7 +83,6 @@ struct hj_ctx {
     uint64_t last_matches = 0, last_agg = 0;
     uint32_t max_items = 0;
     uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
-    int scatter_variant = -1;
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
@@ -326,10 +325,7 @@ int pass_hist(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa, uint64_t 
 }
 
 int pass_scatter(hj_ctx *c, hipStream_t st, int mode, const PassArgs &pa) {
-    // wide fan-out: LDS write-combining lines (aligned 128-B stores); narrow fan-out (shard split, small
-    // inputs): the sorted-tile kernel, whose runs are long anyway.  HJ_SCATTER_VARIANT overrides (experiments).
-    const int variant = c->scatter_variant >= 0 ? c->scatter_variant : ((mode == 0 && pa.P >= 64) ? 4 : 1);
-    { Timed t(c, variant >= 4 ? "k_scatter_wc" : "k_scatter", st, true); HIPCHK(c, launch_scatter(st, mode, variant, pa)); }
+    { Timed t(c, "k_scatter_wc", st, true); HIPCHK(c, launch_scatter(st, mode, pa)); }
     return 0;
 }
 
@@ -612,8 +608,6 @@ int hj_create(hj_ctx **out, int device) {
     memset(c->h_scalars, 0, 128);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
-    const char *sv = getenv("HJ_SCATTER_VARIANT"); // experiment knob: tile geometry of k_scatter
-    if (sv) c->scatter_variant = atoi(sv);
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     *out = c;
     return HJ_OK;

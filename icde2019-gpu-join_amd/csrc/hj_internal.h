@@ -96,14 +96,13 @@ hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_p
 hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
-hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa);
+hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
-size_t scatter_lds_bytes(int threads, int u);
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2);
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,

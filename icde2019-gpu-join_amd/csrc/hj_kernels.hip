@@ -19,7 +19,7 @@
 //         travels with the join's result block; the join kernels do nothing on flagged partitions).
 //     All three scatter kernels share one round machinery (wc_fast): a 1024-thread workgroup (wave64) appends
 //     (key,payload) pairs to per-digit 128-byte LDS write-combining lines and flushes only whole, 128-byte-aligned
-//     lines with 16-byte stores; a sorted-tile variant (k_scatter) serves narrow fan-out (the multi-GPU shard split).
+//     lines with 16-byte stores, at any fan-out from 2 to 512 (the multi-GPU shard split uses the same kernel).
 //     Nothing is read back to the host between kernels; grids are launched at their upper bound.
 //   * the join kernel builds a chained hash table in LDS per build partition (16-bit tags when the
 //     radix bits leave <= 16 key bits, full keys otherwise) and probes it with coalesced 16-byte
@@ -308,127 +308,6 @@ __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__r
     if (end && t > 0) end[t - 1] = v;
 }
 
-// Scatter one span.  Per tile (THREADS*4*U tuples): LDS histogram with ranks (one returning LDS
-// atomic per tuple), workgroup scan, keys AND payloads reordered together through two LDS buffers so
-// that each digit's tuples are consecutive, then ONE write-out pass in which consecutive lanes store
-// consecutive positions of the span's private output run of that digit (the tile-reorder idea of
-// jp.cu:203-278, with contiguous per-span output regions instead of bucket chains, so consecutive
-// tiles extend the same cache lines from the same CU).  The next tile's 16-byte loads are issued
-// before the write-out so HBM reads stay in flight across the barriers.  5 barriers per tile.
-// Algorithmic traffic: 8 B read + 8 B written per tuple.
-template <int MODE, int THREADS, int U>
-__global__ __launch_bounds__(THREADS) void k_scatter(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
-                                                     uint64_t nalloc, const uint64_t *__restrict__ sbeg,
-                                                     const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
-                                                     const uint32_t *__restrict__ span_start,
-                                                     uint32_t span, uint32_t shift, uint32_t P, uint32_t mask_or_n,
-                                                     const uint32_t *__restrict__ hist,
-                                                     const uint64_t *__restrict__ chunk_prefix,
-                                                     int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                     uint64_t n_out, const uint32_t *__restrict__ remap) {
-    constexpr uint32_t TILE_T = THREADS * 4 * U;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t *bufK = reinterpret_cast<int32_t *>(smem);
-    int32_t *bufP = bufK + TILE_T;
-    uint32_t *h = reinterpret_cast<uint32_t *>(bufP + TILE_T); // per-tile count of each digit
-    uint32_t *delta = h + MAX_PARTS;                            // output position minus tile slot, per digit
-    uint32_t *gbase = delta + MAX_PARTS;                        // next output position of each digit (n < 2^32)
-    uint32_t *scratch = gbase + MAX_PARTS;                      // 32 words
-    SpanInfo si;
-    if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
-    const uint32_t tid = threadIdx.x, wv = tid >> 6;
-    for (uint32_t d = tid; d < P; d += THREADS) {
-        uint64_t idx = (uint64_t)si.first * P + (uint64_t)d * si.nsp + si.s;
-        gbase[d] = (uint32_t)((uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG]);
-        h[d] = 0;
-    }
-    const uint64_t a0 = si.lo & ~(uint64_t)3;
-    int4 kv[U], pv[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        uint64_t i = a0 + ((uint64_t)u * THREADS + tid) * 4;
-        kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
-        pv[u] = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    for (uint64_t t0 = a0; t0 < si.hi; t0 += TILE_T) {
-        // ---- A: rank of every tuple inside its digit ----
-        uint32_t dr[U * 4]; // digit << 16 | rank ; 0xFFFFFFFF = not a tuple of this span
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint64_t i = t0 + ((uint64_t)u * THREADS + tid) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                uint64_t idx = i + e;
-                uint32_t code = 0xFFFFFFFFu;
-                if (idx >= si.lo && idx < si.hi) {
-                    uint32_t d = digit_of<MODE>((uint32_t)elem(kv[u], e), shift, mask_or_n, remap);
-                    code = (d << 16) | atomicAdd(&h[d], 1u);
-                }
-                dr[u * 4 + e] = code;
-            }
-        }
-        __syncthreads();
-        // ---- B: exclusive scan of the tile histogram (P <= 512 <= THREADS: one digit per thread);
-        //         the owner thread of a digit also advances its output cursor and clears its count ----
-        uint32_t cnt = tid < P ? h[tid] : 0;
-        uint32_t incl = wave_incl_scan(cnt);
-        if (lane_id() == 63) scratch[wv] = incl;
-        __syncthreads();
-        uint32_t wpre = 0, tile_cnt = 0;
-#pragma unroll
-        for (int w = 0; w < THREADS / 64; w++) {
-            uint32_t t = scratch[w];
-            if (w < (int)wv) wpre += t;
-            tile_cnt += t;
-        }
-        if (tid < P) {
-            uint32_t ex = wpre + incl - cnt;
-            uint32_t g = gbase[tid];
-            delta[tid] = g - ex;
-            h[tid] = ex;          // h becomes the tile-local start of the digit for step C
-            gbase[tid] = g + cnt;
-        }
-        __syncthreads();
-        // ---- C: keys and payloads into digit order ----
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                uint32_t code = dr[u * 4 + e];
-                if (code != 0xFFFFFFFFu) {
-                    uint32_t slot = h[code >> 16] + (code & 0xFFFFu);
-                    bufK[slot] = elem(kv[u], e);
-                    bufP[slot] = elem(pv[u], e);
-                }
-            }
-        // ---- prefetch the next tile while this one is written out ----
-        {
-            const uint64_t t1 = t0 + TILE_T;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint64_t i = t1 + ((uint64_t)u * THREADS + tid) * 4;
-                kv[u] = (i < si.hi) ? load4(keys, i, nalloc) : make_int4(0, 0, 0, 0);
-                pv[u] = (i < si.hi) ? load4(pays, i, nalloc) : make_int4(0, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        // ---- D: one write-out pass: consecutive lanes → consecutive output positions ----
-#pragma unroll
-        for (int j = 0; j < U * 4; j++) {
-            uint32_t i = j * THREADS + tid;
-            if (i < tile_cnt) {
-                int32_t key = bufK[i], pay = bufP[i];
-                uint32_t o = delta[digit_of<MODE>((uint32_t)key, shift, mask_or_n, remap)] + i;
-                out_keys[o] = key;
-                out_pays[o] = pay;
-            }
-        }
-        if (tid < P) h[tid] = 0;
-        __syncthreads();
-    }
-}
-
 // Write-combining scatter (k_scatter_wc, k_part1_fast, k_part2_fast): the software write-combining idea of the
 // reference's CPU partitioner (partition-primitives.cu:40-125) re-expressed in LDS.  Every digit owns 128-byte
 // lines in LDS (32 tuples); tuples are appended to their digit's line and a line leaves the CU only when it is
@@ -490,15 +369,18 @@ struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slot
 // wave-aggregated atomic (same-address LDS atomics serialise per lane).
 // VAR (exact pass under skew): the 512 LDS lines are dealt to the digits in proportion to what the span's histogram
 // says each will receive per round (L_.lt[d] = lines << 16 | first line, L_.own[line] = digit), instead of K each.
-template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false>
+// MODE 1 (exact pass only): the digit is the multi-GPU shard of the key (digit_of<1>: hash, optional position table), P
+// need not be a power of two (K = the largest power of two <= 512/P lines per digit).
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
                                         int32_t *__restrict__ out_pays, uint64_t *__restrict__ obeg,
-                                        uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf) {
+                                        uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf,
+                                        const uint32_t *__restrict__ remap = nullptr) {
     int2 *buf = L_.buf;
     uint32_t *hh = L_.hh, *line = L_.line;
-    const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : (uint32_t)__builtin_ctz((uint32_t)MAX_PARTS / P);
+    const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)MAX_PARTS / P);
     const uint32_t K = 1u << kshift, capS = K * WC_LINE; // lines / slots per digit in LDS
     const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
     const uint32_t mask = P - 1;
@@ -592,7 +474,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const bool valid = (vm[u] >> e) & 1u;
-                const uint32_t d = ((uint32_t)elem(kv[u], e) >> shift) & mask;
+                const uint32_t d = MODE == 0 ? (((uint32_t)elem(kv[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kv[u], e), 0, P, remap);
                 const uint32_t old = HEAVY ? rank_in_digit(h, d, valid)
                                            : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
@@ -746,7 +628,7 @@ size_t fast_lds_bytes_impl() {
 // The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
 // digit d starts at g0 (any alignment); the LDS lines of d mirror the 128-byte output lines being filled.
 // Algorithmic traffic: 8 B read + 8 B written per tuple.
-template <int U>
+template <int U, int MODE>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                                            uint64_t nalloc, const uint64_t *__restrict__ sbeg,
                                                            const uint64_t *__restrict__ send, uint32_t nseg, uint32_t spp,
@@ -755,7 +637,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
                                                            const uint32_t *__restrict__ hist,
                                                            const uint64_t *__restrict__ chunk_prefix,
                                                            int32_t *__restrict__ out_keys, int32_t *__restrict__ out_pays,
-                                                           uint64_t n_out) {
+                                                           uint64_t n_out, const uint32_t *__restrict__ remap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
     wf_carve(L_, smem);
@@ -813,10 +695,10 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     __syncthreads();
     const FastGeom g{0, 0, 0};
     // block_excl_scan hands the workgroup totals to every thread: the branches are workgroup-uniform
-#define HJ_WC(KF, HV, VR) wc_fast<U, KF, 0, true, HV, VR>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr)
+#define HJ_WC(KF, HV, VR) wc_fast<U, KF, 0, true, HV, VR, MODE>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr, remap)
     if (var) { if (any_heavy) HJ_WC(0, true, true); else HJ_WC(0, false, true); }
     else if (any_heavy) HJ_WC(0, true, false);
-    else if (P == (uint32_t)MAX_PARTS) HJ_WC(1, false, false);
+    else if (MODE == 0 && P == (uint32_t)MAX_PARTS) HJ_WC(1, false, false);
     else HJ_WC(0, false, false);
 #undef HJ_WC
 }
@@ -1390,36 +1272,13 @@ hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64
     return hipSuccess;
 }
 
-size_t scatter_lds_bytes(int threads, int u) {
-    return (size_t)threads * 4 * u * 4 * 2 + (size_t)MAX_PARTS * 4 * 3 + 32 * 4;
-}
-
-template <int MODE, int THREADS, int U>
-static hipError_t launch_scatter_t(hipStream_t st, const PassArgs &pa) {
-    static bool attr_set[64] = {}; // per device: one process may hold contexts on several GPUs
-    const size_t lds = scatter_lds_bytes(THREADS, U);
-    auto fn = k_scatter<MODE, THREADS, U>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_attr_mutex);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
-                       pa.span_start, pa.span, pa.shift, pa.P, pa.mask_or_n, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
-                       pa.n_out, pa.remap);
-    return hipGetLastError();
-}
-
 size_t fast_lds_bytes() { return fast_lds_bytes_impl(); }
 
-template <int U>
+template <int U, int MODE>
 static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
     static bool attr_set[64] = {}; // per device
     const size_t lds = fast_lds_bytes();
-    auto fn = k_scatter_wc<U>;
+    auto fn = k_scatter_wc<U, MODE>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     {
@@ -1432,29 +1291,13 @@ static hipError_t launch_scatter_wc_t(hipStream_t st, const PassArgs &pa) {
     }
     hipLaunchKernelGGL(fn, dim3(pa.max_spans), dim3(WC_THREADS), lds, st, pa.keys, pa.pays, pa.nalloc, pa.sbeg, pa.send, pa.nseg, pa.spp,
                        pa.span_start, pa.span, pa.shift, pa.P, pa.hist, pa.chunk_prefix, pa.out_keys, pa.out_pays,
-                       pa.n_out);
+                       pa.n_out, pa.remap);
     return hipGetLastError();
 }
 
-// variant: 0 = 512 threads x 8192-tuple sorted tiles (2 workgroups/CU), 1 = 1024 x 16384 (1/CU),
-//          2 = 512 x 4096, 3 = 1024 x 8192, 4 = LDS write-combining lines (k_scatter_wc; radix digits, power-of-two fan-out)
-hipError_t launch_scatter(hipStream_t st, int mode, int variant, const PassArgs &pa) {
-    if (variant >= 4 && mode == 0 && (pa.P & (pa.P - 1)) == 0) return launch_scatter_wc_t<2>(st, pa);
-    if (variant >= 4) variant = 1;
-    if (mode == 0) {
-        switch (variant) {
-        case 1: return launch_scatter_t<0, 1024, 4>(st, pa);
-        case 2: return launch_scatter_t<0, 512, 2>(st, pa);
-        case 3: return launch_scatter_t<0, 1024, 2>(st, pa);
-        default: return launch_scatter_t<0, 512, 4>(st, pa);
-        }
-    }
-    switch (variant) {
-    case 1: return launch_scatter_t<1, 1024, 4>(st, pa);
-    case 2: return launch_scatter_t<1, 512, 2>(st, pa);
-    case 3: return launch_scatter_t<1, 1024, 2>(st, pa);
-    default: return launch_scatter_t<1, 512, 4>(st, pa);
-    }
+// the exact scatter: radix digits (mode 0) or multi-GPU shards (mode 1: hash, optional position table, any fan-out <= 512)
+hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
+    return mode == 0 ? launch_scatter_wc_t<2, 0>(st, pa) : launch_scatter_wc_t<2, 1>(st, pa);
 }
 
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2) {
