@@ -128,9 +128,27 @@ __device__ __forceinline__ int32_t elem(const int4 &v, int e) {
 // same digit as the wave's first valid lane (a heavy hitter), those lanes are served by ONE atomic add
 // of their number and ranked by a ballot; everybody else adds 1 for itself.  Must be called by all 64
 // lanes of the wave (valid = this lane has a tuple).  Same-address LDS atomics serialise per lane.
-__device__ __forceinline__ uint32_t rank_in_digit(uint32_t *cnt, uint32_t d, bool valid) {
+// few = the pass has at most 2 digits (a 2-GPU shard split; measured slower from 3 digits on): every digit present in the wave is
+// served by one aggregated atomic, in turn — with 2 digits nearly every lane would otherwise queue
+// on one of 2 LDS words.
+__device__ __forceinline__ uint32_t rank_in_digit(uint32_t *cnt, uint32_t d, bool valid, bool few = false) {
     const uint64_t vmask = __ballot(valid);
     uint32_t r = 0;
+    if (few) {
+        uint64_t rem = vmask;
+        while (rem) {
+            const int first = __builtin_ctzll(rem);
+            const uint32_t lead = (uint32_t)__shfl((int)d, first, 64);
+            const bool same = valid && d == lead;
+            const uint64_t smask = __ballot(same);
+            uint32_t base = 0;
+            if ((int)lane_id() == first) base = atomicAdd(&cnt[lead], (uint32_t)__popcll(smask));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (same) r = base + (uint32_t)__popcll(smask & (((uint64_t)1 << lane_id()) - 1));
+            rem &= ~smask;
+        }
+        return r;
+    }
     if (vmask) {
         const int first = __builtin_ctzll(vmask);
         const uint32_t lead = (uint32_t)__shfl((int)d, first, 64);
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
         for (int e = 0; e < 4; e++) {
             uint64_t idx = i + e;
             const bool valid = idx >= si.lo && idx < si.hi;
-            (void)rank_in_digit(h, digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n, remap), valid);
+            (void)rank_in_digit(h, digit_of<MODE>((uint32_t)elem(v, e), shift, mask_or_n, remap), valid, P <= 2);
         }
     }
     __syncthreads();
@@ -475,7 +493,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             for (int e = 0; e < 4; e++) {
                 const bool valid = (vm[u] >> e) & 1u;
                 const uint32_t d = MODE == 0 ? (((uint32_t)elem(kv[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kv[u], e), 0, P, remap);
-                const uint32_t old = HEAVY ? rank_in_digit(h, d, valid)
+                const uint32_t old = HEAVY ? rank_in_digit(h, d, valid, P <= 2)
                                            : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
