@@ -42,6 +42,13 @@ def test_sharded_join_gloo_world2_size_aware_assignment():
     assert imb(res_hash) > 1.15 and imb(res_size) < 1.08, (res_hash["received"], res_size["received"])
 
 
+def test_sharded_join_gloo_world3_size_aware():
+    """A world size that is not a power of two, skewed keys, size-aware assignment."""
+    res = _run(3, {"HJ_DIST_SKEW": "1", "HJ_DIST_BALANCE": "size", "HJ_DIST_CHUNK": "5000"}, 29655)
+    assert res["got"] == res["expect"]
+    assert sum(a + b for a, b in res["received"]) == 20_000 + 50_001
+
+
 def test_assign_by_size_is_deterministic_and_balanced():
     from importlib import import_module
     SJ = import_module(pkg().__name__ + ".dist").ShardedJoin
