@@ -319,6 +319,43 @@ def test_bench_cli_json_cpu_baseline_gpus(P, tmp_path):
         assert r.returncode != 0 and "GPU Error" in r.stderr     # one device only: fails loudly, no fallback
 
 
+def test_two_contexts_on_two_host_threads(P):
+    """One context per host thread (SURVEY §8(b) threading): two threads, two contexts on the same GPU, different LDS
+    table shapes and layouts, joins and the reference entry point running concurrently."""
+    import threading
+    rng = np.random.default_rng(101)
+    data = []
+    for t in range(2):
+        R = rng.integers(0, 40_000, 50_000 + 7 * t).astype(np.int32)
+        S = rng.integers(0, 40_000, 150_000 + 11 * t).astype(np.int32)
+        data.append((R, S, o.join_count(R, None, S, R if False else None, checksum=False)[:2]))
+    errs = []
+
+    def work(t):
+        try:
+            R, S, exp = data[t]
+            cfg = [dict(bits1=5, bits2=4, lds_capacity=512, lds_heads=128), dict(lds_capacity=6000, lds_heads=4096, exact_only=True)][t]
+            with P.HashJoin(0) as hj:
+                hj.configure(**cfg)
+                hj.load_host(P.REL_R, R)
+                hj.load_host(P.REL_S, S)
+                for _ in range(5):
+                    assert hj.join() == exp
+                    k, pr, ps = hj.join_materialize()
+                    assert len(k) == exp[0]
+            r = P.hashJoinClusteredProbe(R, S)
+            assert r["status"] == 0 and r["matches"] == exp[0]
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
 # ---- BASELINE sizes through size-independent properties --------------------------------------------------
 def test_config2_single_pass_as_stated(P):
     """BASELINE config 2 as stated: 2^27 x 2^27, ONE radix pass of 9 bits (2^18-tuple partitions, far beyond the
