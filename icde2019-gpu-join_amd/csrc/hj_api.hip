@@ -357,7 +357,9 @@ void invalidate(hj_ctx *c, int rel = -1) {
 struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; };
 bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f) {
     if (n == 0) return false;
-    const uint32_t target = c->target_spans ? c->target_spans : 512; // 2 workgroups per CU
+    // one workgroup per CU up to 2^28 tuples (fewer, longer spans: the per-span prologue and partial-line epilogue weigh
+    // less: pass 1 -4..-12 % at 2^26-2^27), two per CU beyond (no difference measured at 2^30)
+    const uint32_t target = c->target_spans ? c->target_spans : (n >= ((uint64_t)1 << 29) ? 512 : 256);
     uint64_t span = (n + target - 1) / target;
     span = ((span + TILE - 1) / TILE) * TILE;
     uint64_t nspans = (n + span - 1) / span;
