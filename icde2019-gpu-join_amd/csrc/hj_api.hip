@@ -376,6 +376,8 @@ bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &
 int partition_rel(hj_ctx *c, int r) {
     Rel &R = c->rel[r];
     if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
+    // positions inside the partition kernels are 32-bit: checked before anything is allocated
+    if (R.n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU (n < 2^32 - 16384 tuples required)");
     choose_bits(c);
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));

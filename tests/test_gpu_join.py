@@ -521,6 +521,14 @@ def test_api_errors_and_config(P):
         hj.configure(bits1=4)   # invalidates both
         with pytest.raises(P.HJError):
             hj.join_count()
+        # maximum size: positions are 32-bit inside the partition kernels; one tuple too many is refused before any
+        # buffer is allocated or any byte of the (here fictitious) columns is read
+        hj.configure()
+        big = (1 << 32) - 16384
+        rc = hj._L.hj_bind_device(hj._h, P.REL_R, C.c_void_p(1 << 20), C.c_void_p(1 << 21), big)
+        assert rc == 0
+        assert hj._L.hj_partition(hj._h, P.REL_R) == -1 and b"too large" in hj._L.hj_error(hj._h)
+        hj.load_host(P.REL_R, R, R)
 
 
 def test_bench_cli_file_and_multipliers(P, tmp_path):
