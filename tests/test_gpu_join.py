@@ -424,6 +424,32 @@ def test_large_unique_properties(P, logn):
         assert torch.equal(Rk[opr.long()], ok) and torch.equal(Sk[ops.long()], ok)   # key == R[payR] == S[payS]
 
 
+def test_largest_two_pass_size(P):
+    """2^31 x 2^31 unique keys: the largest power-of-two relations one GPU takes (32-bit positions), 18 radix bits =
+    8192-tuple partitions (two LDS-table chunks per partition).  Count, multiset-preserving partitioning, placement."""
+    import torch
+    n = 1 << 31
+    dev = torch.device("cuda:0")
+    Rk, Sk, Rp, Sp = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4))
+    with P.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream) as hj:
+        hj.gen_unique(Rk, n, 0, n, 11)
+        hj.gen_unique(Sk, n, 0, n, 12)
+        hj.fill_payload(Rp, n, "rowid")
+        hj.fill_payload(Sp, n, "ones")
+        hj.sync()
+        hj.bind_device(P.REL_R, Rk, Rp)
+        hj.bind_device(P.REL_S, Sk, Sp)
+        before = hj.digest_pairs(Rk, Rp, n)
+        m, agg = hj.join()
+        assert m == n
+        assert agg == (n * (n - 1) // 2) % (1 << 64)           # sum of R's row ids (payS = 1), every R tuple matched once
+        assert hj.config()["bits1"] + hj.config()["bits2"] == 18
+        bad, _ = hj.verify_partitions(P.REL_R)
+        assert bad == 0
+        k, p, off, nparts = hj.partition_pointers(P.REL_R)
+        assert nparts == 1 << 18 and hj.digest_pairs(k, p, n) == before
+
+
 # ---- streaming probe side (SURVEY §8(f) rank 1: outOfGPU_Join3_payload, hjcp.cu:1684-1984) ----------------
 @pytest.mark.parametrize("seg", [0, 1000, 4096, 50_000, 10**9])
 def test_stream_probe_segments(P, seg):
