@@ -47,7 +47,6 @@ struct Rel {
     Buf off1, off2, root;     // partition offsets (uint64) of the exact passes
     Buf beg, end;             // final partition ranges [nparts] (uint64): what the join reads, whichever path ran
     Buf s1beg, s1end;         // slot ranges written by the histogram-free pass 1 [P1 * nspans]
-    Buf flag;                 // device uint32: the histogram-free passes gave up (a slot overflowed)
     Buf comp_k, comp_p, comp_off; // gap-free copy for hj_get_partitions when the layout is slotted
     const int32_t *part_k = nullptr, *part_p = nullptr;
     const uint64_t *part_beg = nullptr, *part_end = nullptr;
@@ -74,7 +73,7 @@ struct hj_ctx {
     // workspace
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
-    Buf scalars;                // device: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc
+    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
     bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
@@ -381,8 +380,8 @@ int partition_rel(hj_ctx *c, int r) {
     choose_bits(c);
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));
-    RET(ensure(c, R.flag, 64));
-    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, (uint32_t *)R.flag.p)); }
+    uint32_t *const flag = reinterpret_cast<uint32_t *>((uint64_t *)c->scalars.p + 8 + r); // travels with the result block
+    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, flag)); }
     uint32_t b1 = c->bits1, b2 = c->bits2;
     // A relation known to be skewed (its histogram-free attempt overflowed) is split as evenly as possible between
     // the two exact passes: fewer than 512 digits per pass leave LDS lines to deal to the heavy digits (k_scatter_wc).
@@ -423,7 +422,7 @@ int partition_rel(hj_ctx *c, int r) {
             //      block — redoes this relation with the exact passes (retry_overflowed) ----
             RET(ensure(c, R.s1beg, (size_t)P1 * f.nspans * 8));
             RET(ensure(c, R.s1end, (size_t)P1 * f.nspans * 8));
-            uint32_t *ovf = (uint32_t *)R.flag.p;
+            uint32_t *ovf = flag;
             FastArgs fa{};
             fa.keys = R.in_k; fa.pays = R.in_p; fa.n = R.n; fa.span = f.span; fa.nspans = f.nspans;
             fa.shift = b2; fa.P = P1; fa.cap = f.cap1;
@@ -466,7 +465,7 @@ int partition_rel(hj_ctx *c, int r) {
 int resolve_layout(hj_ctx *c, Rel &R) {
     if (!R.fast_tried) return 0;
     uint32_t ovf = 0;
-    HIPCHK(c, hipMemcpyAsync(&ovf, R.flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ovf, (uint64_t *)c->scalars.p + 8 + (&R - c->rel), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (ovf) {
         R.prefer_exact = true;
@@ -513,8 +512,8 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
-    a.bflag = (B.fast_tried && !B.flag_known_good) ? (const uint32_t *)B.flag.p : nullptr;
-    a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? (const uint32_t *)Pb.flag.p : nullptr;
+    a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
+    a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
@@ -552,11 +551,8 @@ int scan_wave_counts(hj_ctx *c) {
 }
 
 int fetch_scalars(hj_ctx *c) {
-    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 8 * 8, hipMemcpyDeviceToHost, c->stream));
-    // the same round trip brings back the overflow flags of relations whose histogram-free passes were queued
-    for (int r = 0; r < 2; r++)
-        if (c->rel[r].fast_tried && !c->rel[r].flag_known_good)
-            HIPCHK(c, hipMemcpyAsync(c->h_scalars + 8 + r, c->rel[r].flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    // one 80-byte copy: the results and, behind them, the overflow flags of the two relations' histogram-free passes
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 10 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->redo_mask = 0;
     for (int r = 0; r < 2; r++) {
@@ -606,8 +602,9 @@ int hj_create(hj_ctx **out, int device) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_EHIP; }
     c->stream = c->own_stream;
-    if (hipMalloc(&c->scalars.p, 64) != hipSuccess) { delete c; return HJ_ENOMEM; }
-    c->scalars.cap = 64;
+    if (hipMalloc(&c->scalars.p, 128) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    c->scalars.cap = 128;
+    (void)hipMemset(c->scalars.p, 0, 128);
     if (hipHostMalloc((void **)&c->h_scalars, 128, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
     memset(c->h_scalars, 0, 128);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
@@ -627,7 +624,7 @@ int hj_destroy(hj_ctx *c) {
         Rel &R = c->rel[r];
         release(R.own_k); release(R.own_p); release(R.a_k); release(R.a_p); release(R.b_k); release(R.b_p);
         release(R.off1); release(R.off2); release(R.root);
-        release(R.beg); release(R.end); release(R.s1beg); release(R.s1end); release(R.flag);
+        release(R.beg); release(R.end); release(R.s1beg); release(R.s1end);
         release(R.comp_k); release(R.comp_p); release(R.comp_off);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
