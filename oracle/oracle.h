@@ -14,7 +14,7 @@
  * are pinned to the reference itself, compiled here from where it lies by oracle/Makefile (`ref` target, outputs
  * only into oracle/_ref/, git-ignored):
  *   - generator half: oracle/_ref/refgen = /root/reference/src/generator_ETHZ.cu (unmodified, g++ -x c++);
- *     tests/golden/*.bin are its outputs (tests/golden/make_golden.py), replayed bit for bit;
+ *     the .bin files under tests/golden/ are its outputs (tests/golden/make_golden.py), replayed bit for bit;
  *   - join half: oracle/_ref/refjoin = the reference's own CPU join, joinCpu + h_hashMurmur
  *     (/root/reference/src/hash_join_clustered_probe.cu:2013-2059: the span is cut out of the file at build time and
  *     compiled next to the reference's common-host.h, no stand-in headers); tests/golden/join_answers.json holds the
