@@ -914,20 +914,20 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
     }
 }
 
-// LDS layout (dynamic): head[nh] u32 | pay[cap] i32 | key[cap] (u16 tag or u32 key) | next[cap] u16
-// The reference's table: elem int16 tag, payload int32, next int16, head int32[1024] (jp.cu:899-902).
+// LDS layout (dynamic): head[nh] u32 | entries[cap] 8 bytes ({tag16 << 16 | next16, payload} or {key, payload}) | with full
+// keys: next[cap] u16.  The reference's table: elem int16 tag, payload int32, next int16, head int32[1024] (jp.cu:899-902):
+// the same 8 bytes per tuple, here laid out so that one 8-byte LDS load per chain hop fetches tag, link and payload.
 template <bool TAG16, int JM>
 __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     constexpr bool MAT = JM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t item = blockIdx.x;
     if (item >= *a.n_items) return;
+    // LDS: head[nh] u32 | ent[cap] 8-byte entries | (full keys only) next[cap] u16.  An entry is read with ONE 8-byte LDS
+    // load per chain hop: TAG16 {tag << 16 | next, payload}; full keys {key, payload} (+ the separate next link).
     uint32_t *head = reinterpret_cast<uint32_t *>(smem);
-    int32_t *lpay = reinterpret_cast<int32_t *>(smem + (size_t)a.nh * 4);
-    unsigned char *kbase = smem + (size_t)a.nh * 4 + (size_t)a.cap * 4;
-    uint16_t *ltag = reinterpret_cast<uint16_t *>(kbase);
-    uint32_t *lkey = reinterpret_cast<uint32_t *>(kbase);
-    uint16_t *lnext = reinterpret_cast<uint16_t *>(kbase + (size_t)a.cap * (TAG16 ? 2 : 4));
+    uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
+    uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const JoinItem it = a.items[item];
@@ -972,11 +972,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                     for (int e = 0; e < 4; e++) {
                         uint64_t idx = i + e;
                         if (idx >= gb && idx < gb + nbc) {
-                            uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                            if (TAG16) ltag[slot] = (uint16_t)(key >> bits); else lkey[slot] = key;
-                            lpay[slot] = elem(bpv[r], e);
-                            uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
-                            lnext[slot] = (uint16_t)old;
+                            const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                            const uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                            if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                            else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
                         }
                     }
                 }
@@ -1011,12 +1010,13 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         const uint32_t pos = pos4[e];
                         if (pos != 0xFFFFu) {
                             const uint32_t key = (uint32_t)elem(kv, e);
-                            const bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                            const uint2 en = ent[pos];
+                            const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
                             if (eq) {
                                 my_matches++;
-                                my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)elem(pv, e));
+                                my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)elem(pv, e));
                             }
-                            pos4[e] = lnext[pos];
+                            pos4[e] = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                         }
                     }
                 }
@@ -1031,31 +1031,34 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 pos &= 0xFFFFu; // chain links are 16 bit; 0xFFFF = end
                 if (!MAT) {
                     while (pos != 0xFFFFu) {
-                        bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                        const uint2 en = ent[pos];
+                        const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
                         if (eq) {
                             my_matches++;
                             if (JM == 2) {
                                 // late materialisation (join_partitioned_varpayload, jp.cu:1524-1533): payloads are
                                 // row ids; gather the extra columns of both sides and add them up
-                                const int32_t bval = lpay[pos];
+                                const int32_t bval = (int32_t)en.y;
                                 int64_t acc = 0;
                                 for (uint32_t z = 0; z < a.ncp; z++) acc += a.Dp[(uint64_t)(uint32_t)ppay + z * a.sp];
                                 for (uint32_t z = 0; z < a.ncb; z++) acc += a.Db[(uint64_t)(uint32_t)bval + z * a.sb];
                                 my_agg += (uint64_t)acc;
                             } else {
-                                my_agg += (uint64_t)((int64_t)lpay[pos] * (int64_t)ppay);
+                                my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)ppay);
                             }
                         }
-                        pos = lnext[pos];
+                        pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                     }
                 } else {
                     // every step of the wave: each lane advances to its next matching entry, the
                     // matching lanes are ranked by a 64-bit ballot and write one coalesced run
                     for (;;) {
+                        uint2 en = make_uint2(0, 0);
                         while (pos != 0xFFFFu) {
-                            bool eq = TAG16 ? (ltag[pos] == (uint16_t)(key >> bits)) : (lkey[pos] == key);
+                            en = ent[pos];
+                            const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
                             if (eq) break;
-                            pos = lnext[pos];
+                            pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                         }
                         const bool m = pos != 0xFFFFu;
                         const uint64_t mask = __ballot(m);
@@ -1064,10 +1067,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                             uint64_t o = cur + __popcll(mask & lt_mask);
                             if (o < a.out_cap) {
                                 a.out_key[o] = (int32_t)key;
-                                a.out_bpay[o] = lpay[pos];
+                                a.out_bpay[o] = (int32_t)en.y;
                                 a.out_ppay[o] = ppay;
                             }
-                            pos = lnext[pos];
+                            pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                         }
                         cur += __popcll(mask);
                     }
