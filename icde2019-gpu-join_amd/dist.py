@@ -35,6 +35,10 @@ class ShardedJoin:
         self._buf = {}
         self.last_received = (0, 0)
         self.force_exchange = False   # tests: run split + exchange even at world size 1
+        # A transport that cannot move device memory (gloo): columns are staged through host memory.  Slow, but it lets
+        # the real engine run at world size > 1 where RCCL is not available (two ranks sharing one GPU in the tests).
+        self.staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+        self.cdev = torch.device("cpu") if self.staged else device   # where the small control tensors live
 
     def _get(self, name, n):
         """Reusable int32 column of at least n elements (HBM is plentiful: keep, do not re-allocate)."""
@@ -53,7 +57,7 @@ class ShardedJoin:
     def exchange_async(self, cols, send_counts):
         """All-to-all-v of several columns that share one split: cols = {name: tensor[sum(send_counts)]}.
         Returns ({name: tensor}, n_received, [work handles]); the columns are valid after work.wait()."""
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.dev)
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.ctl)
         recv_counts = [int(x) for x in rc.tolist()]
@@ -67,6 +71,24 @@ class ShardedJoin:
         out, works = {}, []
         for name, t in cols.items():
             r = self._get("recv_" + name, total)
+            if self.staged:
+                torch.cuda.current_stream(self.dev).synchronize()
+                th, rh = t[:soff[-1]].cpu(), torch.empty(total, dtype=torch.int32)
+                hops = []
+                for step in range(self.world):
+                    p, q = (self.rank + step) % self.world, (self.rank - step) % self.world
+                    if step == 0:
+                        rh[roff[p]:roff[p] + int(send_counts[p])] = th[soff[p]:soff[p + 1]]
+                        continue
+                    if int(send_counts[p]):
+                        hops.append(dist.P2POp(dist.isend, th[soff[p]:soff[p + 1]], p, group=self.group))
+                    if recv_counts[q]:
+                        hops.append(dist.P2POp(dist.irecv, rh[roff[q]:roff[q + 1]], q, group=self.group))
+                for wk in (dist.batch_isend_irecv(hops) if hops else []):
+                    wk.wait()
+                r[:total].copy_(rh)
+                out[name] = r
+                continue
             ops = []
             for step in range(self.world):
                 p = (self.rank + step) % self.world      # rank-staggered peer order
@@ -125,7 +147,7 @@ class ShardedJoin:
         halves = []
         for v in vals:
             halves += [v & 0xFFFFFFFF, v >> 32]
-        t = torch.tensor(halves, dtype=torch.int64, device=self.dev)
+        t = torch.tensor(halves, dtype=torch.int64, device=self.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
         h = [int(x) for x in t.tolist()]
         mask = (1 << 64) - 1
@@ -159,7 +181,7 @@ class ShardedJoin:
             # movement), add up over the ranks, assign by size
             ns = w * self.VIRTUAL
             local = [a + b for a, b in zip(e.shard_count(Rk, nR, ns), e.shard_count(Sk, nS, ns))]
-            t = torch.tensor(local, dtype=torch.int64, device=self.dev)
+            t = torch.tensor(local, dtype=torch.int64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
             plan = self.assign_by_size([int(x) for x in t.tolist()], w)
             self.last_plan = plan

@@ -68,9 +68,14 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     pkg = graft.load_package()
     if gpu:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl", device_id=dev)
+        one = os.environ.get("HJ_DIST_ONE_GPU") == "1"   # every rank on cuda:0, host-staged exchange over gloo
+        idx = 0 if one else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(idx)
+        dev = torch.device("cuda", idx)
+        if one:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         engine = pkg.HashJoin(dev.index, stream=torch.cuda.current_stream().cuda_stream)
     else:
         dev = torch.device("cpu")
@@ -118,7 +123,7 @@ def main():
     res = []
     for i in range(2):  # twice: buffers are reused across steps; the first with the exchange check on
         res.append(dj.join(sl(R, nR), sl(Pr, nR), sl(S, nS), sl(Ps, nS), verify=(i == 0)))
-    mine = torch.tensor(list(dj.last_received), dtype=torch.int64, device=dev)
+    mine = torch.tensor(list(dj.last_received), dtype=torch.int64, device=dj.cdev if hasattr(dj, "cdev") else dev)
     allr = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     recv = [[int(x) for x in t.tolist()] for t in allr]

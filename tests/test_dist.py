@@ -87,6 +87,21 @@ def test_sharded_join_rccl_world1():
     assert res["got"] == res["expect"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_join_real_engine_ranks_share_one_gpu(world):
+    """The REAL engine at world size 2 and 3 on a one-GPU box: every rank opens its own context on cuda:0 and the columns
+    travel host-staged over gloo (RCCL refuses two ranks on one device).  Exercises what the gloo/oracle tests cannot:
+    the HIP engine with per-rank received sizes, the stream ordering between split, exchange and partition, the
+    size-aware assignment with skew, partition layouts that differ between ranks."""
+    res = _run(world, {"HJ_DIST_GPU": "1", "HJ_DIST_ONE_GPU": "1"}, 29660 + world)
+    assert res["got"] == res["expect"]
+    res = _run(world, {"HJ_DIST_GPU": "1", "HJ_DIST_ONE_GPU": "1", "HJ_DIST_BALANCE": "size", "HJ_DIST_SKEW": "1",
+                       "HJ_DIST_N": "600000,2500001"}, 29670 + world)
+    assert res["got"] == res["expect"]
+    assert sum(a + b for a, b in res["received"]) == 600000 + 2500001
+
+
 def _gpu_count():
     try:
         import torch
