@@ -307,6 +307,11 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # HJ_BENCH_BACKEND=gloo: plumbing check of the N>1 code path on a one-GPU box — every rank on cuda:0, columns staged
+    # through host memory (dist.ShardedJoin.staged).  Not a measurement.
+    backend = os.environ.get("HJ_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = 0
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -317,8 +322,11 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29599")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if backend == "gloo" else dev   # where tensors of small collectives live
     pkg = graft.load_package()
     n = 1 << a.log2n
     total_n = n * world
@@ -385,7 +393,7 @@ def main():
     dt = time.perf_counter() - t0
     assert got == expect, (got, expect)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kt = hj.timings()
@@ -395,7 +403,7 @@ def main():
 
     dist_info = None
     if use_dist:
-        recv = torch.tensor(list(dj.last_received), dtype=torch.int64, device=dev)
+        recv = torch.tensor(list(dj.last_received), dtype=torch.int64, device=cdev)
         allrecv = [torch.empty_like(recv) for _ in range(world)]
         dist.all_gather(allrecv, recv)
         dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),

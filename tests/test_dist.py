@@ -102,6 +102,24 @@ def test_sharded_join_real_engine_ranks_share_one_gpu(world):
     assert sum(a + b for a, b in res["received"]) == 600000 + 2500001
 
 
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` on its own (the driver's command shape) must start two ranks, not report a 1-rank
+    run: checked on a one-GPU box with the host-staged gloo transport (HJ_BENCH_BACKEND=gloo), small relations."""
+    env = dict(os.environ, HJ_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "20", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dist"]["world"] == 2 and line["config"]["matches"] == 2 << 20
+    assert sum(a for a, _ in line["dist"]["received_tuples_per_rank_R_S"]) == 2 << 20
+    # a launcher that disagrees with --gpus is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
 def _gpu_count():
     try:
         import torch
