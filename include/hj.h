@@ -95,7 +95,9 @@ int hj_bind_device(hj_ctx *ctx, int rel, const int32_t *d_keys, const int32_t *d
 
 /* ---- the path (replaces prepare_Relation_payload jp.cu:1582-1613 + decompose_chains/join launches
  *      hjcp.cu:904-913,972-974) ---- */
-/* Radix-partition one relation into contiguous partitions on the low key bits (async). */
+/* Radix-partition one relation on the low key bits (async).  A partition is a range of the partitioned columns:
+ * fixed-capacity slots from the histogram-free passes or gap-free ranges from the exact passes (hj_config.exact_only);
+ * the join reads either, hj_get_partitions always hands out the gap-free form. */
 int hj_partition(hj_ctx *ctx, int rel);
 /* Build+probe every partition pair, count only (join_partitioned_aggregate jp.cu:885-1095).
  * matches = |R ⋈ S|; agg = sum payR*payS mod 2^64 (low 32 bits = the reference's int32 aggregate,
