@@ -16,7 +16,8 @@ vp = C.c_void_p
 class Config(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
                 ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
-                ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("materialize_two_pass", C.c_uint32),
+                ("lds_stage", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class KernelTime(C.Structure):
@@ -104,11 +105,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        # HJ_LIB: load another build of the same ABI (A/B experiments only)
-        _lib = C.CDLL(os.environ.get("HJ_LIB", LIB_PATH), mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # always the in-tree build: no override
         for name, (res, argt) in SIGNATURES.items():
-            if "HJ_LIB" in os.environ and not hasattr(_lib, name):
-                continue  # an older build in an A/B run
             f = getattr(_lib, name)  # AttributeError if the header and the library disagree
             f.restype = res
             f.argtypes = argt

@@ -10,11 +10,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -73,7 +76,7 @@ struct hj_ctx {
     // workspace
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
-    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S
+    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
     bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
@@ -83,6 +86,7 @@ struct hj_ctx {
     uint32_t max_items = 0;
     uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
+    uint32_t stage_cap = 0;         // experiment knob (HJ_STAGE_CAP): staged matches per flush of the one-probe materialising kernel
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
     hipStream_t copy = nullptr;     // H2D of the next probe segment
@@ -476,8 +480,8 @@ int resolve_layout(hj_ctx *c, Rel &R) {
     return 0;
 }
 
-// work-item list + per-wave counts; leaves scanned wave counts in place for the materialising kernel
-int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nullptr) {
+// work-item list of the current partitions: k_join_plan + scan + k_join_expand (decompose_chains, jp.cu:843-874)
+int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
@@ -514,13 +518,23 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
-    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1)); }
+    a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1, sc + 10)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
                                                                 (const uint64_t *)c->jchunk_prefix.p, (JoinItem *)c->items.p)); }
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
+    return 0;
+}
+
+// work-item list + per-wave counts (the scan of the counts is only run when the two-probe materialising path follows)
+int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nullptr) {
+    RET(plan_join(c, a_out, tag16));
+    JoinArgs &a = a_out;
+    hipStream_t st = c->stream;
+    uint64_t *sc = (uint64_t *)c->scalars.p;
     if (late) {
         a.Db = late->Db; a.Dp = late->Dp; a.ncb = late->ncb; a.ncp = late->ncp; a.sb = late->sb; a.sp = late->sp;
         Timed t(c, "k_join_late_mat");
@@ -551,8 +565,8 @@ int scan_wave_counts(hj_ctx *c) {
 }
 
 int fetch_scalars(hj_ctx *c) {
-    // one 80-byte copy: the results and, behind them, the overflow flags of the two relations' histogram-free passes
-    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 10 * 8, hipMemcpyDeviceToHost, c->stream));
+    // one 88-byte copy: the results, the overflow flags of the two relations' histogram-free passes, the output cursor
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 11 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->redo_mask = 0;
     for (int r = 0; r < 2; r++) {
@@ -610,6 +624,7 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
+    if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
     *out = c;
     return HJ_OK;
 }
@@ -663,6 +678,7 @@ int hj_configure(hj_ctx *c, const hj_config *cfg) {
     if (cfg->bits1 > 9 || cfg->bits2 > 9) return fail(c, HJ_EINVAL, "at most 9 radix bits per pass");
     if (cfg->lds_capacity > 65535) return fail(c, HJ_EINVAL, "lds_capacity must be <= 65535 (16-bit chain links)");
     if (cfg->lds_heads & (cfg->lds_heads - 1)) return fail(c, HJ_EINVAL, "lds_heads must be a power of two");
+    if (cfg->lds_stage && (cfg->lds_stage < 64 || cfg->lds_stage > 16384)) return fail(c, HJ_EINVAL, "lds_stage must be in [64, 16384]");
     c->cfg = *cfg;
     invalidate(c);
     return HJ_OK;
@@ -677,6 +693,8 @@ int hj_get_config(const hj_ctx *c, hj_config *cfg) {
     cfg->build_side = c->build == HJ_REL_R ? 1 : 2;
     cfg->lds_capacity = c->cap; cfg->lds_heads = c->nh; cfg->probe_chunk = c->chunk;
     cfg->exact_only = c->cfg.exact_only || !c->fast_path;
+    cfg->materialize_two_pass = c->cfg.materialize_two_pass;
+    cfg->lds_stage = c->cfg.lds_stage;
     return HJ_OK;
 }
 
@@ -743,10 +761,26 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     return HJ_OK;
 }
 
-int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
-    if (!c) return HJ_EINVAL;
-    if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
-    HIPCHK(c, hipSetDevice(c->device));
+} // extern "C"
+
+namespace {
+
+// LDS staging block of the one-probe materialising kernel: what is left of half a CU's LDS (two workgroups per CU) next to
+// the hash table, 6 bytes per staged match
+uint32_t stage_capacity(const hj_ctx *c, bool tag16) {
+    if (c->cfg.lds_stage) return c->cfg.lds_stage;
+    if (c->stage_cap) return c->stage_cap;
+    const size_t table = join_mat_lds_bytes(c->nh, c->cap, tag16, 0);
+    const size_t half = 80 * 1024;
+    uint32_t s = table + 512 * 6 < half ? (uint32_t)((half - table) / 6) : 512;
+    s &= ~63u;
+    if (s > 4608) s = 4608; // 9 records per thread stay in registers across the output reservation (MAT_R)
+    return s;
+}
+
+// the two-probe path: count (unless the counts of these partitions are on the device already), scan, second probe writing
+// at the scanned per-wave positions: deterministic given the partitions, no output atomics (hj_config.materialize_two_pass)
+int materialize_two_pass(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
     JoinArgs a;
     bool tag16;
     const bool reuse = c->join_planned;
@@ -762,13 +796,58 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
     a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
     a.out_cap = cap;
-    { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, 1)); }
+    { Timed t(c, "k_join_mat_2nd_probe"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, 1)); }
     c->join_planned = false; // conservative: one reuse per count
     RET(fetch_scalars(c));   // [sync]: the output columns are complete when this returns
     c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg;
     if (n_out) *n_out = c->h_scalars[1];
-    if (c->h_scalars[1] > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu",
-                                           (unsigned long long)c->h_scalars[1], (unsigned long long)cap);
+    return 0;
+}
+
+// ONE probe: plan the work items, k_join_mat stages + reserves + writes; the cursor comes back with the result block
+int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        JoinArgs a;
+        bool tag16;
+        if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
+            a = c->last_args; tag16 = c->last_tag16;
+            HIPCHK(c, hipMemsetAsync((uint64_t *)c->scalars.p + 10, 0, 8, c->stream));
+        } else {
+            RET(plan_join(c, a, tag16));
+        }
+        a.out_key = d_key;
+        a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
+        a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
+        a.out_cap = cap;
+        a.stage_cap = stage_capacity(c, tag16);
+        const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap);
+        if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table + staging block of %zu bytes exceed 160 KiB", lds);
+        { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join_mat(c->stream, a, c->max_items, tag16)); }
+        c->join_planned = false;
+        RET(fetch_scalars(c)); // [sync]
+        if (!c->redo_mask) break;
+        if (attempt) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+        const uint32_t m = c->redo_mask; // slots overflowed (skew): the kernel did nothing; exact passes, then once more
+        for (int r = 0; r < 2; r++)
+            if (m & (1u << r)) RET(partition_rel(c, r));
+    }
+    if (n_out) *n_out = c->h_scalars[10];
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+    if (!c) return HJ_EINVAL;
+    if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t n = 0;
+    if (c->cfg.materialize_two_pass) RET(materialize_two_pass(c, d_key, d_payR, d_payS, cap, &n));
+    else RET(materialize_one_probe(c, d_key, d_payR, d_payS, cap, &n));
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu", (unsigned long long)n, (unsigned long long)cap);
     return HJ_OK;
 }
 
@@ -907,6 +986,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
         }
     }
     bool out_used[2] = {false, false};
+    c->rel[HJ_REL_S].prefer_exact = false; // every call streams new data: the histogram-free passes get their chance again
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
@@ -959,7 +1039,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
             ja.out_bpay = (int32_t *)c->out_p1[b].p; // R builds: build payload = payR
             ja.out_ppay = (int32_t *)c->out_p2[b].p;
             ja.out_cap = m;
-            { Timed t(c, "k_join_materialize");
+            { Timed t(c, "k_join_mat_2nd_probe");
               if (launch_join(c->stream, ja, c->max_items, c->last_tag16, 1) != hipSuccess) { rc = fail(c, HJ_EHIP, "materialise launch"); break; } }
             c->join_planned = false;
             if (hipEventRecord(c->out_ready[b], c->stream) != hipSuccess || hipStreamWaitEvent(c->d2h, c->out_ready[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); break; }
@@ -1019,12 +1099,22 @@ namespace {
 // Partition id = hj_shard_of(key, parts) (hash: balanced for dense keys).
 constexpr uint32_t HWC = 16; // tuples per 64-byte line
 
+// Streaming (non-temporal) line flush: AVX2 on x86-64 hosts that have it (checked once at run time); everywhere else the
+// lines leave with plain stores — same result, the destination lines are then read for ownership first.
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void wc_flush_line(int32_t *dst, const int32_t *src) {
     _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), _mm256_load_si256(reinterpret_cast<const __m256i *>(src)));
     _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 8), _mm256_load_si256(reinterpret_cast<const __m256i *>(src + 8)));
 }
+bool host_has_streaming_stores() { static const bool ok = __builtin_cpu_supports("avx2"); return ok; }
+void wc_fence() { _mm_sfence(); }
+#else
+void wc_flush_line(int32_t *dst, const int32_t *src) { memcpy(dst, src, HWC * 4); }
+bool host_has_streaming_stores() { return false; }
+void wc_fence() {}
+#endif
 
-__attribute__((target("avx2"))) void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
+void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
                                                       const uint64_t *start, int32_t *oK, int32_t *oP, bool stream) {
     // line[p]: 64-byte-aligned output position of the line being filled; fill[p]: next slot; first[p]: first valid slot
     std::vector<uint64_t> line(parts);
@@ -1056,25 +1146,33 @@ __attribute__((target("avx2"))) void wc_scatter_chunk(const int32_t *K, const in
     }
     for (uint32_t p = 0; p < parts; p++) // half-full lines
         for (uint32_t j = first[p]; j < fill[p]; j++) { oK[line[p] + j] = bufK[p * HWC + j]; if (oP) oP[line[p] + j] = bufP[p * HWC + j]; }
-    _mm_sfence();
+    wc_fence();
     free(bufK);
     free(bufP);
 }
 
-void host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
+// false: a host thread could not be started (pids limit of the container): nothing usable was written
+bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
                        int32_t *oK, int32_t *oP, std::vector<uint64_t> &off) {
     if (threads < 1) threads = 1;
     std::vector<uint64_t> hist((size_t)threads * parts, 0);
     auto chunk = [&](uint32_t t, uint64_t &lo, uint64_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < threads; t++)
-        th.emplace_back([&, t] {
+    // run f(t) for t = 0..threads-1 on that many host threads; thread 0's share runs on the caller
+    auto parallel = [&](auto f) -> bool {
+        std::vector<std::thread> th;
+        bool ok = true;
+        try {
+            for (uint32_t t = 1; t < threads; t++) th.emplace_back(f, t);
+        } catch (const std::system_error &) { ok = false; }
+        if (ok) f(0);
+        for (auto &x : th) x.join();
+        return ok;
+    };
+    if (!parallel([&](uint32_t t) {
             uint64_t lo, hi; chunk(t, lo, hi);
             uint64_t *h = hist.data() + (size_t)t * parts;
             for (uint64_t i = lo; i < hi; i++) h[host_shard_of(K[i], parts)]++;
-        });
-    for (auto &x : th) x.join();
-    th.clear();
+        })) return false;
     off.assign(parts + 1, 0);
     uint64_t sum = 0;
     for (uint32_t p = 0; p < parts; p++) {
@@ -1082,15 +1180,14 @@ void host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
         for (uint32_t t = 0; t < threads; t++) { uint64_t cnt = hist[(size_t)t * parts + p]; hist[(size_t)t * parts + p] = sum; sum += cnt; }
     }
     off[parts] = sum;
-    // 64-byte streaming stores need 64-byte-aligned columns (pinned staging is page-aligned); two threads may share the
-    // destination line where their runs of a partition meet: both write their own slots with plain stores (first/last line)
-    const bool stream = (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
-    for (uint32_t t = 0; t < threads; t++)
-        th.emplace_back([&, t] {
-            uint64_t lo, hi; chunk(t, lo, hi);
-            wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream);
-        });
-    for (auto &x : th) x.join();
+    // 64-byte streaming stores need 64-byte-aligned columns (pinned staging is page-aligned) and a CPU that has them; two
+    // threads may share the destination line where their runs of a partition meet: both write their own slots with plain
+    // stores (first/last line)
+    const bool stream = host_has_streaming_stores() && (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
+    return parallel([&](uint32_t t) {
+        uint64_t lo, hi; chunk(t, lo, hi);
+        wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream);
+    });
 }
 
 } // namespace
@@ -1141,7 +1238,8 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         }
         if (!rc) {
             pk[r] = c->host_k[r]; pp[r] = c->host_p[r];
-            host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r]);
+            if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r]))
+                rc = fail(c, HJ_ENOMEM, "could not start %u host threads for the level-0 split", host_threads);
         }
     }
     {
@@ -1200,7 +1298,7 @@ int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t
     if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     std::vector<uint64_t> off;
     const auto t0 = std::chrono::steady_clock::now();
-    host_level0_split(keys, pays, n, parts, threads, out_keys, out_pays, off);
+    if (!host_level0_split(keys, pays, n, parts, threads, out_keys, out_pays, off)) return HJ_ENOMEM;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t p = 0; p <= parts; p++) offsets[p] = off[p];
     if (gbs) *gbs = dt > 0 ? (out_pays ? 16.0 : 8.0) * (double)n / dt / 1e9 : 0;

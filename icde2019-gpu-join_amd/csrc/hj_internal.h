@@ -82,6 +82,8 @@ struct JoinArgs {
     const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
     int32_t *out_key, *out_bpay, *out_ppay;
     uint64_t out_cap;
+    unsigned long long *out_cursor; // one-probe materialisation: next free output position (zeroed by k_join_plan)
+    uint32_t stage_cap;             // ... matches staged in LDS per flush
     // late materialisation: column-major extra columns gathered by row id on every match
     const int32_t *Db, *Dp;  // build side / probe side tables
     uint32_t ncb, ncp;       // columns to gather
@@ -103,13 +105,15 @@ uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
-hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2);
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor);
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(int device, size_t bytes);
-hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise, 2 late materialisation
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise (second probe, scanned positions), 2 late materialisation
+size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16, uint32_t stage_cap);
+hipError_t launch_join_mat(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16); // materialise in one probe
 hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max);
 hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, const int32_t *bp, const int32_t *pk, const int32_t *pp,
                              uint64_t np, int32_t *lookup, uint64_t range, uint64_t *out2);

@@ -877,14 +877,14 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, 
 // jp.cu:843-874, threshold = 2*bucket_size at hjcp.cu:904); no item when either side is empty.
 // bflag / pflag: overflow flags of relations whose histogram-free passes were queued (nullptr otherwise).  A raised
 // flag means the ranges are not valid: no items, the join kernels then do nothing and the host redoes the relation.
-// Thread 0 also zeroes the two result accumulators of k_sum2.
+// Thread 0 also zeroes the two result accumulators of k_sum2 and the output cursor of k_join_mat.
 __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
                             const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                             uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt,
                             const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
-                            uint64_t *__restrict__ zero2) {
+                            uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) { zero2[0] = 0; zero2[1] = 0; }
+    if (p == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
     if (p >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[p] = 0; return; }
     uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
@@ -1086,6 +1086,201 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
             a.wave_counts[(uint64_t)item * JOIN_WAVES + wave] = my_matches;
             a.wave_agg[(uint64_t)item * JOIN_WAVES + wave] = my_agg;
         }
+    }
+}
+
+// ---- materialisation in ONE probe ----
+// The reference's lead timed run writes its output in the same probe that finds the matches: matching lanes are ranked
+// by a ballot into a small shared-memory staging block and one reservation on a global counter is taken per flush
+// (join_partitioned_results, jp.cu:1228-1261, 1358-1388: 16 pairs per warp, one atomicAdd per 32 ints).  Same idea sized
+// for gfx950: the whole workgroup stages into ONE block of stage_cap matches in LDS (6 bytes per match: the probe
+// payload and the 16-bit slot of the build tuple in the LDS table — key and build payload are read back from the table at
+// flush time), so an item of the default size (one ~4096-tuple partition) takes ONE reservation of its exact match count
+// on the output cursor (2^30 matches: 2.6e5 returning atomics instead of the reference's 3.4e7) and leaves as three runs
+// of coalesced 4-byte-per-lane stores.  The output is gap-free, in no particular order (as in the reference: atomics decide).
+// Duplicates / probe chunks with more matches than the block holds: a wave that finds the block full keeps its chain
+// positions in registers and waits at the flush barrier; after the flush every wave resumes where it stopped.
+// LDS: head[nh] | ent[cap] | (full keys) next[cap] u16 | stage payload[stage_cap] u32 | stage slot[stage_cap] u16 | ctl[2][4].
+constexpr int MAT_R = 9;  // staged records a thread carries in registers across the reservation: 512 x 9 = 4608 = the default block
+template <bool TAG16>
+__global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t item = blockIdx.x;
+    if (item >= *a.n_items) return;
+    const uint32_t S = a.stage_cap;
+    uint32_t *head = reinterpret_cast<uint32_t *>(smem);
+    uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
+    uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
+    const size_t tbl = ((size_t)a.nh * 4 + (size_t)a.cap * 8 + (TAG16 ? 0 : (size_t)a.cap * 2) + 15) & ~(size_t)15;
+    uint32_t *sp = reinterpret_cast<uint32_t *>(smem + tbl);
+    uint16_t *ss = reinterpret_cast<uint16_t *>(smem + tbl + (size_t)S * 4);
+    uint32_t *ctl2 = reinterpret_cast<uint32_t *>(smem + tbl + (size_t)S * 4 + (((size_t)S * 2 + 15) & ~(size_t)15)); // 2 x {staged, paused, base lo, base hi}
+    uint32_t par = 0;
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
+    const JoinItem it = a.items[item];
+    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
+    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    const uint32_t plow = it.p; // the partition id is the low `bits` key bits: a 16-bit tag + the id give the key back
+    const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
+
+    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
+        const uint64_t gb = b0 + bc;
+        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+        const uint64_t wfirst = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256;
+        int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
+        if (wfirst + (uint64_t)ln * 4 < q1) {
+            nk = load4(a.pk, wfirst + (uint64_t)ln * 4, a.p_nalloc);
+            np = load4(a.pp, wfirst + (uint64_t)ln * 4, a.p_nalloc);
+        }
+        for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
+        if (tid == 0) { ctl2[par * 4] = 0; ctl2[par * 4 + 1] = 0; }
+        __syncthreads();
+        // ---- build: as k_join ----
+        for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 3) {
+            int4 bkv[3], bpv[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                if (i < gb + nbc) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint64_t idx = i + e;
+                        if (idx >= gb && idx < gb + nbc) {
+                            const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                            const uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                            if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                            else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- probe, resumable: (w0, kv, pv, pos4) is the wave's position; a wave leaves the loop when it is done or when the
+        //      staging block is full, and comes back after the flush ----
+        uint64_t w0 = wfirst;
+        bool fresh = true;
+        int4 kv = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
+        uint32_t pos4[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        for (;; par ^= 1u) {
+            uint32_t *ctl = ctl2 + par * 4; // staged, paused, base lo, base hi — the other parity's words are reset meanwhile
+            bool paused = false;
+            while (w0 < q1) { // wave-uniform
+                if (fresh) {
+                    const uint64_t i = w0 + (uint64_t)ln * 4;
+                    kv = nk; pv = np;
+                    const uint64_t inext = i + (uint64_t)JOIN_THREADS * 4;
+                    nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
+                    if (inext < q1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint64_t idx = i + e;
+                        const bool valid = idx >= q0 && idx < q1;
+                        pos4[e] = (valid ? head[((uint32_t)elem(kv, e) >> bits) & nhm] : 0xFFFFFFFFu) & 0xFFFFu;
+                    }
+                    fresh = false;
+                }
+                for (;;) {
+                    // the lane's four chains advance in lockstep (their LDS reads overlap) until each sits ON its next match
+                    // or has ended; pos4[e] stays on a match until the match has been staged
+                    uint32_t om = 0, nx4[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+                    for (;;) {
+                        bool walking = false;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const uint32_t pos = pos4[e];
+                            if (pos != 0xFFFFu && !((om >> e) & 1u)) {
+                                const uint32_t key = (uint32_t)elem(kv, e);
+                                const uint2 en = ent[pos];
+                                const uint32_t nx = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
+                                const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
+                                if (eq) { om |= 1u << e; nx4[e] = nx; }
+                                else { pos4[e] = nx; walking |= nx != 0xFFFFu; }
+                            }
+                        }
+                        if (!walking) break;
+                    }
+                    // all matches the wave sits on take their staging slots with ONE LDS atomic: chain-0 matches first, ...
+                    uint64_t m4[4];
+                    uint32_t n = 0, before[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { m4[e] = __ballot((om >> e) & 1u); before[e] = n; n += (uint32_t)__popcll(m4[e]); }
+                    if (!n) break; // every chain of every lane has ended: next 256 probe tuples
+                    uint32_t b = 0;
+                    if (ln == 0) b = atomicAdd(&ctl[0], n);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t idx = b + before[e] + (uint32_t)__popcll(m4[e] & lt_mask);
+                        if (((om >> e) & 1u) && idx < S) {
+                            sp[idx] = (uint32_t)elem(pv, e);
+                            ss[idx] = (uint16_t)pos4[e];
+                            pos4[e] = nx4[e]; // staged: move on
+                        }
+                    }
+                    if (b + n > S) { paused = true; break; } // block full: the unstaged chains stay on their matches
+                }
+                if (paused) break;
+                w0 += (uint64_t)JOIN_THREADS * 4;
+                fresh = true;
+            }
+            if (paused && ln == 0) ctl[1] = 1u;
+            __syncthreads();
+            const uint32_t staged = ctl[0], again = ctl[1];
+            const uint32_t T = staged < S ? staged : S;
+            if (tid == 0) {
+                if (T) { // one reservation of the exact number of staged matches
+                    const unsigned long long base = atomicAdd(a.out_cursor, (unsigned long long)T);
+                    ctl[2] = (uint32_t)base; ctl[3] = (uint32_t)(base >> 32);
+                }
+                ctl2[(par ^ 1u) * 4] = 0; ctl2[(par ^ 1u) * 4 + 1] = 0; // the next round's counters
+            }
+            // while the reservation is in flight: the first MAT_R records of every thread leave LDS for registers (key and
+            // build payload from the table entry of the staged slot)
+            uint32_t rk[MAT_R], rb[MAT_R], rp[MAT_R];
+#pragma unroll
+            for (int r = 0; r < MAT_R; r++) {
+                const uint32_t i = tid + (uint32_t)r * JOIN_THREADS;
+                if (i < T) {
+                    const uint2 en = ent[ss[i]];
+                    rk[r] = TAG16 ? (((en.x >> 16) << bits) | plow) : en.x;
+                    rb[r] = en.y;
+                    rp[r] = sp[i];
+                }
+            }
+            __syncthreads();
+            const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
+#pragma unroll
+            for (int r = 0; r < MAT_R; r++) {
+                const uint32_t i = tid + (uint32_t)r * JOIN_THREADS;
+                const uint64_t o = base + i;
+                if (i < T && o < a.out_cap) {
+                    a.out_key[o] = (int32_t)rk[r];
+                    a.out_bpay[o] = (int32_t)rb[r];
+                    a.out_ppay[o] = (int32_t)rp[r];
+                }
+            }
+            if (T > (uint32_t)MAT_R * JOIN_THREADS) { // a larger staging block than the registers cover (hj_config.lds_stage)
+                for (uint32_t i = tid + (uint32_t)MAT_R * JOIN_THREADS; i < T; i += JOIN_THREADS) {
+                    const uint2 en = ent[ss[i]];
+                    const uint64_t o = base + i;
+                    if (o < a.out_cap) {
+                        a.out_key[o] = (int32_t)(TAG16 ? (((en.x >> 16) << bits) | plow) : en.x);
+                        a.out_bpay[o] = (int32_t)en.y;
+                        a.out_ppay[o] = (int32_t)sp[i];
+                    }
+                }
+                __syncthreads(); // workgroup-uniform: the staging block is free again only now
+            }
+            if (!again) break;
+        }
+        __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
     }
 }
 
@@ -1321,9 +1516,9 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
     return mode == 0 ? launch_scatter_wc_t<2, 0>(st, pa) : launch_scatter_wc_t<2, 1>(st, pa);
 }
 
-hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2) {
+hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor) {
     hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt,
-                       a.bflag, a.pflag, zero2);
+                       a.bflag, a.pflag, zero2, zero_cursor);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1353,6 +1548,34 @@ hipError_t join_set_lds_limit(int device, size_t bytes) {
         if (e != hipSuccess) return e;
     }
     if (device >= 0 && device < 64) limit[device] = bytes;
+    return hipSuccess;
+}
+
+size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16, uint32_t stage_cap) {
+    const size_t tbl = ((size_t)nh * 4 + (size_t)cap * 8 + (tag16 ? 0 : (size_t)cap * 2) + 15) & ~(size_t)15;
+    return tbl + (size_t)stage_cap * 4 + (((size_t)stage_cap * 2 + 15) & ~(size_t)15) + 32;
+}
+
+hipError_t launch_join_mat(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16) {
+    static size_t limit[64] = {};
+    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        if (dev < 0 || dev >= 64 || lds > limit[dev]) {
+            const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat<true>), reinterpret_cast<const void *>(&k_join_mat<false>)};
+            for (const void *f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            if (dev >= 0 && dev < 64) limit[dev] = lds;
+        }
+    }
+    dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
+    if (tag16) hipLaunchKernelGGL((k_join_mat<true>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_join_mat<false>), g, b, lds, st, a);
+    HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
 

@@ -56,7 +56,13 @@ typedef struct hj_config {
                             * bump-allocated buckets of jp.cu:138-192 without their atomics) and falls back to the exact
                             * passes when skew overflows a slot (the overflow flag travels with the join's result block; a
                             * flagged relation is re-partitioned and the join re-run inside the same call). */
-    uint32_t reserved[8];
+    uint32_t materialize_two_pass; /* 0: hj_join_materialize writes the output in ONE probe (matches staged in LDS, one
+                            * reservation on a global output cursor per flush, as join_partitioned_results jp.cu:1228-1261 does
+                            * per warp).  1: count, scan, second probe writing at the scanned positions — no output atomics, the
+                            * order of the output is a function of the partitions alone. */
+    uint32_t lds_stage;    /* one-probe materialisation: matches staged in LDS per flush (one output reservation each);
+                            * 0 = what fits next to the hash table at two workgroups per CU (~4700) */
+    uint32_t reserved[6];
 } hj_config;
 
 /* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream).
@@ -104,8 +110,9 @@ int hj_partition(hj_ctx *ctx, int rel);
  * jp.cu:1073,1092).  Either pointer may be NULL.  [sync] */
 int hj_join_count(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
 /* Build+probe and write every (key,payR,payS) output tuple to the caller's HBM columns
- * (join_partitioned_results jp.cu:1107-1416, without its 2^24 FOLD ring: every tuple is kept).
- * cap = capacity of each output column in tuples; *n_out = tuples produced.  HJ_ECAPACITY if
+ * (join_partitioned_results jp.cu:1107-1416, without its 2^24 FOLD ring: every tuple is kept), in the same probe that
+ * finds the matches (the reference's lead timed run, hjcp.cu:913,937-940).  The output is gap-free [0, n_out), its order
+ * unspecified.  cap = capacity of each output column in tuples; *n_out = tuples produced.  HJ_ECAPACITY if
  * n_out > cap (nothing beyond cap is written).  [sync] */
 int hj_join_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap,
                         uint64_t *n_out);

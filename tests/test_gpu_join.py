@@ -40,14 +40,33 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
         m, agg = hj.join()
         assert (m, agg) == (em, eagg), ("count/agg", (m, agg), (em, eagg), hj.config())
         if materialize:
-            k, pr, ps = hj.join_materialize()
-            assert len(k) == em
-            assert o.triples_checksum(k, pr, ps) == echk
-            if em <= 2_000_000:
-                ek, epr, eps = o.join_materialize(R, Pr, S, Ps)
-                got, exp = sorted_triples(k, pr, ps), sorted_triples(ek, epr, eps)
-                for a, b in zip(got, exp):
-                    assert np.array_equal(a, b)
+            exp = sorted_triples(*o.join_materialize(R, Pr, S, Ps)) if em <= 2_000_000 else None
+
+            def check(k, pr, ps, what):
+                assert len(k) == em, what
+                assert o.triples_checksum(k, pr, ps) == echk, what
+                if exp is not None:
+                    for a, b in zip(sorted_triples(k, pr, ps), exp):
+                        assert np.array_equal(a, b), what
+
+            # materialisation in ONE probe (the default): behind a count (item list reused) ...
+            check(*hj.join_materialize(), "one probe, after a count")
+            # ... on fresh partitions with no count before it (the timed shape: partition, partition, materialise) ...
+            hj.partition(P.REL_R)
+            hj.partition(P.REL_S)
+            check(*hj.join_materialize(cap=em), "one probe, no count")
+            # ... with a staging block so small that every wave stops and resumes many times ...
+            hj.configure(**dict(cfg or {}, lds_stage=64))
+            hj.partition(P.REL_R)
+            hj.partition(P.REL_S)
+            check(*hj.join_materialize(cap=em), "one probe, 64-match staging block")
+            # ... and the two-probe path (count, scan, second probe at scanned positions)
+            hj.configure(**dict(cfg or {}, materialize_two_pass=True))
+            assert hj.join() == (em, eagg)
+            check(*hj.join_materialize(), "two probes")
+            hj.partition(P.REL_R)
+            hj.partition(P.REL_S)
+            check(*hj.join_materialize(cap=em), "two probes, no count")
         return hj.config()
 
 

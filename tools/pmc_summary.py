@@ -34,7 +34,10 @@ def main():
                 if c in e:
                     e[c + "_over_WAVE_CYCLES"] = e[c]["per_launch"] / e["SQ_WAVE_CYCLES"]["per_launch"]
         out[k] = e
-    json.dump({"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icde2019-gpu-join_amd", "libhj.so")
+    json.dump({"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+               "command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                           "--no-cpu-baseline --no-materialize --no-extras " + " ".join(sys.argv[2:]) +
                           " (one pass per counter group; FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE doubled per MI355X_MICROARCH.md HBM)",
                "kernels": out}, sys.stdout, indent=1, sort_keys=True)
