@@ -5,8 +5,12 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhj.so")
-BENCH_PATH = os.path.join(_HERE, "bench")
+# HJ_ASAN=1 (CPU test leg only, tests/test_asan.py): the host-only AddressSanitizer/UBSan build of the plain-C++ half of the
+# library (generator drop-in, host write-combining split, shard function) and of the driver (`make asan`).  It has no GPU
+# entry points: only the symbols it exports are bound.
+ASAN = os.environ.get("HJ_ASAN") == "1"
+LIB_PATH = os.path.join(_HERE, "libhj_host_asan.so" if ASAN else "libhj.so")
+BENCH_PATH = os.path.join(_HERE, "bench_asan" if ASAN else "bench")
 
 i32p = C.POINTER(C.c_int32)
 u64p = C.POINTER(C.c_uint64)
@@ -97,7 +101,7 @@ _lib = None
 def build(force=False):
     """Compile libhj.so and bench for gfx950 (hipcc cross-compiles without a GPU)."""
     if force or not (os.path.exists(LIB_PATH) and os.path.exists(BENCH_PATH)):
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "all"])
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "asan" if ASAN else "all"])
     return LIB_PATH
 
 
@@ -107,6 +111,8 @@ def lib():
         build()
         _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # always the in-tree build: no override
         for name, (res, argt) in SIGNATURES.items():
+            if ASAN and not hasattr(_lib, name):
+                continue  # a GPU entry point: not part of the host-only sanitizer build
             f = getattr(_lib, name)  # AttributeError if the header and the library disagree
             f.restype = res
             f.argtypes = argt

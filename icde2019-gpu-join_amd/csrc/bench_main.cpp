@@ -14,7 +14,9 @@
 // is named unique_skew<theta>_S<m>.bin (D7: the reference's sprintf has one argument too few);
 // relation files are checked for short reads (D12).
 #include <getopt.h>
+#ifndef HJ_HOST_ONLY
 #include <hip/hip_runtime.h>
+#endif
 #include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,6 +31,13 @@
 
 #include "hj.h"
 #include "hj_reference_abi.h"
+
+#ifdef HJ_HOST_ONLY
+// `make asan`: the driver without a GPU path (option parsing, cache-file naming, generation: -b 8), linked against the
+// host-only sanitizer build of the library.  -b 7 reports that this build cannot join.
+extern "C" unsigned int hashJoinClusteredProbe(args *, timingInfo *) { fprintf(stderr, "GPU Error: host-only build\n"); return 0; }
+extern "C" void hj_reference_last_result(hj_last_result *out) { memset(out, 0, sizeof *out); out->status = HJ_EHIP; }
+#endif
 
 namespace {
 
@@ -178,6 +187,7 @@ CpuJoin cpu_join(const int32_t *R, uint64_t nR, const int32_t *S, uint64_t nS) {
     return out;
 }
 
+#ifndef HJ_HOST_ONLY
 // --gpus N (N > 1): the reference joins level-0 partitions independently (hjcp.cu:1503-1618); here each of N GPUs gets
 // one level-0 shard of R and S (host split, hj_host_split), its own context and host thread, and the counts add up.
 struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0, split_gbs = 0; int status = 0; };
@@ -218,11 +228,18 @@ MultiResult multi_gpu_join(const args &ja, int gpus) {
     return out;
 }
 
+#else
+struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0, split_gbs = 0; int status = HJ_EHIP; };
+MultiResult multi_gpu_join(const args &, int) { return MultiResult(); }
+#endif
+
 int32_t *alloc_col(uint64_t n, bool *pinned) {
     void *p = nullptr;
     size_t bytes = (size_t)(n ? n : 1) * sizeof(int32_t);
     // main.cu:181-183 (MEM_HOST): pinned, mapped host columns; plain malloc when no GPU is present (-b 8)
+#ifndef HJ_HOST_ONLY
     if (hipHostMalloc(&p, bytes, hipHostMallocMapped) == hipSuccess) { *pinned = true; return (int32_t *)p; }
+#endif
     *pinned = false;
     return (int32_t *)malloc(bytes);
 }
@@ -379,7 +396,12 @@ int main(int argc, char **argv) {
         if (in.cpu_baseline) printf(", \"cpu_baseline\": {\"seconds\": %.4f, \"threads\": %u, \"matches\": %llu}", cpu.seconds, cpu.threads, cpu.matches);
         printf("}\n");
     }
+#ifndef HJ_HOST_ONLY
     if (pin_r) (void)hipHostFree(ja.R); else free(ja.R);
     if (pin_s) (void)hipHostFree(ja.S); else free(ja.S);
+#else
+    free(ja.R);
+    free(ja.S);
+#endif
     return status;
 }

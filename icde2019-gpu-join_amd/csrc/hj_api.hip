@@ -10,9 +10,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 #include <algorithm>
 #include <chrono>
@@ -23,6 +20,7 @@
 
 #include "hj.h"
 #include "hj_internal.h"
+#include "hj_host.h"
 
 using namespace hj;
 
@@ -1088,110 +1086,6 @@ int hj_join_stream_probe_materialize(hj_ctx *c, const int32_t *h_keys, const int
     return stream_probe(c, h_keys, h_pays, n, segment_tuples, payload_mode, n_out, agg, out, cap);
 }
 
-namespace {
-
-// Host-side level-0 split (the role of partitions_host_omp_nontemporal_payload, partition-primitives.cu:40-125, and
-// partition_prepare/do_payload :129-232): per-thread histograms over contiguous chunks, prefix, then a scatter through
-// per-thread SOFTWARE WRITE-COMBINING buffers — one 64-byte line of keys and one of payloads per partition, mirroring
-// the 64-byte-aligned destination line being filled — flushed with non-temporal AVX2 stores, so the output lines are
-// never read into the cache (the reference's scheme; it keeps 256-tuple batches per partition, LOG_BATCH, and assumes
-// aligned outputs; here a run may start anywhere: its first line is written with plain stores).
-// Partition id = hj_shard_of(key, parts) (hash: balanced for dense keys).
-constexpr uint32_t HWC = 16; // tuples per 64-byte line
-
-// Streaming (non-temporal) line flush: AVX2 on x86-64 hosts that have it (checked once at run time); everywhere else the
-// lines leave with plain stores — same result, the destination lines are then read for ownership first.
-#if defined(__x86_64__)
-__attribute__((target("avx2"))) void wc_flush_line(int32_t *dst, const int32_t *src) {
-    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), _mm256_load_si256(reinterpret_cast<const __m256i *>(src)));
-    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 8), _mm256_load_si256(reinterpret_cast<const __m256i *>(src + 8)));
-}
-bool host_has_streaming_stores() { static const bool ok = __builtin_cpu_supports("avx2"); return ok; }
-void wc_fence() { _mm_sfence(); }
-#else
-void wc_flush_line(int32_t *dst, const int32_t *src) { memcpy(dst, src, HWC * 4); }
-bool host_has_streaming_stores() { return false; }
-void wc_fence() {}
-#endif
-
-void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
-                                                      const uint64_t *start, int32_t *oK, int32_t *oP, bool stream) {
-    // line[p]: 64-byte-aligned output position of the line being filled; fill[p]: next slot; first[p]: first valid slot
-    std::vector<uint64_t> line(parts);
-    std::vector<uint8_t> fill(parts), first(parts);
-    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4);
-    for (uint32_t p = 0; p < parts; p++) {
-        line[p] = start[p] & ~(uint64_t)(HWC - 1);
-        fill[p] = first[p] = (uint8_t)(start[p] & (HWC - 1));
-    }
-    for (uint64_t i = lo; i < hi; i++) {
-        const int32_t key = K[i];
-        const uint32_t p = host_shard_of(key, parts);
-        uint32_t s = fill[p];
-        bufK[p * HWC + s] = key;
-        if (oP) bufP[p * HWC + s] = Pv ? Pv[i] : 1;
-        if (++s == HWC) { // the line is complete: it leaves with streaming stores (no read-for-ownership of the destination)
-            const uint64_t o = line[p];
-            if (first[p] == 0 && stream) {
-                wc_flush_line(oK + o, bufK + p * HWC);
-                if (oP) wc_flush_line(oP + o, bufP + p * HWC);
-            } else {
-                for (uint32_t j = first[p]; j < HWC; j++) { oK[o + j] = bufK[p * HWC + j]; if (oP) oP[o + j] = bufP[p * HWC + j]; }
-                first[p] = 0;
-            }
-            line[p] = o + HWC;
-            s = 0;
-        }
-        fill[p] = (uint8_t)s;
-    }
-    for (uint32_t p = 0; p < parts; p++) // half-full lines
-        for (uint32_t j = first[p]; j < fill[p]; j++) { oK[line[p] + j] = bufK[p * HWC + j]; if (oP) oP[line[p] + j] = bufP[p * HWC + j]; }
-    wc_fence();
-    free(bufK);
-    free(bufP);
-}
-
-// false: a host thread could not be started (pids limit of the container): nothing usable was written
-bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
-                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off) {
-    if (threads < 1) threads = 1;
-    std::vector<uint64_t> hist((size_t)threads * parts, 0);
-    auto chunk = [&](uint32_t t, uint64_t &lo, uint64_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
-    // run f(t) for t = 0..threads-1 on that many host threads; thread 0's share runs on the caller
-    auto parallel = [&](auto f) -> bool {
-        std::vector<std::thread> th;
-        bool ok = true;
-        try {
-            for (uint32_t t = 1; t < threads; t++) th.emplace_back(f, t);
-        } catch (const std::system_error &) { ok = false; }
-        if (ok) f(0);
-        for (auto &x : th) x.join();
-        return ok;
-    };
-    if (!parallel([&](uint32_t t) {
-            uint64_t lo, hi; chunk(t, lo, hi);
-            uint64_t *h = hist.data() + (size_t)t * parts;
-            for (uint64_t i = lo; i < hi; i++) h[host_shard_of(K[i], parts)]++;
-        })) return false;
-    off.assign(parts + 1, 0);
-    uint64_t sum = 0;
-    for (uint32_t p = 0; p < parts; p++) {
-        off[p] = sum;
-        for (uint32_t t = 0; t < threads; t++) { uint64_t cnt = hist[(size_t)t * parts + p]; hist[(size_t)t * parts + p] = sum; sum += cnt; }
-    }
-    off[parts] = sum;
-    // 64-byte streaming stores need 64-byte-aligned columns (pinned staging is page-aligned) and a CPU that has them; two
-    // threads may share the destination line where their runs of a partition meet: both write their own slots with plain
-    // stores (first/last line)
-    const bool stream = host_has_streaming_stores() && (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
-    return parallel([&](uint32_t t) {
-        uint64_t lo, hi; chunk(t, lo, hi);
-        wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream);
-    });
-}
-
-} // namespace
-
 // CPU-GPU co-processing (outOfGPU_Join2_payload, hjcp.cu:1000-1680): both relations live in HOST memory;
 // the host splits them into level-0 partitions (16-way on 16 threads in the reference, hjcp.cu:1256-1266,
 // pp.cuh:38-39), and every level-0 partition pair is an independent join (hjcp.cu:1503-1618): uploaded
@@ -1289,19 +1183,6 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     if (rc) return rc;
     if (matches) *matches = tot_m;
     if (agg) *agg = tot_a;
-    return HJ_OK;
-}
-
-int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads, int32_t *out_keys,
-                  int32_t *out_pays, uint64_t *offsets, double *gbs) {
-    if ((n && (!keys || !out_keys)) || !offsets || parts == 0 || parts > 4096) return HJ_EINVAL;
-    if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> off;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (!host_level0_split(keys, pays, n, parts, threads, out_keys, out_pays, off)) return HJ_ENOMEM;
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (uint32_t p = 0; p <= parts; p++) offsets[p] = off[p];
-    if (gbs) *gbs = dt > 0 ? (out_pays ? 16.0 : 8.0) * (double)n / dt / 1e9 : 0;
     return HJ_OK;
 }
 
@@ -1444,8 +1325,6 @@ int hj_shard_count(hj_ctx *c, const int32_t *d_keys, uint64_t n, uint32_t nshard
     for (uint32_t i = 0; i < nshards; i++) h_counts[i] = c->h_shard_off[i];
     return HJ_OK;
 }
-
-uint32_t hj_shard_of(int32_t key, uint32_t nshards) { return host_shard_of(key, nshards); }
 
 int hj_gen_unique(hj_ctx *c, int32_t *d_keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed) {
     if (!c) return HJ_EINVAL;

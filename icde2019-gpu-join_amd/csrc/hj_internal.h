@@ -129,7 +129,6 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
 hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts);
-uint32_t host_shard_of(int32_t key, uint32_t nshards);
 
 } // namespace hj
 #endif

@@ -1797,10 +1797,4 @@ hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, co
     return hipSuccess;
 }
 
-uint32_t host_shard_of(int32_t key, uint32_t nshards) {
-    uint32_t h = (uint32_t)key;
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return (uint32_t)(((uint64_t)h * nshards) >> 32);
-}
-
 } // namespace hj

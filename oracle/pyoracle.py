@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+# HJ_ASAN=1 (tests/test_asan.py): the AddressSanitizer/UBSan build of the oracle (`make -C oracle asan`)
+_ASAN = os.environ.get("HJ_ASAN") == "1"
+_SO = os.path.join(_HERE, "liboracle_asan.so" if _ASAN else "liboracle.so")
 _lib = None
 
 _i32p = C.POINTER(C.c_int32)
@@ -20,7 +22,7 @@ _u64p = C.POINTER(C.c_uint64)
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
     if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     ref = os.environ.get("HJ_REFERENCE", "/root/reference")
     if os.path.isdir(ref) and (force or not os.path.exists(os.path.join(_HERE, "_ref", "refgen"))
                                or not os.path.exists(os.path.join(_HERE, "_ref", "refjoin"))):
