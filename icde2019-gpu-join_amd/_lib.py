@@ -35,6 +35,17 @@ class Args(C.Structure):  # include/hj_reference_abi.h  (src/common-host.h:39-52
                 ("threadsNum", C.c_int), ("sharedMem", C.c_uint), ("pivotsNum", C.c_uint)]
 
 
+class DistConfig(C.Structure):  # include/hj_dist.h
+    _fields_ = [("slices", C.c_uint32), ("exact_only", C.c_uint32), ("self_via_link", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+
+class DistStats(C.Structure):
+    _fields_ = [("received", C.c_uint64 * 2), ("link_bytes", C.c_uint64), ("payload_bytes", C.c_uint64), ("path", C.c_uint32),
+                ("slices", C.c_uint32), ("spans_per_slice", C.c_uint32), ("slot_capacity", C.c_uint32 * 2),
+                ("split_ms", C.c_float * 2), ("pass1_ms", C.c_float * 2), ("pass2_join_ms", C.c_float),
+                ("first_split_ms", C.c_float), ("last_pass1_ms", C.c_float), ("wall_ms", C.c_float), ("reserved", C.c_uint32 * 8)]
+
+
 class LastResult(C.Structure):
     _fields_ = [("matches", C.c_ulonglong), ("agg", C.c_ulonglong), ("materialized", C.c_ulonglong),
                 ("partition_ms", C.c_double * 2), ("join_ms", C.c_double * 2), ("status", C.c_int)]
@@ -91,6 +102,23 @@ SIGNATURES = {
     "hj_create_relation_n": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64]),
     "hj_read_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
     "hj_write_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
+    "hj_dist_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]),
+    "hj_dist_destroy": (C.c_int, [vp]),
+    "hj_dist_error": (C.c_char_p, [vp]),
+    "hj_dist_world": (C.c_int, [vp]),
+    "hj_dist_transport": (C.c_char_p, [vp]),
+    "hj_dist_context": (vp, [vp, C.c_int]),
+    "hj_dist_configure": (C.c_int, [vp, C.POINTER(DistConfig)]),
+    "hj_dist_bind": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_uint64]),
+    "hj_dist_join": (C.c_int, [vp, u64p, u64p]),
+    "hj_dist_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(DistStats)]),
+    "hj_dist_unique_id": (C.c_int, [vp]),
+    "hj_dist_rank_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, vp]),
+    "hj_dist_rank_destroy": (C.c_int, [vp]),
+    "hj_dist_rank_error": (C.c_char_p, [vp]),
+    "hj_dist_rank_configure": (C.c_int, [vp, C.POINTER(DistConfig)]),
+    "hj_dist_rank_join": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, u64p, u64p]),
+    "hj_dist_rank_get_stats": (C.c_int, [vp, C.POINTER(DistStats)]),
     "hashJoinClusteredProbe": (C.c_uint, [C.POINTER(Args), vp]),
     "hj_reference_last_result": (None, [C.POINTER(LastResult)]),
 }

@@ -21,92 +21,12 @@
 #include "hj.h"
 #include "hj_internal.h"
 #include "hj_host.h"
+#include "hj_ctx.h"
 
 using namespace hj;
+using namespace hjx;
 
-namespace {
-
-constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-byte tail loads)
-constexpr uint32_t TARGET_SPANS = 1024; // 4 spans per CU: measured best (profiles/r1_spans_sweep.txt)
-constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 65536;
-constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
-
-struct KStat { std::string name; uint32_t launches = 0; float total_ms = 0, last_ms = 0; };
-struct Stamp { int kid; hipEvent_t a, b; };
-
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct Rel {
-    const int32_t *in_k = nullptr, *in_p = nullptr; // input columns (caller's or own_*)
-    uint64_t n = 0;
-    bool bound = false;
-    Buf own_k, own_p;         // hj_load_host copies
-    Buf a_k, a_p, b_k, b_p;   // pass-1 / final partitioned columns
-    Buf off1, off2, root;     // partition offsets (uint64) of the exact passes
-    Buf beg, end;             // final partition ranges [nparts] (uint64): what the join reads, whichever path ran
-    Buf s1beg, s1end;         // slot ranges written by the histogram-free pass 1 [P1 * nspans]
-    Buf comp_k, comp_p, comp_off; // gap-free copy for hj_get_partitions when the layout is slotted
-    const int32_t *part_k = nullptr, *part_p = nullptr;
-    const uint64_t *part_beg = nullptr, *part_end = nullptr;
-    const uint64_t *part_off = nullptr; // nparts+1 contiguous offsets: only valid when the exact passes ran
-    uint64_t n_alloc = 0;      // elements of the partitioned columns (bounds of 16-byte tail loads)
-    uint32_t nparts = 0;
-    uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
-    bool partitioned = false;
-    bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
-    bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
-    bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
-};
-
-} // namespace
-
-struct hj_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr, own_stream = nullptr;
-    hj_config cfg{};
-    uint32_t bits1 = 0, bits2 = 0, cap = 0, nh = 0, chunk = 0; // effective
-    int build = HJ_REL_R;
-    std::string err;
-    Rel rel[2];
-    // workspace
-    struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
-    Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
-    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat
-    uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
-    bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
-    bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
-    JoinArgs last_args{};
-    bool last_tag16 = false;
-    uint64_t last_matches = 0, last_agg = 0;
-    uint32_t max_items = 0;
-    uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
-    uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
-    uint32_t stage_cap = 0;         // experiment knob (HJ_STAGE_CAP): staged matches per flush of the one-probe materialising kernel
-    bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
-    int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
-    hipStream_t copy = nullptr;     // H2D of the next probe segment
-    Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)
-    uint64_t *h_shard_off = nullptr;
-    Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
-    Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
-    int32_t *host_k[2] = {nullptr, nullptr}, *host_p[2] = {nullptr, nullptr}; // pinned staging of the host split (R, S): kept across calls
-    size_t host_cap[2] = {0, 0};    // elements
-    double host_split_gbs = 0;      // throughput of the last host level-0 split (bytes read + written per second)
-    Buf out_k[2], out_p1[2], out_p2[2]; // streamed materialisation: double-buffered device output columns
-    hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
-    hipEvent_t out_ready[2] = {}, out_free[2] = {};
-    hipEvent_t seg_ready[2] = {};
-    // timing
-    int events = 0;                 // 0 none (default), 1 main kernels (partition passes / join), 2 every launch: hj_enable_timings, HJ_KERNEL_EVENTS
-    std::vector<KStat> kstats;
-    std::vector<Stamp> stamps;
-    std::vector<hipEvent_t> pool;
-};
-
-namespace {
+namespace hjx {
 
 int fail(hj_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -117,20 +37,6 @@ int fail(hj_ctx *c, int code, const char *fmt, ...) {
     if (c) c->err = buf;
     return code;
 }
-
-#define HIPCHK(c, call)                                                                              \
-    do {                                                                                              \
-        hipError_t e__ = (call);                                                                      \
-        if (e__ != hipSuccess)                                                                        \
-            return fail(c, e__ == hipErrorOutOfMemory ? HJ_ENOMEM : HJ_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
-                        hipGetErrorString(e__));                                                      \
-    } while (0)
-
-#define RET(x)                                                                                        \
-    do {                                                                                              \
-        int r__ = (x);                                                                                \
-        if (r__) return r__;                                                                          \
-    } while (0)
 
 int ensure(hj_ctx *c, Buf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return 0;
@@ -193,38 +99,32 @@ void resolve_completed(hj_ctx *c) {
 }
 
 // RAII: HIP events on the context stream around one kernel launch
-struct Timed {
-    hj_ctx *c;
-    Stamp s;
-    bool on;
-    hipStream_t st;
-    static bool is_main(const char *n) {
-        return !strncmp(n, "k_hist", 6) || !strncmp(n, "k_scatter", 9) || !strncmp(n, "k_part", 6) || !strncmp(n, "k_join_count", 12) ||
-               !strncmp(n, "k_join_mat", 10) || !strncmp(n, "k_join_late", 11) || !strncmp(n, "k_np_", 5);
+bool Timed::is_main(const char *n) {
+    return !strncmp(n, "k_hist", 6) || !strncmp(n, "k_scatter", 9) || !strncmp(n, "k_part", 6) || !strncmp(n, "k_join_count", 12) ||
+           !strncmp(n, "k_join_mat", 10) || !strncmp(n, "k_join_late", 11) || !strncmp(n, "k_np_", 5) || !strncmp(n, "k_split", 7);
+}
+// Each timed launch costs two event records on the stream; timing all ~35 launches of a step costs 4 %
+// at 2^30 x 2^30 and 27 % at 2^24 (measured), so by default only the kernels that move data are timed.
+Timed::Timed(hj_ctx *ctx, const char *name, hipStream_t stream, bool use_given)
+    : c(ctx), on(ctx->events == 2 || (ctx->events == 1 && is_main(name))), st(use_given ? stream : ctx->stream) {
+    if (!on) return;
+    if (c->stamps.size() >= 256) resolve_completed(c);
+    s.kid = kid_of(c, name);
+    s.a = get_event(c);
+    s.b = get_event(c);
+    if (!s.a || !s.b) { // out of events: run untimed rather than record a null event
+        if (s.a) c->pool.push_back(s.a);
+        if (s.b) c->pool.push_back(s.b);
+        on = false;
+        return;
     }
-    // Each timed launch costs two event records on the stream; timing all ~35 launches of a step costs 4 %
-    // at 2^30 x 2^30 and 27 % at 2^24 (measured), so by default only the kernels that move data are timed.
-    Timed(hj_ctx *ctx, const char *name, hipStream_t stream = nullptr, bool use_given = false)
-        : c(ctx), on(ctx->events == 2 || (ctx->events == 1 && is_main(name))), st(use_given ? stream : ctx->stream) {
-        if (!on) return;
-        if (c->stamps.size() >= 256) resolve_completed(c);
-        s.kid = kid_of(c, name);
-        s.a = get_event(c);
-        s.b = get_event(c);
-        if (!s.a || !s.b) { // out of events: run untimed rather than record a null event
-            if (s.a) c->pool.push_back(s.a);
-            if (s.b) c->pool.push_back(s.b);
-            on = false;
-            return;
-        }
-        (void)hipEventRecord(s.a, st);
-    }
-    ~Timed() {
-        if (!on) return;
-        (void)hipEventRecord(s.b, st);
-        c->stamps.push_back(s);
-    }
-};
+    (void)hipEventRecord(s.a, st);
+}
+Timed::~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(s.b, st);
+    c->stamps.push_back(s);
+}
 
 // after a synchronisation of every stream that carries stamps
 void resolve_stamps(hj_ctx *c) {
@@ -347,7 +247,7 @@ int check_rel(hj_ctx *c, int rel) {
     return 0;
 }
 
-void invalidate(hj_ctx *c, int rel = -1) {
+void invalidate(hj_ctx *c, int rel) {
     if (rel < 0) c->rel[0].partitioned = c->rel[1].partitioned = false;
     else c->rel[rel].partitioned = false;
     c->join_planned = false;
@@ -355,7 +255,6 @@ void invalidate(hj_ctx *c, int rel = -1) {
 
 // Geometry of the histogram-free passes for a relation of n tuples (see hj_kernels.hip): spans of pass 1, slot
 // capacities of both passes.  false when the slotted layout would not fit 32-bit positions.
-struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; };
 bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f) {
     if (n == 0) return false;
     // one workgroup per CU up to 2^28 tuples (fewer, longer spans: the per-span prologue and partial-line epilogue weigh
@@ -593,7 +492,24 @@ int count_and_fetch(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = 
     return 0;
 }
 
-} // namespace
+// hj_dist.hip: the count without the local redo — a raised overflow flag must reach every rank before anybody re-partitions.
+// The flags are in c->h_scalars[8], [9] afterwards (and c->redo_mask); with a flag up the kernels did nothing: matches = 0.
+int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
+    JoinArgs a;
+    bool tag16;
+    RET(run_count(c, a, tag16));
+    RET(fetch_scalars(c));
+    if (matches) *matches = c->h_scalars[1];
+    if (agg) *agg = c->h_scalars[2];
+    return 0;
+}
+
+void hj_invalidate_all(hj_ctx *c) {
+    invalidate(c);
+    for (int r = 0; r < 2; r++) { c->rel[r].fast_tried = false; c->rel[r].flag_known_good = false; c->rel[r].bound = false; }
+}
+
+} // namespace hjx
 
 // ================================================================================================
 // C ABI

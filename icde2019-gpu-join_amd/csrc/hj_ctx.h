@@ -1,0 +1,142 @@
+// hj_ctx.h — the context behind the C ABI (include/hj.h) and the internal helpers hj_api.hip shares with hj_dist.hip.
+#ifndef HJ_CTX_H_
+#define HJ_CTX_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "hj.h"
+#include "hj_internal.h"
+
+namespace hjx {
+
+constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-byte tail loads)
+constexpr uint32_t TARGET_SPANS = 1024; // 4 spans per CU: measured best (profiles/r1_spans_sweep.txt)
+constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 65536;
+constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
+
+struct KStat { std::string name; uint32_t launches = 0; float total_ms = 0, last_ms = 0; };
+struct Stamp { int kid; hipEvent_t a, b; };
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Rel {
+    const int32_t *in_k = nullptr, *in_p = nullptr; // input columns (caller's or own_*)
+    uint64_t n = 0;
+    bool bound = false;
+    Buf own_k, own_p;         // hj_load_host copies
+    Buf a_k, a_p, b_k, b_p;   // pass-1 / final partitioned columns
+    Buf off1, off2, root;     // partition offsets (uint64) of the exact passes
+    Buf beg, end;             // final partition ranges [nparts] (uint64): what the join reads, whichever path ran
+    Buf s1beg, s1end;         // slot ranges written by the histogram-free pass 1 [P1 * nspans]
+    Buf comp_k, comp_p, comp_off; // gap-free copy for hj_get_partitions when the layout is slotted
+    const int32_t *part_k = nullptr, *part_p = nullptr;
+    const uint64_t *part_beg = nullptr, *part_end = nullptr;
+    const uint64_t *part_off = nullptr; // nparts+1 contiguous offsets: only valid when the exact passes ran
+    uint64_t n_alloc = 0;      // elements of the partitioned columns (bounds of 16-byte tail loads)
+    uint32_t nparts = 0;
+    uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
+    bool partitioned = false;
+    bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
+    bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
+    bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
+};
+
+} // namespace hjx
+
+struct hj_ctx {
+    using Buf = hjx::Buf; using Rel = hjx::Rel; using KStat = hjx::KStat; using Stamp = hjx::Stamp;
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    hj_config cfg{};
+    uint32_t bits1 = 0, bits2 = 0, cap = 0, nh = 0, chunk = 0; // effective
+    int build = HJ_REL_R;
+    std::string err;
+    Rel rel[2];
+    // workspace
+    struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
+    Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
+    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat
+    uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
+    bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
+    bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
+    hj::JoinArgs last_args{};
+    bool last_tag16 = false;
+    uint64_t last_matches = 0, last_agg = 0;
+    uint32_t max_items = 0;
+    uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
+    uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
+    uint32_t stage_cap = 0;         // experiment knob (HJ_STAGE_CAP): staged matches per flush of the one-probe materialising kernel
+    bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
+    int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
+    hipStream_t copy = nullptr;     // H2D of the next probe segment
+    Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)
+    uint64_t *h_shard_off = nullptr;
+    Buf seg_k[2], seg_p[2];         // double-buffered probe segments / level-0 S partitions
+    Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
+    int32_t *host_k[2] = {nullptr, nullptr}, *host_p[2] = {nullptr, nullptr}; // pinned staging of the host split (R, S): kept across calls
+    size_t host_cap[2] = {0, 0};    // elements
+    double host_split_gbs = 0;      // throughput of the last host level-0 split (bytes read + written per second)
+    Buf out_k[2], out_p1[2], out_p2[2]; // streamed materialisation: double-buffered device output columns
+    hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
+    hipEvent_t out_ready[2] = {}, out_free[2] = {};
+    hipEvent_t seg_ready[2] = {};
+    // timing
+    int events = 0;                 // 0 none (default), 1 main kernels (partition passes / join), 2 every launch: hj_enable_timings, HJ_KERNEL_EVENTS
+    std::vector<KStat> kstats;
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> pool;
+};
+
+
+namespace hjx {
+
+int fail(hj_ctx *c, int code, const char *fmt, ...);
+int ensure(hj_ctx *c, Buf &b, size_t bytes);
+void release(Buf &b);
+void choose_bits(hj_ctx *c);
+void invalidate(hj_ctx *c, int rel = -1);
+// Geometry of the histogram-free passes for a relation of n tuples
+struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; };
+bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f);
+int fetch_scalars(hj_ctx *c);
+int kid_of(hj_ctx *c, const char *name);
+hipEvent_t get_event(hj_ctx *c);
+void resolve_completed(hj_ctx *c);
+int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg);
+void hj_invalidate_all(hj_ctx *c);
+
+// RAII: HIP events on a stream around one kernel launch (per-kernel statistics, hj_timings)
+struct Timed {
+    hj_ctx *c;
+    hj_ctx::Stamp s;
+    bool on;
+    hipStream_t st;
+    static bool is_main(const char *n);
+    Timed(hj_ctx *ctx, const char *name, hipStream_t stream = nullptr, bool use_given = false);
+    ~Timed();
+};
+
+} // namespace hjx
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return hjx::fail(c, e__ == hipErrorOutOfMemory ? HJ_ENOMEM : HJ_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+                             hipGetErrorString(e__));                                                 \
+    } while (0)
+
+#define RET(x)                                                                                        \
+    do {                                                                                              \
+        int r__ = (x);                                                                                \
+        if (r__) return r__;                                                                          \
+    } while (0)
+
+#endif

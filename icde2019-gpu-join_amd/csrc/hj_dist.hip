@@ -1,0 +1,799 @@
+// hj_dist.hip — multi-GPU join behind the C ABI of include/hj_dist.h: level-0 shard split, all-to-all over xGMI with RCCL,
+// local radix passes + build/probe, all-reduce of the count.
+//
+// Reference analogue: the co-processing path joins 16 host-made level-0 partitions independently
+// (hash_join_clustered_probe.cu:1256-1266, 1503-1618); here the level-0 partitions are made on the GPUs and cross the links.
+//
+// One Rank object drives one GPU.  Two transports implement the same four collectives (Link):
+//   RcclLink  ncclSend/ncclRecv groups, ncclAllGather, ncclAllReduce on the rank's communication stream;
+//   CopyLink  ranks of ONE process that share a device (RCCL refuses duplicate GPUs): peers' buffers are pulled with
+//             hipMemcpyAsync, ordered by HIP events and a host barrier.  It exists so that the whole pipeline — slicing,
+//             fixed-size regions, segment tables, flag gathering, the exact fallback — runs at world sizes 2 and 3 on a
+//             one-GPU box (tests/test_dist_c.py).
+//
+// Fast path (sliced, no host read of any count):
+//   per relation, K slices; slice i: k_part1_fast<MODE 1> writes shard g's tuples into slots (g, span) of fixed capacity, so
+//   that shard g's slots are ONE contiguous region of nsp*cap tuples -> one grouped send/recv per slice moves region g to
+//   rank g (message sizes are a function of (n_max, G, K) alone) together with the slots' end positions -> the receiver
+//   turns them into a segment table (k_dist_segments) and runs its local pass 1 over the segments (k_part2_fast in its
+//   seg_pass1 geometry), pass 2 and the join as on one GPU.
+//   Streams: compute (the context's) and comm.  compute: s0 s1 p0 s2 p1 ... ; comm: x0 x1 x2 ...  (s = split, x = exchange,
+//   p = local pass 1), x_i after s_i, p_i after x_i: split(i+1) || exchange(i) || pass-1(i-1).
+//   A slot that overflows anywhere raises that rank's flag; the flags are summed with the result (one all-reduce) and every
+//   rank then repeats the join on the exact path.
+// Exact path: exact split (histogram + scatter), counts to the host, all-gather of the counts, messages of exact size,
+//   local partition + join (what dist.py did from Python in rounds 1-2).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hj.h"
+#include "hj_ctx.h"
+#include "hj_dist.h"
+#include "hj_internal.h"
+
+using namespace hj;
+using namespace hjx;
+
+namespace {
+
+constexpr uint64_t PAD = 16;
+constexpr size_t MSG_CHUNK = (size_t)512 << 20; // RCCL 2.26 / ROCm 7 corrupted single messages of >= 2 GiB (tools/rccl_2gib_repro.py)
+
+struct Msg {          // one peer's share of an exchange
+    int peer;
+    const void *src;  // what I send to peer
+    size_t sbytes;
+    void *dst;        // where peer's message to me lands
+    size_t rbytes;
+};
+
+// The collectives the pipeline needs; every call is enqueued on `st` (device buffers throughout).
+struct Link {
+    virtual ~Link() {}
+    virtual const char *name() const = 0;
+    virtual int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) = 0;
+    virtual int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) = 0; // dst[world][bytes]
+    virtual int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *scratch /* [world*n] */, hipStream_t st, std::string &err) = 0;
+};
+
+// ---- RCCL over xGMI ----
+struct RcclLink : Link {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool own = true;
+    ~RcclLink() override { if (comm && own) (void)ncclCommDestroy(comm); }
+    const char *name() const override { return "rccl"; }
+    static int chk(ncclResult_t r, const char *what, std::string &err) {
+        if (r == ncclSuccess) return 0;
+        err = std::string(what) + ": " + ncclGetErrorString(r);
+        return HJ_EHIP;
+    }
+    int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) override {
+        // ONE group = one all-to-all-v: every ordered pair has its own xGMI link, nothing is relayed
+        int rc = chk(ncclGroupStart(), "ncclGroupStart", err);
+        for (const Msg &m : msgs) {
+            for (size_t o = 0; o < m.sbytes && !rc; o += MSG_CHUNK)
+                rc = chk(ncclSend((const char *)m.src + o, std::min(MSG_CHUNK, m.sbytes - o), ncclInt8, m.peer, comm, st), "ncclSend", err);
+            for (size_t o = 0; o < m.rbytes && !rc; o += MSG_CHUNK)
+                rc = chk(ncclRecv((char *)m.dst + o, std::min(MSG_CHUNK, m.rbytes - o), ncclInt8, m.peer, comm, st), "ncclRecv", err);
+        }
+        const int rc2 = chk(ncclGroupEnd(), "ncclGroupEnd", err);
+        return rc ? rc : rc2;
+    }
+    int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) override {
+        return chk(ncclAllGather(src, dst, bytes, ncclInt8, comm, st), "ncclAllGather", err);
+    }
+    int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *, hipStream_t st, std::string &err) override {
+        return chk(ncclAllReduce(inout, inout, n, ncclUint64, ncclSum, comm, st), "ncclAllReduce", err); // wraps mod 2^64
+    }
+};
+
+// ---- ranks of one process sharing a device: pull the peers' buffers ----
+struct CopyGroup {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    std::vector<std::vector<Msg>> posted;    // per rank: its messages of the current exchange
+    std::vector<const void *> gsrc;          // per rank: source of the current all-gather
+    std::vector<hipEvent_t> ready;           // per rank: "my buffers of the current collective are written"
+    explicit CopyGroup(int w) : world(w), posted(w), gsrc(w, nullptr), ready(w, nullptr) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++waiting == world) { waiting = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+__global__ void k_sum_ranks(const uint64_t *__restrict__ gathered, uint32_t world, uint32_t n, uint64_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = 0;
+    for (uint32_t q = 0; q < world; q++) s += gathered[(uint64_t)q * n + i];
+    out[i] = s;
+}
+
+struct CopyLink : Link {
+    CopyGroup *g = nullptr;
+    int rank = 0;
+    const char *name() const override { return "device-copy"; }
+    static int chk(hipError_t e, const char *what, std::string &err) {
+        if (e == hipSuccess) return 0;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return HJ_EHIP;
+    }
+    int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) override {
+        g->posted[rank] = msgs;
+        int rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
+        g->barrier(); // every rank has posted and recorded
+        for (size_t j = 0; j < msgs.size(); j++) {
+            if (rc) break;
+            const Msg &m = msgs[j];
+            // my k-th message with peer p pairs with p's k-th message with me (both sides list their columns in the same order)
+            size_t k = 0;
+            for (size_t i = 0; i < j; i++) k += msgs[i].peer == m.peer;
+            const Msg *theirs = nullptr;
+            for (const Msg &pm : g->posted[m.peer])
+                if (pm.peer == rank) { if (k == 0) { theirs = &pm; break; } k--; }
+            if (!theirs || theirs->sbytes != m.rbytes) {
+                err = "device-copy exchange: rank " + std::to_string(rank) + " expects " + std::to_string(m.rbytes) + " bytes from rank " +
+                      std::to_string(m.peer) + ", which sends " + (theirs ? std::to_string(theirs->sbytes) : std::string("nothing")) +
+                      " (message " + std::to_string(j) + " of " + std::to_string(msgs.size()) + ", peer posted " + std::to_string(g->posted[m.peer].size()) + ")";
+                rc = HJ_EHIP;
+                break;
+            }
+            rc = chk(hipStreamWaitEvent(st, g->ready[m.peer], 0), "hipStreamWaitEvent", err);
+            if (!rc && m.rbytes) rc = chk(hipMemcpyAsync(m.dst, theirs->src, m.rbytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", err);
+        }
+        g->barrier(); // the posted lists may be overwritten
+        return rc;
+    }
+    int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) override {
+        g->gsrc[rank] = src;
+        int rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
+        g->barrier();
+        for (int q = 0; q < g->world && !rc; q++) {
+            rc = chk(hipStreamWaitEvent(st, g->ready[q], 0), "hipStreamWaitEvent", err);
+            if (!rc) rc = chk(hipMemcpyAsync((char *)dst + (size_t)q * bytes, g->gsrc[q], bytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", err);
+        }
+        g->barrier();
+        return rc;
+    }
+    int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *scratch, hipStream_t st, std::string &err) override {
+        int rc = allgather(inout, scratch, n * 8, st, err);
+        if (rc) return rc;
+        // every rank has copied every contribution before anybody overwrites its own: the stream order of each rank alone
+        // does not give that, so the ranks meet once more behind their copies
+        rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
+        g->barrier();
+        for (int q = 0; q < g->world && !rc; q++) rc = chk(hipStreamWaitEvent(st, g->ready[q], 0), "hipStreamWaitEvent", err);
+        g->barrier();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_ranks, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, scratch, (uint32_t)g->world, (uint32_t)n, inout);
+        return chk(hipGetLastError(), "k_sum_ranks", err);
+    }
+};
+
+
+} // namespace
+
+// ================================================================================================
+// one rank
+// ================================================================================================
+struct hj_dist_rank {
+    hj_ctx *c = nullptr;
+    bool own_ctx = false;
+    int rank = 0, world = 1;
+    std::unique_ptr<Link> link;
+    hj_dist_config cfg{};
+    std::string err;
+    hipStream_t comm = nullptr;
+    hj_dist_stats st{};
+    bool prefer_exact = false; // the last fast attempt overflowed somewhere: exact path until new columns are bound
+    const int32_t *last_cols[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t last_n[2] = {0, 0};
+    // buffers (grow-only)
+    hj_ctx::Buf send_k[2], send_p[2], recv_k[2], recv_p[2];
+    hj_ctx::Buf s_beg[2], s_end[2];      // slot ranges written by the split [K][G*nsp]
+    hj_ctx::Buf r_end[2];                // received end positions [K][G*nsp]
+    hj_ctx::Buf seg_beg[2], seg_end[2];  // segment tables of the local pass 1 [K][nsp*G]
+    hj_ctx::Buf small;                   // device scratch: sizes, flags, results (u64 words)
+    uint64_t *h_small = nullptr;         // pinned mirror
+    std::vector<hipEvent_t> ev_split, ev_xchg, ev_t; // per (relation, slice); timing events
+    hipEvent_t ev_misc[4] = {};
+    hj_ctx::Buf x_send_k[2], x_send_p[2], x_recv_k[2], x_recv_p[2], x_counts; // exact path
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[600];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace {
+
+#define DCHK(r, call)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess) return (r)->fail(e__ == hipErrorOutOfMemory ? HJ_ENOMEM : HJ_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+    } while (0)
+#define DRET(r, x)                                                                                          \
+    do {                                                                                                    \
+        int r__ = (x);                                                                                      \
+        if (r__) { if ((r)->err.empty()) (r)->err = hj_error((r)->c); return r__; }                         \
+    } while (0)
+#define LRET(r, x)                                                                                          \
+    do {                                                                                                    \
+        int r__ = (x);                                                                                      \
+        if (r__) return r__;                                                                                \
+    } while (0)
+
+int dist_ensure(hj_dist_rank *r, hj_ctx::Buf &b, size_t bytes) {
+    int rc = ensure(r->c, b, bytes);
+    if (rc) r->err = hj_error(r->c);
+    return rc;
+}
+
+int rank_init(hj_dist_rank *r) {
+    DCHK(r, hipSetDevice(r->c->device));
+    DCHK(r, hipStreamCreateWithFlags(&r->comm, hipStreamNonBlocking));
+    LRET(r, dist_ensure(r, r->small, 4096));
+    DCHK(r, hipMemset(r->small.p, 0, 4096));
+    DCHK(r, hipHostMalloc((void **)&r->h_small, 4096, hipHostMallocDefault));
+    for (auto &e : r->ev_misc) DCHK(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
+}
+
+void rank_free(hj_dist_rank *r) {
+    if (!r) return;
+    if (r->c) (void)hipSetDevice(r->c->device);
+    if (r->comm) (void)hipStreamSynchronize(r->comm);
+    for (int x = 0; x < 2; x++) {
+        release(r->send_k[x]); release(r->send_p[x]); release(r->recv_k[x]); release(r->recv_p[x]);
+        release(r->s_beg[x]); release(r->s_end[x]); release(r->r_end[x]); release(r->seg_beg[x]); release(r->seg_end[x]);
+        release(r->x_send_k[x]); release(r->x_send_p[x]); release(r->x_recv_k[x]); release(r->x_recv_p[x]);
+    }
+    release(r->x_counts);
+    release(r->small);
+    if (r->h_small) (void)hipHostFree(r->h_small);
+    for (auto e : r->ev_split) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_xchg) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_t) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_misc) if (e) (void)hipEventDestroy(e);
+    r->link.reset();
+    if (r->comm) (void)hipStreamDestroy(r->comm);
+    if (r->own_ctx && r->c) hj_destroy(r->c);
+    delete r;
+}
+
+// Geometry of the sliced exchange of one relation: a function of (n_max over the ranks, G, K) and the radix bits only —
+// identical on every rank, which is what makes the message sizes known without asking anybody.
+struct SliceGeom {
+    uint32_t K = 0, nsp = 0, span = 0, cap0 = 0, cap1 = 0, cap2 = 0, NS = 0;
+    uint64_t L = 0, region = 0, sizeA = 0, sizeB = 0;
+};
+bool plan_slices(uint64_t nmax, uint32_t G, uint32_t Kwant, uint32_t P1, uint32_t P2, SliceGeom &g) {
+    if (nmax == 0) nmax = 1;
+    // Pass 2 reads at most 1024 segments per parent = local pass-1 spans over all slices: K slices of <= 1024/K spans.  The
+    // default K = 4 keeps every split / pass-1 launch 256 workgroups wide (one per CU); K = 8 halves the exposed first split and
+    // last pass 1 but runs those kernels 128 wide.
+    uint32_t K = Kwant ? Kwant : 4;
+    while (K > 1 && nmax / K < ((uint64_t)1 << 16)) K--;
+    uint64_t L = (nmax + K - 1) / K;
+    L = ((L + TILE - 1) / TILE) * TILE;
+    K = (uint32_t)((nmax + L - 1) / L);
+    const uint32_t want = std::min<uint32_t>(256u, 1024u / K);
+    uint64_t span = (L + want - 1) / want;
+    span = ((span + TILE - 1) / TILE) * TILE;
+    const uint32_t nsp = (uint32_t)((L + span - 1) / span);
+    if ((uint64_t)K * nsp > 1024) return false;
+    g.K = K; g.L = L; g.span = (uint32_t)span; g.nsp = nsp; g.NS = K * nsp;
+    g.cap0 = fast_slot_cap((span + G - 1) / G, G);
+    g.region = (uint64_t)nsp * g.cap0;
+    // the local pass-1 workgroup reads the G slots (*, s): span tuples in expectation
+    uint64_t sd = 1;
+    while (sd * sd < span) sd++;
+    g.cap1 = fast_slot_cap((span + 8 * sd + P1 - 1) / P1, P1);
+    g.cap2 = fast_slot_cap((nmax + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
+    g.sizeA = (uint64_t)P1 * g.NS * g.cap1;
+    g.sizeB = (uint64_t)P1 * P2 * g.cap2;
+    const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
+    return g.sizeA < lim && g.sizeB < lim && (uint64_t)K * G * g.region < lim;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f; }
+
+// ---- the sliced fixed-size pipeline.  Returns 0 with *flagged set when some slot overflowed somewhere (result void). ----
+int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], const uint64_t nmax[2], uint64_t out[2], bool *flagged,
+              bool *applicable) {
+    hj_ctx *c = r->c;
+    const uint32_t G = (uint32_t)r->world, me = (uint32_t)r->rank;
+    *applicable = false;
+    // radix bits from the nominal sizes (every rank computes the same)
+    for (int x = 0; x < 2; x++) { c->rel[x].n = nmax[x]; c->rel[x].bound = true; }
+    choose_bits(c);
+    const uint32_t b1 = c->bits1, b2 = c->bits2;
+    if (!b2 || !c->fast_path || c->cfg.exact_only) return 0; // single-pass sizes: exact path
+    const uint32_t P1 = 1u << b1, P2 = 1u << b2;
+    SliceGeom g[2];
+    for (int x = 0; x < 2; x++)
+        if (!plan_slices(nmax[x], G, r->cfg.slices, P1, P2, g[x])) return 0;
+    *applicable = true;
+    hipStream_t cs = c->stream, ms = r->comm;
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    uint64_t *small = (uint64_t *)r->small.p; // [0..3] result block, [4..5] received, [8..] gathered flags, [64..] all-reduce scratch
+    const size_t nev = 0;
+    (void)nev;
+    // buffers + events
+    uint32_t maxK = std::max(g[0].K, g[1].K);
+    while (r->ev_split.size() < 2 * (size_t)maxK) {
+        hipEvent_t a, b, t0, t1, t2, t3;
+        DCHK(r, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        DCHK(r, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        DCHK(r, hipEventCreate(&t0)); DCHK(r, hipEventCreate(&t1)); DCHK(r, hipEventCreate(&t2)); DCHK(r, hipEventCreate(&t3));
+        r->ev_split.push_back(a); r->ev_xchg.push_back(b);
+        r->ev_t.push_back(t0); r->ev_t.push_back(t1); r->ev_t.push_back(t2); r->ev_t.push_back(t3);
+    }
+    while (r->ev_t.size() < 4 * 2 * (size_t)maxK + 4) { hipEvent_t t; DCHK(r, hipEventCreate(&t)); r->ev_t.push_back(t); }
+    for (int x = 0; x < 2; x++) {
+        const SliceGeom &q = g[x];
+        const size_t el = (size_t)q.K * G * q.region + PAD;
+        LRET(r, dist_ensure(r, r->send_k[x], el * 4)); LRET(r, dist_ensure(r, r->send_p[x], el * 4));
+        LRET(r, dist_ensure(r, r->recv_k[x], el * 4)); LRET(r, dist_ensure(r, r->recv_p[x], el * 4));
+        const size_t slots = (size_t)q.K * G * q.nsp;
+        LRET(r, dist_ensure(r, r->s_beg[x], slots * 8)); LRET(r, dist_ensure(r, r->s_end[x], slots * 8));
+        LRET(r, dist_ensure(r, r->r_end[x], slots * 8));
+        LRET(r, dist_ensure(r, r->seg_beg[x], slots * 8)); LRET(r, dist_ensure(r, r->seg_end[x], slots * 8));
+        hj_ctx::Rel &R = c->rel[x];
+        RET(ensure(c, R.a_k, (size_t)(q.sizeA + PAD) * 4)); RET(ensure(c, R.a_p, (size_t)(q.sizeA + PAD) * 4));
+        RET(ensure(c, R.b_k, (size_t)(q.sizeB + PAD) * 4)); RET(ensure(c, R.b_p, (size_t)(q.sizeB + PAD) * 4));
+        RET(ensure(c, R.s1beg, (size_t)P1 * q.NS * 8)); RET(ensure(c, R.s1end, (size_t)P1 * q.NS * 8));
+        RET(ensure(c, R.beg, (size_t)P1 * P2 * 8)); RET(ensure(c, R.end, (size_t)P1 * P2 * 8));
+        RET(ensure(c, R.root, 16));
+    }
+    // flags of both relations down, received counters zero
+    for (int x = 0; x < 2; x++) { Timed t(c, "k_set_root"); DCHK(r, launch_set_root(cs, (uint64_t *)c->rel[x].root.p, nmax[x], reinterpret_cast<uint32_t *>(sc + 8 + x))); }
+    DCHK(r, hipMemsetAsync(small + 4, 0, 16, cs));
+    r->st.link_bytes = 0; r->st.payload_bytes = 0;
+
+    auto split = [&](int x, uint32_t i) -> int {
+        const SliceGeom &q = g[x];
+        const uint64_t lo = std::min<uint64_t>((uint64_t)i * q.L, n[x]), hi = std::min<uint64_t>(lo + q.L, n[x]);
+        FastArgs fa{};
+        fa.keys = cols[2 * x] + lo; fa.pays = cols[2 * x + 1] + lo; fa.n = hi - lo; fa.span = q.span; fa.nspans = q.nsp;
+        fa.shift = 0; fa.P = G; fa.cap = q.cap0; fa.mode = 1;
+        const uint64_t base = (uint64_t)i * G * q.region; // slice i's G regions; positions inside the kernel are relative to it
+        fa.out_keys = (int32_t *)r->send_k[x].p + base; fa.out_pays = (int32_t *)r->send_p[x].p + base;
+        fa.obeg = (uint64_t *)r->s_beg[x].p + (size_t)i * G * q.nsp; fa.oend = (uint64_t *)r->s_end[x].p + (size_t)i * G * q.nsp;
+        fa.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
+        DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 0], cs));
+        { Timed t(c, "k_split_fast"); DCHK(r, launch_part1_fast(cs, fa)); }
+        DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 1], cs));
+        DCHK(r, hipEventRecord(r->ev_split[x * maxK + i], cs));
+        return 0;
+    };
+    auto exchange = [&](int x, uint32_t i) -> int {
+        const SliceGeom &q = g[x];
+        DCHK(r, hipStreamWaitEvent(ms, r->ev_split[x * maxK + i], 0));
+        const uint64_t base = (uint64_t)i * G * q.region;
+        const size_t eb = (size_t)i * G * q.nsp;
+        std::vector<Msg> mk, mp, me_;
+        for (uint32_t step = 0; step < G; step++) {
+            const uint32_t p = (me + step) % G; // rank-staggered peer order
+            const int32_t *sk = (const int32_t *)r->send_k[x].p + base + (uint64_t)p * q.region, *sp = (const int32_t *)r->send_p[x].p + base + (uint64_t)p * q.region;
+            int32_t *dk = (int32_t *)r->recv_k[x].p + base + (uint64_t)p * q.region, *dp = (int32_t *)r->recv_p[x].p + base + (uint64_t)p * q.region;
+            const uint64_t *se = (const uint64_t *)r->s_end[x].p + eb + (size_t)p * q.nsp;
+            uint64_t *de = (uint64_t *)r->r_end[x].p + eb + (size_t)p * q.nsp;
+            if (p == me && !r->cfg.self_via_link) { // own share: device copies, no link involved
+                DCHK(r, hipMemcpyAsync(dk, sk, q.region * 4, hipMemcpyDeviceToDevice, ms));
+                DCHK(r, hipMemcpyAsync(dp, sp, q.region * 4, hipMemcpyDeviceToDevice, ms));
+                DCHK(r, hipMemcpyAsync(de, se, (size_t)q.nsp * 8, hipMemcpyDeviceToDevice, ms));
+                continue;
+            }
+            mk.push_back(Msg{(int)p, sk, (size_t)q.region * 4, dk, (size_t)q.region * 4});
+            mp.push_back(Msg{(int)p, sp, (size_t)q.region * 4, dp, (size_t)q.region * 4});
+            me_.push_back(Msg{(int)p, se, (size_t)q.nsp * 8, de, (size_t)q.nsp * 8});
+            if (p != me) r->st.link_bytes += (uint64_t)q.region * 8 + (uint64_t)q.nsp * 8;
+        }
+        std::vector<Msg> all(mk);
+        all.insert(all.end(), mp.begin(), mp.end());
+        all.insert(all.end(), me_.begin(), me_.end());
+        if (!all.empty() || G > 1) {
+            int rc = r->link->exchange(all, ms, r->err);
+            if (rc) return rc;
+        }
+        DCHK(r, hipEventRecord(r->ev_xchg[x * maxK + i], ms));
+        return 0;
+    };
+    auto pass1 = [&](int x, uint32_t i) -> int {
+        const SliceGeom &q = g[x];
+        hj_ctx::Rel &R = c->rel[x];
+        DCHK(r, hipStreamWaitEvent(cs, r->ev_xchg[x * maxK + i], 0));
+        const size_t eb = (size_t)i * G * q.nsp;
+        uint64_t *sb = (uint64_t *)r->seg_beg[x].p + eb, *se = (uint64_t *)r->seg_end[x].p + eb;
+        DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 2], cs));
+        DCHK(r, launch_dist_segments(cs, (const uint64_t *)r->r_end[x].p + eb, G, q.nsp, q.cap0, me, (uint64_t)i * G * q.region, sb, se,
+                                     reinterpret_cast<uint32_t *>(sc + 8 + x), small + 4 + x));
+        FastArgs fb{};
+        fb.keys = (const int32_t *)r->recv_k[x].p; fb.pays = (const int32_t *)r->recv_p[x].p;
+        fb.sbeg = sb; fb.send = se; fb.nparents = q.nsp; fb.spp = G;
+        fb.shift = b2; fb.P = P1; fb.cap = q.cap1; fb.seg_pass1 = 1; fb.span0 = i * q.nsp; fb.nspans = q.NS;
+        fb.out_keys = (int32_t *)R.a_k.p; fb.out_pays = (int32_t *)R.a_p.p;
+        fb.obeg = (uint64_t *)R.s1beg.p; fb.oend = (uint64_t *)R.s1end.p;
+        fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
+        { Timed t(c, "k_part1_fast"); DCHK(r, launch_part2_fast(cs, fb)); }
+        DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 3], cs));
+        return 0;
+    };
+    auto pass2 = [&](int x) -> int {
+        const SliceGeom &q = g[x];
+        hj_ctx::Rel &R = c->rel[x];
+        FastArgs fb{};
+        fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
+        fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = q.NS;
+        fb.shift = 0; fb.P = P2; fb.cap = q.cap2;
+        fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
+        fb.obeg = (uint64_t *)R.beg.p; fb.oend = (uint64_t *)R.end.p;
+        fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
+        { Timed t(c, "k_part2_fast"); DCHK(r, launch_part2_fast(cs, fb)); }
+        R.nparts = P1 * P2;
+        R.part_k = (const int32_t *)R.b_k.p; R.part_p = (const int32_t *)R.b_p.p;
+        R.part_beg = (const uint64_t *)R.beg.p; R.part_end = (const uint64_t *)R.end.p;
+        R.part_off = nullptr;
+        R.n_alloc = q.sizeB;
+        R.pb1 = b1; R.pb2 = b2;
+        R.partitioned = true; R.fast_tried = true; R.flag_known_good = false;
+        R.n = (uint64_t)q.K * G * q.region; // upper bound of what this rank can have received (sizes the work-item list)
+        return 0;
+    };
+    // ---- enqueue: the schedule of the header comment, R then S ----
+    struct Step { int x; uint32_t i; };
+    std::vector<Step> order;
+    for (int x = 0; x < 2; x++) for (uint32_t i = 0; i < g[x].K; i++) order.push_back(Step{x, i});
+    for (size_t j = 0; j < order.size(); j++) {
+        LRET(r, split(order[j].x, order[j].i));
+        LRET(r, exchange(order[j].x, order[j].i));
+        if (j >= 1) LRET(r, pass1(order[j - 1].x, order[j - 1].i));
+        // the relation that finished its pass 1 takes its pass 2 while the other one is on the links
+        if (j >= 1 && order[j - 1].x == 0 && order[j].x == 1 && order[j - 1].i + 1 == g[0].K) LRET(r, pass2(0));
+    }
+    LRET(r, pass1(order.back().x, order.back().i));
+    if (g[1].K == 0) LRET(r, pass2(0));
+    hipEvent_t t_tail0 = r->ev_t[4 * 2 * maxK + 0], t_tail1 = r->ev_t[4 * 2 * maxK + 1];
+    DCHK(r, hipEventRecord(t_tail0, cs));
+    LRET(r, pass2(1));
+    c->join_planned = false;
+    // build + probe on what this rank owns; its flags ride along in the result block
+    uint64_t m = 0, a = 0;
+    {
+        // hj_join_count would re-partition on a raised flag; here a raised flag must reach every rank first
+        int rc = hj_join_count_noretry(c, &m, &a);
+        if (rc) { r->err = hj_error(c); return rc; }
+    }
+    DCHK(r, hipEventRecord(t_tail1, cs));
+    // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
+    r->h_small[0] = m; r->h_small[1] = a; r->h_small[2] = c->h_scalars[8] & 0xFFFFFFFFu; r->h_small[3] = c->h_scalars[9] & 0xFFFFFFFFu;
+    DCHK(r, hipMemcpyAsync(small, r->h_small, 32, hipMemcpyHostToDevice, cs));
+    LRET(r, r->link->allreduce_sum_u64(small, 4, small + 64, cs, r->err));
+    DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 48, hipMemcpyDeviceToHost, cs));
+    DCHK(r, hipStreamSynchronize(cs));
+    DCHK(r, hipStreamSynchronize(ms));
+    out[0] = r->h_small[8]; out[1] = r->h_small[9];
+    *flagged = (r->h_small[10] | r->h_small[11]) != 0;
+    r->st.received[0] = r->h_small[12]; r->st.received[1] = r->h_small[13];
+    // stage times
+    r->st.path = 0; r->st.slices = maxK; r->st.spans_per_slice = g[0].nsp; r->st.slot_capacity[0] = g[0].cap0; r->st.slot_capacity[1] = g[1].cap0;
+    for (int x = 0; x < 2; x++) {
+        r->st.split_ms[x] = 0; r->st.pass1_ms[x] = 0;
+        for (uint32_t i = 0; i < g[x].K; i++) {
+            r->st.split_ms[x] += ev_ms(r->ev_t[4 * (x * maxK + i) + 0], r->ev_t[4 * (x * maxK + i) + 1]);
+            r->st.pass1_ms[x] += ev_ms(r->ev_t[4 * (x * maxK + i) + 2], r->ev_t[4 * (x * maxK + i) + 3]);
+        }
+        r->st.payload_bytes = 0;
+    }
+    r->st.first_split_ms = ev_ms(r->ev_t[0], r->ev_t[1]);
+    r->st.last_pass1_ms = ev_ms(r->ev_t[4 * (1 * maxK + g[1].K - 1) + 2], r->ev_t[4 * (1 * maxK + g[1].K - 1) + 3]);
+    r->st.pass2_join_ms = ev_ms(t_tail0, t_tail1);
+    return 0;
+}
+
+// ---- exact-count exchange: exact split, counts read by the host, messages of exact size, standard local path ----
+int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], uint64_t out[2]) {
+    hj_ctx *c = r->c;
+    const uint32_t G = (uint32_t)r->world, me = (uint32_t)r->rank;
+    hipStream_t cs = c->stream, ms = r->comm;
+    uint64_t *small = (uint64_t *)r->small.p;
+    LRET(r, dist_ensure(r, r->x_counts, (size_t)G * G * 8 + (size_t)G * 8));
+    uint64_t recv_tot[2] = {0, 0};
+    r->st.link_bytes = 0;
+    for (int x = 0; x < 2; x++) {
+        LRET(r, dist_ensure(r, r->x_send_k[x], (size_t)(n[x] + PAD) * 4)); LRET(r, dist_ensure(r, r->x_send_p[x], (size_t)(n[x] + PAD) * 4));
+        std::vector<uint64_t> cnt(G, 0);
+        // level-0 split, one contiguous run per owner; [sync]: the run lengths come back to the host
+        DRET(r, hj_shard_split(c, cols[2 * x], cols[2 * x + 1], n[x], G, (int32_t *)r->x_send_k[x].p, (int32_t *)r->x_send_p[x].p, cnt.data()));
+        // every rank's counts to every rank
+        uint64_t *d_mine = (uint64_t *)r->x_counts.p + (size_t)G * G, *d_all = (uint64_t *)r->x_counts.p;
+        DCHK(r, hipMemcpyAsync(d_mine, cnt.data(), (size_t)G * 8, hipMemcpyHostToDevice, cs));
+        DCHK(r, hipStreamSynchronize(cs)); // cnt is pageable
+        LRET(r, r->link->allgather(d_mine, d_all, (size_t)G * 8, cs, r->err));
+        std::vector<uint64_t> all((size_t)G * G);
+        DCHK(r, hipMemcpyAsync(all.data(), d_all, (size_t)G * G * 8, hipMemcpyDeviceToHost, cs));
+        DCHK(r, hipStreamSynchronize(cs));
+        std::vector<uint64_t> soff(G + 1, 0), roff(G + 1, 0);
+        for (uint32_t q = 0; q < G; q++) { soff[q + 1] = soff[q] + cnt[q]; roff[q + 1] = roff[q] + all[(size_t)q * G + me]; }
+        recv_tot[x] = roff[G];
+        LRET(r, dist_ensure(r, r->x_recv_k[x], (size_t)(roff[G] + PAD) * 4)); LRET(r, dist_ensure(r, r->x_recv_p[x], (size_t)(roff[G] + PAD) * 4));
+        // the split ran on the compute stream; the exchange goes to the communication stream
+        DCHK(r, hipEventRecord(r->ev_misc[x], cs));
+        DCHK(r, hipStreamWaitEvent(ms, r->ev_misc[x], 0));
+        std::vector<Msg> msgs;
+        for (int col = 0; col < 2; col++) {
+            const int32_t *sb = (const int32_t *)(col ? r->x_send_p[x].p : r->x_send_k[x].p);
+            int32_t *rb = (int32_t *)(col ? r->x_recv_p[x].p : r->x_recv_k[x].p);
+            for (uint32_t step = 0; step < G; step++) {
+                const uint32_t p = (me + step) % G;
+                if (p == me && !r->cfg.self_via_link) {
+                    if (cnt[p]) DCHK(r, hipMemcpyAsync(rb + roff[p], sb + soff[p], cnt[p] * 4, hipMemcpyDeviceToDevice, ms));
+                    continue;
+                }
+                msgs.push_back(Msg{(int)p, sb + soff[p], (size_t)cnt[p] * 4, rb + roff[p], (size_t)all[(size_t)p * G + me] * 4});
+                if (p != me) r->st.link_bytes += cnt[p] * 4;
+            }
+        }
+        LRET(r, r->link->exchange(msgs, ms, r->err));
+        DCHK(r, hipEventRecord(r->ev_misc[2 + x], ms));
+    }
+    // local path on what arrived: R's partition passes run while S is still on the links
+    DRET(r, hj_bind_device(c, HJ_REL_R, (const int32_t *)r->x_recv_k[0].p, (const int32_t *)r->x_recv_p[0].p, recv_tot[0]));
+    DRET(r, hj_bind_device(c, HJ_REL_S, (const int32_t *)r->x_recv_k[1].p, (const int32_t *)r->x_recv_p[1].p, recv_tot[1]));
+    DCHK(r, hipStreamWaitEvent(cs, r->ev_misc[2], 0));
+    DRET(r, hj_partition(c, HJ_REL_R));
+    DCHK(r, hipStreamWaitEvent(cs, r->ev_misc[3], 0));
+    DRET(r, hj_partition(c, HJ_REL_S));
+    uint64_t m = 0, a = 0;
+    DRET(r, hj_join_count(c, &m, &a));
+    r->h_small[0] = m; r->h_small[1] = a;
+    DCHK(r, hipMemcpyAsync(small, r->h_small, 16, hipMemcpyHostToDevice, cs));
+    LRET(r, r->link->allreduce_sum_u64(small, 2, small + 64, cs, r->err));
+    DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 16, hipMemcpyDeviceToHost, cs));
+    DCHK(r, hipStreamSynchronize(cs));
+    DCHK(r, hipStreamSynchronize(ms));
+    out[0] = r->h_small[8]; out[1] = r->h_small[9];
+    r->st.received[0] = recv_tot[0]; r->st.received[1] = recv_tot[1];
+    r->st.path = 1; r->st.slices = 1;
+    r->st.payload_bytes = r->st.link_bytes;
+    return 0;
+}
+
+int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
+              uint64_t *matches, uint64_t *agg) {
+    hj_ctx *c = r->c;
+    r->err.clear();
+    if ((nR && (!Rk || !Rp)) || (nS && (!Sk || !Sp))) return r->fail(HJ_EINVAL, "null column");
+    if ((((uintptr_t)Rk | (uintptr_t)Rp | (uintptr_t)Sk | (uintptr_t)Sp) & 15)) return r->fail(HJ_EINVAL, "device columns must be 16-byte aligned");
+    DCHK(r, hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t *cols[4] = {Rk, Rp, Sk, Sp};
+    const uint64_t n[2] = {nR, nS};
+    if (memcmp(cols, r->last_cols, sizeof cols) || n[0] != r->last_n[0] || n[1] != r->last_n[1]) r->prefer_exact = false; // new data
+    memcpy(r->last_cols, cols, sizeof cols); r->last_n[0] = n[0]; r->last_n[1] = n[1];
+    // nominal sizes = the largest local slice of each relation over the ranks, and whether anybody wants the exact path:
+    // one small all-gather, read by the host before anything is planned (sizes decide the geometry on every rank)
+    uint64_t *small = (uint64_t *)r->small.p;
+    r->h_small[0] = nR; r->h_small[1] = nS; r->h_small[2] = (r->prefer_exact || r->cfg.exact_only) ? 1 : 0;
+    DCHK(r, hipMemcpyAsync(small + 16, r->h_small, 24, hipMemcpyHostToDevice, c->stream));
+    LRET(r, r->link->allgather(small + 16, small + 128, 24, c->stream, r->err));
+    DCHK(r, hipMemcpyAsync(r->h_small + 32, small + 128, (size_t)r->world * 24, hipMemcpyDeviceToHost, c->stream));
+    DCHK(r, hipStreamSynchronize(c->stream));
+    uint64_t nmax[2] = {0, 0};
+    bool exact = false;
+    for (int q = 0; q < r->world; q++) {
+        nmax[0] = std::max(nmax[0], r->h_small[32 + 3 * q]); nmax[1] = std::max(nmax[1], r->h_small[32 + 3 * q + 1]);
+        exact |= r->h_small[32 + 3 * q + 2] != 0;
+    }
+    uint64_t out[2] = {0, 0};
+    int rc = 0;
+    bool done = false;
+    if (!exact) {
+        bool flagged = false, applicable = false;
+        rc = join_fast(r, cols, n, nmax, out, &flagged, &applicable);
+        if (rc) return rc;
+        if (applicable && !flagged) done = true;
+        if (flagged) r->prefer_exact = true; // every rank saw the same summed flags: everybody goes exact together
+    }
+    if (!done) {
+        hj_invalidate_all(c);
+        rc = join_exact(r, cols, n, out);
+        if (rc) return rc;
+    }
+    r->st.wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (matches) *matches = out[0];
+    if (agg) *agg = out[1];
+    return HJ_OK;
+}
+
+} // namespace
+
+// ================================================================================================
+// one process, G ranks
+// ================================================================================================
+struct hj_dist {
+    int world = 0;
+    std::vector<hj_dist_rank *> ranks;
+    std::unique_ptr<CopyGroup> copy;
+    std::string err, transport;
+    struct Bound { const int32_t *k = nullptr, *p = nullptr; uint64_t n = 0; } bound[64][2];
+};
+
+extern "C" {
+
+int hj_dist_create(hj_dist **out, int nranks, const int *devices) {
+    if (!out) return HJ_EINVAL;
+    *out = nullptr;
+    if (nranks < 1 || nranks > 64) return HJ_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HJ_EHIP; // no GPU: fail loudly
+    std::vector<int> dev(nranks);
+    bool distinct = true;
+    for (int r = 0; r < nranks; r++) {
+        dev[r] = devices ? devices[r] : r;
+        if (dev[r] < 0 || dev[r] >= ndev) return HJ_EINVAL; // fewer GPUs visible than ranks asked for
+        for (int q = 0; q < r; q++) distinct &= dev[q] != dev[r];
+    }
+    hj_dist *d = new hj_dist();
+    d->world = nranks;
+    std::vector<ncclComm_t> comms(nranks, nullptr);
+    if (distinct) {
+        if (ncclCommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { delete d; return HJ_EHIP; }
+        d->transport = "rccl";
+    } else {
+        d->copy.reset(new CopyGroup(nranks));
+        d->transport = "device-copy";
+    }
+    int rc = 0;
+    for (int r = 0; r < nranks && !rc; r++) {
+        hj_dist_rank *k = new hj_dist_rank();
+        d->ranks.push_back(k);
+        k->rank = r; k->world = nranks; k->own_ctx = true;
+        rc = hj_create(&k->c, dev[r]);
+        if (rc) break;
+        if (distinct) { RcclLink *l = new RcclLink(); l->comm = comms[r]; l->rank = r; l->world = nranks; k->link.reset(l); }
+        else {
+            CopyLink *l = new CopyLink(); l->g = d->copy.get(); l->rank = r; k->link.reset(l);
+            if (hipSetDevice(dev[r]) != hipSuccess || hipEventCreateWithFlags(&d->copy->ready[r], hipEventDisableTiming) != hipSuccess) rc = HJ_EHIP;
+        }
+        if (!rc) rc = rank_init(k);
+    }
+    if (rc) { hj_dist_destroy(d); return rc; }
+    *out = d;
+    return HJ_OK;
+}
+
+int hj_dist_destroy(hj_dist *d) {
+    if (!d) return HJ_EINVAL;
+    for (auto *k : d->ranks) rank_free(k);
+    if (d->copy) for (auto e : d->copy->ready) if (e) (void)hipEventDestroy(e);
+    delete d;
+    return HJ_OK;
+}
+
+const char *hj_dist_error(const hj_dist *d) { return d ? d->err.c_str() : "null hj_dist"; }
+int hj_dist_world(const hj_dist *d) { return d ? d->world : 0; }
+const char *hj_dist_transport(const hj_dist *d) { return d ? d->transport.c_str() : ""; }
+hj_ctx *hj_dist_context(hj_dist *d, int rank) { return (d && rank >= 0 && rank < d->world) ? d->ranks[rank]->c : nullptr; }
+
+int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg) {
+    if (!d || !cfg) return HJ_EINVAL;
+    if (cfg->slices > 64) { d->err = "at most 64 slices"; return HJ_EINVAL; }
+    for (auto *k : d->ranks) k->cfg = *cfg;
+    return HJ_OK;
+}
+
+int hj_dist_bind(hj_dist *d, int rank, int rel, const int32_t *d_keys, const int32_t *d_pays, uint64_t n) {
+    if (!d || rank < 0 || rank >= d->world || (rel != HJ_REL_R && rel != HJ_REL_S)) return HJ_EINVAL;
+    d->bound[rank][rel].k = d_keys; d->bound[rank][rel].p = d_pays; d->bound[rank][rel].n = n;
+    return HJ_OK;
+}
+
+int hj_dist_join(hj_dist *d, uint64_t *matches, uint64_t *agg) {
+    if (!d) return HJ_EINVAL;
+    std::vector<int> rc(d->world, 0);
+    std::vector<uint64_t> m(d->world, 0), a(d->world, 0);
+    std::vector<std::thread> th;
+    // one host thread per GPU: each enqueues its rank's pipeline; the collectives meet on the links
+    for (int r = 0; r < d->world; r++)
+        th.emplace_back([&, r] {
+            const auto &b = d->bound[r];
+            rc[r] = rank_join(d->ranks[r], b[0].k, b[0].p, b[0].n, b[1].k, b[1].p, b[1].n, &m[r], &a[r]);
+        });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < d->world; r++)
+        if (rc[r]) { d->err = "rank " + std::to_string(r) + ": " + d->ranks[r]->err; return rc[r]; }
+    for (int r = 1; r < d->world; r++)
+        if (m[r] != m[0] || a[r] != a[0]) { d->err = "ranks disagree on the all-reduced result"; return HJ_EHIP; }
+    if (matches) *matches = m[0];
+    if (agg) *agg = a[0];
+    return HJ_OK;
+}
+
+int hj_dist_get_stats(hj_dist *d, int rank, hj_dist_stats *out) {
+    if (!d || !out || rank < 0 || rank >= d->world) return HJ_EINVAL;
+    *out = d->ranks[rank]->st;
+    return HJ_OK;
+}
+
+// ---- one process per GPU ----
+int hj_dist_unique_id(void *id128) {
+    if (!id128) return HJ_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == HJ_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return HJ_EHIP;
+    memcpy(id128, &id, sizeof id);
+    return HJ_OK;
+}
+
+int hj_dist_rank_create(hj_dist_rank **out, hj_ctx *ctx, int rank, int world, const void *id128) {
+    if (!out) return HJ_EINVAL;
+    *out = nullptr;
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return HJ_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HJ_EHIP;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    RcclLink *l = new RcclLink();
+    l->rank = rank; l->world = world;
+    if (ncclCommInitRank(&l->comm, world, id, rank) != ncclSuccess) { delete l; return HJ_EHIP; }
+    hj_dist_rank *k = new hj_dist_rank();
+    k->c = ctx; k->rank = rank; k->world = world; k->link.reset(l);
+    int rc = rank_init(k);
+    if (rc) { rank_free(k); return rc; }
+    *out = k;
+    return HJ_OK;
+}
+
+int hj_dist_rank_destroy(hj_dist_rank *r) {
+    if (!r) return HJ_EINVAL;
+    rank_free(r);
+    return HJ_OK;
+}
+
+const char *hj_dist_rank_error(const hj_dist_rank *r) { return r ? r->err.c_str() : "null hj_dist_rank"; }
+
+int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg) {
+    if (!r || !cfg) return HJ_EINVAL;
+    if (cfg->slices > 64) return r->fail(HJ_EINVAL, "at most 64 slices");
+    r->cfg = *cfg;
+    return HJ_OK;
+}
+
+int hj_dist_rank_join(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk, const int32_t *d_Sp,
+                      uint64_t nS, uint64_t *matches, uint64_t *agg) {
+    if (!r) return HJ_EINVAL;
+    return rank_join(r, d_Rk, d_Rp, nR, d_Sk, d_Sp, nS, matches, agg);
+}
+
+int hj_dist_rank_get_stats(hj_dist_rank *r, hj_dist_stats *out) {
+    if (!r || !out) return HJ_EINVAL;
+    *out = r->st;
+    return HJ_OK;
+}
+
+} // extern "C"

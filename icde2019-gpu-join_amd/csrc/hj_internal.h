@@ -59,6 +59,8 @@ struct FastArgs {
     int32_t *out_keys, *out_pays;
     uint64_t *obeg, *oend;       // slot ranges written by the pass: pass 1 [P * nspans] (digit major), pass 2 [nparents * P]
     uint32_t *ovf;               // overflow flag (also read: a set flag makes the kernel return at once)
+    uint32_t mode;               // pass 1: 0 = radix digit, 1 = multi-GPU shard of the key (hash; P = number of GPUs)
+    uint32_t seg_pass1, span0;   // launch_part2_fast as a pass 1 over received segments: workgroup b is span span0 + b of nspans
 };
 
 // one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
@@ -102,6 +104,9 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
+hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
+                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received);
+hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag);
 hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);

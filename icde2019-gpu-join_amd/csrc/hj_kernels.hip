@@ -721,23 +721,64 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
 #undef HJ_WC
 }
 
-// pass 1: one workgroup per span of the contiguous input
-template <int U>
+// pass 1: one workgroup per span of the contiguous input.  MODE 1: the digit is the multi-GPU shard of the key (hash, any
+// fan-out 1..512) — the histogram-free level-0 split of the sliced exchange (hj_dist.hip): shard g's slots (g, *) form one
+// contiguous region of fixed size, which is what travels to GPU g.  FEW: at most 4 digits — ranks are taken with the
+// wave-aggregated atomic (nearly every lane would otherwise queue on one of a few LDS words).
+template <int U, int MODE, bool FEW>
 __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
     wf_carve(L_, smem);
     if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // an earlier workgroup gave up already
     const uint32_t tid = threadIdx.x, s = blockIdx.x;
-    const uint64_t lo = (uint64_t)s * a.span;
+    const uint64_t lo = (uint64_t)s * a.span < a.n ? (uint64_t)s * a.span : a.n; // a span past the end (short slice of a multi-GPU split): empty
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
     FastGeom g{s, a.nspans, a.cap};
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     if (tid < a.P) L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap;
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (MODE == 0 && a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, false, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 0, false, FEW, false, MODE>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// multi-GPU: segment table of one received slice.  Peer q's split wrote its slots (me, s) into a region of nsp slots of cap
+// tuples, which arrived at keys[base + q*nsp*cap ...]; oend[q*nsp + s] = end position of that slot in the SENDER's buffer,
+// whose slot (me, s) started at (me*nsp + s)*cap.  Workgroup s of the local pass 1 reads the G segments (*, s):
+// sbeg/send[s*G + q].  A fill beyond cap (a corrupted message) raises the flag.
+__global__ void k_dist_segments(const uint64_t *__restrict__ oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
+                                uint64_t *__restrict__ sbeg, uint64_t *__restrict__ send, uint32_t *__restrict__ flag,
+                                unsigned long long *__restrict__ received) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * nsp) return;
+    const uint32_t q = t / nsp, sidx = t % nsp;
+    const uint64_t sender_beg = ((uint64_t)me * nsp + sidx) * cap;
+    const uint64_t e = oend[t];
+    uint64_t fill = e >= sender_beg ? e - sender_beg : 0;
+    if (e < sender_beg || fill > cap) { *flag = 1u; fill = 0; }
+    const uint64_t b = base + ((uint64_t)q * nsp + sidx) * cap;
+    sbeg[(uint64_t)sidx * G + q] = b;
+    send[(uint64_t)sidx * G + q] = b + fill;
+    if (fill) atomicAdd(received, (unsigned long long)fill);
+}
+
+hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
+                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received) {
+    hipLaunchKernelGGL(k_dist_segments, dim3((G * nsp + 255) / 256), dim3(256), 0, st, oend, G, nsp, cap, me, base, sbeg, send, flag,
+                       reinterpret_cast<unsigned long long *>(received));
+    return hipGetLastError();
+}
+
+// flag |= any of the n gathered flags (the overflow flags of every rank's level-0 split, after an all-gather)
+__global__ void k_or_flags(const uint32_t *__restrict__ gathered, uint32_t n, uint32_t *__restrict__ flag) {
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v |= gathered[i];
+    if (v) *flag = 1u;
+}
+hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag) {
+    hipLaunchKernelGGL(k_or_flags, dim3(1), dim3(64), 0, st, gathered, n, flag);
+    return hipGetLastError();
 }
 
 // pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
@@ -748,7 +789,9 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     WfLds L_;
     wf_carve(L_, smem);
     const uint32_t tid = threadIdx.x, parent = blockIdx.x;
-    FastGeom g{parent * a.P, 1u, a.cap};
+    // pass 2: child c of parent d -> slot d*P + c.  seg_pass1 (multi-GPU, hj_dist.hip): the workgroup is span span0 + parent of
+    // a pass 1 whose input arrives as segments (the slots received from every peer): digit d -> slot (d, span0 + parent)
+    const FastGeom g = a.seg_pass1 ? FastGeom{a.span0 + parent, a.nspans, a.cap} : FastGeom{parent * a.P, 1u, a.cap};
     uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
     // segment table of this parent: 4-tuple units per segment, scanned
     uint32_t units = 0;
@@ -1767,11 +1810,22 @@ static hipError_t fast_attr(F fn, bool *flags) {
 }
 
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
-    static bool set[64] = {};
-    auto fn = k_part1_fast<2>;
-    hipError_t e = fast_attr(fn, set);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    static bool set[3][64] = {};
+    hipError_t e;
+    // mode 1 = the multi-GPU level-0 split (shard digit); few digits take the wave-aggregated rank
+    if (fa.mode == 0) {
+        auto fn = k_part1_fast<2, 0, false>;
+        if ((e = fast_attr(fn, set[0])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    } else if (fa.P <= 4) {
+        auto fn = k_part1_fast<2, 1, true>;
+        if ((e = fast_attr(fn, set[1])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    } else {
+        auto fn = k_part1_fast<2, 1, false>;
+        if ((e = fast_attr(fn, set[2])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    }
     return hipGetLastError();
 }
 

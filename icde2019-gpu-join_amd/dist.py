@@ -210,3 +210,143 @@ class ShardedJoin:
         m, agg = e.join_count()                                   # unchanged single-GPU build+probe
         gm, ga = self._allreduce_u64([m, agg])
         return gm, ga
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same exchange behind the C ABI (include/hj_dist.h, csrc/hj_dist.hip): C++ host code calling RCCL directly, sliced
+# so that split(i+1) || exchange(i) || local pass-1(i-1) overlap, fixed-size messages (no count comes back to the host).
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+from . import _lib as _hjlib
+from .join import HJError as _HJError, HashJoin as _HashJoin, _dev_ptr
+
+
+def _stats_dict(s):
+    return {"received": [int(s.received[0]), int(s.received[1])], "link_bytes": int(s.link_bytes), "payload_bytes": int(s.payload_bytes),
+            "path": "sliced" if s.path == 0 else "exact", "slices": int(s.slices), "spans_per_slice": int(s.spans_per_slice),
+            "slot_capacity": [int(s.slot_capacity[0]), int(s.slot_capacity[1])],
+            "split_ms": [float(s.split_ms[0]), float(s.split_ms[1])], "pass1_ms": [float(s.pass1_ms[0]), float(s.pass1_ms[1])],
+            "pass2_join_ms": float(s.pass2_join_ms), "first_split_ms": float(s.first_split_ms), "last_pass1_ms": float(s.last_pass1_ms),
+            "wall_ms": float(s.wall_ms)}
+
+
+class GroupJoin:
+    """hj_dist: ONE process drives every rank (one context + one host thread per rank).  devices[r] = HIP device of rank r;
+    distinct devices talk over RCCL, ranks sharing a device over the in-process device-copy transport (tests)."""
+
+    def __init__(self, devices):
+        self._L = _hjlib.lib()
+        arr = (_C.c_int * len(devices))(*devices)
+        h = _C.c_void_p()
+        rc = self._L.hj_dist_create(_C.byref(h), len(devices), arr)
+        if rc:
+            raise _HJError(rc, "hj_dist_create(%r) failed (fewer GPUs visible than ranks, or no GPU)" % (list(devices),))
+        self._h = h
+        self.world = len(devices)
+        self._keep = {}
+
+    def _ck(self, rc):
+        if rc:
+            raise _HJError(rc, (self._L.hj_dist_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hj_dist_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def transport(self):
+        return self._L.hj_dist_transport(self._h).decode()
+
+    def context(self, rank):
+        """The rank's HashJoin context (borrowed: owned by the group) — configure radix bits, generate inputs with it."""
+        hj = _HashJoin.__new__(_HashJoin)
+        hj._L = self._L
+        hj._h = _C.c_void_p(self._L.hj_dist_context(self._h, rank))
+        hj._keep = {}
+        hj.close = lambda: None   # never destroyed from here
+        return hj
+
+    def configure(self, slices=0, exact_only=False, self_via_link=False):
+        cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link))
+        self._ck(self._L.hj_dist_configure(self._h, _C.byref(cfg)))
+
+    def bind(self, rank, rel, keys, pays, n=None):
+        n = int(keys.numel()) if n is None else n
+        self._keep[(rank, rel)] = (keys, pays)
+        self._ck(self._L.hj_dist_bind(self._h, rank, rel, _dev_ptr(keys), _dev_ptr(pays), n))
+
+    def join(self):
+        m, a = _C.c_uint64(), _C.c_uint64()
+        self._ck(self._L.hj_dist_join(self._h, _C.byref(m), _C.byref(a)))
+        return m.value, a.value
+
+    def stats(self, rank):
+        s = _hjlib.DistStats()
+        self._ck(self._L.hj_dist_get_stats(self._h, rank, _C.byref(s)))
+        return _stats_dict(s)
+
+
+class RankJoin:
+    """hj_dist_rank: one process per GPU.  `engine` is this rank's HashJoin; the 128-byte RCCL id made by rank 0 is handed
+    to the others through torch.distributed (any backend: it is a broadcast of 128 bytes over the control plane)."""
+
+    def __init__(self, engine, rank, world, group=None):
+        self._L = _hjlib.lib()
+        self.e = engine
+        idbuf = (_C.c_ubyte * 128)()
+        if rank == 0:
+            rc = self._L.hj_dist_unique_id(_C.cast(idbuf, _C.c_void_p))
+            if rc:
+                raise _HJError(rc, "hj_dist_unique_id failed")
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        idbuf = (_C.c_ubyte * 128).from_buffer_copy(raw)
+        h = _C.c_void_p()
+        rc = self._L.hj_dist_rank_create(_C.byref(h), engine._h, rank, world, _C.cast(idbuf, _C.c_void_p))
+        if rc:
+            raise _HJError(rc, "hj_dist_rank_create(rank %d of %d) failed" % (rank, world))
+        self._h = h
+        self.last_received = (0, 0)
+
+    def _ck(self, rc):
+        if rc:
+            raise _HJError(rc, (self._L.hj_dist_rank_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hj_dist_rank_destroy(self._h)
+            self._h = None
+
+    def configure(self, slices=0, exact_only=False, self_via_link=False):
+        cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link))
+        self._ck(self._L.hj_dist_rank_configure(self._h, _C.byref(cfg)))
+
+    def join(self, Rk, Rp, Sk, Sp, verify=False):
+        m, a = _C.c_uint64(), _C.c_uint64()
+        self._ck(self._L.hj_dist_rank_join(self._h, _dev_ptr(Rk), _dev_ptr(Rp), int(Rk.numel()), _dev_ptr(Sk), _dev_ptr(Sp),
+                                           int(Sk.numel()), _C.byref(m), _C.byref(a)))
+        st = self.stats()
+        self.last_received = tuple(st["received"])
+        return m.value, a.value
+
+    def stats(self):
+        s = _hjlib.DistStats()
+        self._ck(self._L.hj_dist_rank_get_stats(self._h, _C.byref(s)))
+        return _stats_dict(s)

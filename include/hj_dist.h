@@ -1,0 +1,93 @@
+/*
+ * hj_dist.h — C ABI of the multi-GPU join (libhj.so): level-0 shard split -> all-to-all over xGMI (RCCL) -> local
+ * radix passes + build/probe on every GPU -> all-reduce of the count.
+ *
+ * The reference is single-GPU.  Its structural analogue is the co-processing path, which splits both relations 16 ways
+ * on the host and joins every level-0 partition independently (src/hash_join_clustered_probe.cu:1256-1266, 1503-1618);
+ * here the level-0 split runs on every GPU (owner = hash of the key), the shards cross the links, and each GPU joins what
+ * it owns.  BASELINE.json north_star: "C++ host code ... through a thin C-ABI ... RCCL all-to-all over xGMI".
+ *
+ * Two ways to drive it:
+ *   hj_dist       one process, G ranks: one hj context + one host thread per rank, RCCL communicators from
+ *                 ncclCommInitAll (what `bench --gpus N` uses);
+ *   hj_dist_rank  one process per GPU (torchrun / mpirun): rank 0 makes a 128-byte id (hj_dist_unique_id), hands it to
+ *                 the others by whatever means the launcher offers, every rank calls hj_dist_rank_create
+ *                 (ncclCommInitRank) (what bench.py --gpus N uses).
+ *
+ * The pipeline (hj_dist.hip): every relation is cut into K slices.  Slice i is split by shard with the histogram-free
+ * pass (fixed-capacity slots: shard g's slots form one contiguous, fixed-size region), the G regions leave as ONE group
+ * of ncclSend/ncclRecv per slice — message sizes depend only on (n, G, K), so no count ever has to come back to the
+ * host — and the receiver runs its local pass 1 over the slots it got, as segments.  split(i+1) || exchange(i) ||
+ * pass-1(i-1) overlap on two streams.  Skew that overflows a slot raises a flag that is all-gathered; every rank then
+ * takes the exact path (exact split, counts read by the host, exact messages).
+ */
+#ifndef HJ_DIST_H_
+#define HJ_DIST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hj.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hj_dist hj_dist;
+typedef struct hj_dist_rank hj_dist_rank;
+
+typedef struct hj_dist_config {
+    uint32_t slices;        /* K slices per relation; 0 = 4 (fewer when a slice would be smaller than 2^16 tuples) */
+    uint32_t exact_only;    /* 1: always the exact-count exchange (what skewed inputs fall back to) */
+    uint32_t self_via_link; /* 1 (tests): a rank's own share also travels through ncclSend/ncclRecv instead of a device copy */
+    uint32_t reserved[5];
+} hj_dist_config;
+
+typedef struct hj_dist_stats {
+    uint64_t received[2];      /* tuples of R and of S this rank owned after the exchange */
+    uint64_t link_bytes;       /* bytes this rank sent to OTHER ranks in the last join (padding of the fixed-size regions included) */
+    uint64_t payload_bytes;    /* ... of which tuples (8 bytes each) */
+    uint32_t path;             /* 0 = sliced fixed-size exchange, 1 = exact-count exchange */
+    uint32_t slices, spans_per_slice, slot_capacity[2];
+    /* device time of the local stages of the last join (HIP events), ms: what the links have to hide */
+    float split_ms[2];         /* level-0 split of R, S: sum over the slices */
+    float pass1_ms[2];         /* local pass 1 over the received slots: sum over the slices */
+    float pass2_join_ms;       /* pass 2 of both relations + build/probe */
+    float first_split_ms;      /* split of the first slice (nothing to overlap it with) */
+    float last_pass1_ms;       /* pass 1 of the last slice (the links are idle by then) */
+    float wall_ms;             /* the whole hj_dist(_rank)_join call on this rank */
+    uint32_t reserved[8];
+} hj_dist_stats;
+
+/* ---- one process, G ranks ---- */
+/* devices[r] = HIP device of rank r (NULL: rank r on device r).  Distinct devices: RCCL.  Ranks that share a device (RCCL
+ * refuses duplicate GPUs; test mode on a one-GPU box): the same pipeline over an in-process device-copy transport.
+ * HJ_EINVAL if nranks < 1 or a device is not visible (`bench --gpus N` on a box with fewer than N GPUs fails here). */
+int hj_dist_create(hj_dist **out, int nranks, const int *devices);
+int hj_dist_destroy(hj_dist *d);
+const char *hj_dist_error(const hj_dist *d);
+int hj_dist_world(const hj_dist *d);
+const char *hj_dist_transport(const hj_dist *d);                /* "rccl" or "device-copy" */
+hj_ctx *hj_dist_context(hj_dist *d, int rank);                  /* the rank's context: load / generate its slices with it */
+int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg);
+int hj_dist_bind(hj_dist *d, int rank, int rel, const int32_t *d_keys, const int32_t *d_pays, uint64_t n);
+/* The sharded join of what the ranks have bound: global match count and sum payR*payS mod 2^64.  [sync] */
+int hj_dist_join(hj_dist *d, uint64_t *matches, uint64_t *agg);
+int hj_dist_get_stats(hj_dist *d, int rank, hj_dist_stats *out);
+
+/* ---- one process per GPU ---- */
+#define HJ_DIST_ID_BYTES 128
+int hj_dist_unique_id(void *id128);                              /* ncclGetUniqueId; rank 0 only */
+int hj_dist_rank_create(hj_dist_rank **out, hj_ctx *ctx, int rank, int world, const void *id128); /* ncclCommInitRank: collective */
+int hj_dist_rank_destroy(hj_dist_rank *r);
+const char *hj_dist_rank_error(const hj_dist_rank *r);
+int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg);
+/* Collective: every rank calls it with its local slices (device columns on the context's GPU).  [sync] */
+int hj_dist_rank_join(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk,
+                      const int32_t *d_Sp, uint64_t nS, uint64_t *matches, uint64_t *agg);
+int hj_dist_rank_get_stats(hj_dist_rank *r, hj_dist_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJ_DIST_H_ */

@@ -11,7 +11,7 @@ from hjtest import ROOT, has_gpu, pkg
 
 def _declared_functions():
     names = set()
-    for h in ("hj.h", "hj_reference_abi.h"):
+    for h in ("hj.h", "hj_reference_abi.h", "hj_dist.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
