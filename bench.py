@@ -303,6 +303,13 @@ def main():
     ap.add_argument("--balance", choices=["hash", "size"], default="hash",
                     help="multi-GPU level-0 assignment: hash shard g -> GPU g, or 8 virtual shards per GPU assigned by size")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even at world size 1 (sanity runs)")
+    ap.add_argument("--dist-impl", choices=["c", "torch"], default="c",
+                    help="multi-GPU driver: c = hj_dist (C++ over RCCL behind the C ABI: sliced fixed-size exchange), torch = dist.py over torch.distributed")
+    ap.add_argument("--slices", type=int, default=0, help="hj_dist: slices per relation (0 = default)")
+    ap.add_argument("--single-group", action="store_true", help="hj_dist A/B: one pass 2 + join per relation instead of joining the probe side's last slice separately")
+    ap.add_argument("--phantom", type=int, default=0,
+                    help="with --force-dist on ONE GPU: run the sliced pipeline in the shape of a job of this many GPUs (every region copied "
+                         "locally instead of crossing a link) and model the link time beside the measured local stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM ceilings and the phase split (profiling runs)")
@@ -378,9 +385,18 @@ def main():
     expect = total_n * dup  # every key occurs dup times in R and in S
 
     dj = None
+    c_impl = False
     if use_dist:
         from importlib import import_module
-        dj = import_module(pkg.__name__ + ".dist").ShardedJoin(hj, pkg, dev, balance=a.balance)
+        dmod = import_module(pkg.__name__ + ".dist")
+        c_impl = a.dist_impl == "c" and backend != "gloo" and a.balance == "hash"
+        if c_impl:
+            # the exchange behind the C ABI: C++ host code over RCCL (ncclCommInitRank with an id broadcast over the control plane)
+            dj = dmod.RankJoin(hj, rank, world)
+            dj.configure(slices=a.slices, exact_only=a.exact_only, phantom_world=a.phantom if world == 1 else 0, single_group=a.single_group)
+        else:
+            dj = dmod.ShardedJoin(hj, pkg, dev, balance=a.balance)
+            dj.force_exchange = a.force_dist
 
     def step(verify=False):
         if not use_dist:
@@ -430,7 +446,28 @@ def main():
         allrecv = [torch.empty_like(recv) for _ in range(world)]
         dist.all_gather(allrecv, recv)
         dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "driver": "hj_dist (C++ over RCCL, include/hj_dist.h)" if c_impl else "dist.py (torch.distributed)",
                      "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
+        if c_impl:
+            st = dj.stats()
+            G = a.phantom if (world == 1 and a.phantom > 1) else world
+            dist_info["rank0"] = st
+            if st["path"] == "sliced" and G > 1:
+                # Timeline model: every ordered pair of GPUs has its own xGMI link; a rank's bytes to ONE peer
+                # cross ONE link direction at LINK_GBS.  Local stages measured by HIP events in this run; everything except the
+                # first split, the last pass 1, and pass 2 + join is enqueued to run under the exchange.
+                LINK_GBS = 76.8
+                per_peer = st["link_bytes"] / (G - 1)
+                link_ms = per_peer / (LINK_GBS * 1e9) * 1e3
+                local_ms = sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"]
+                exposed = st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"]
+                dist_info["model"] = {"gpus": G, "phantom": bool(world == 1), "link_GBs_per_direction": LINK_GBS,
+                                      "bytes_per_link_direction": per_peer, "link_ms": round(link_ms, 3),
+                                      "local_ms_total": round(local_ms, 3), "exposed_local_ms": round(exposed, 3),
+                                      "exposed_over_link": round(exposed / link_ms, 4),
+                                      "modelled_step_ms": round(max(link_ms, local_ms - exposed) + exposed, 3),
+                                      "modelled_Gtuples_per_s_per_gpu": round(2.0 * n / ((max(link_ms, local_ms - exposed) + exposed) * 1e-3) / 1e9, 2),
+                                      "note": "split(i+1) || exchange(i) || pass-1(i-1); exposed = first split + last pass 1 + pass 2 and join of the probe side's last group of slices"}
 
     # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)

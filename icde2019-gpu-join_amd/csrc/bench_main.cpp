@@ -4,8 +4,9 @@
 //   ./bench -b 7 -a HJC -R <n> -S <m> [-s theta] [--non-unique] [--full-range] [--file -k R.bin -l S.bin]
 //           [-x mult] [-y mult] [-t -v -m -p -w: accepted, echoed, ignored by HJC like the reference]
 //           [--seed N]   (new: reproducible generation; default = time(NULL) like the reference)
-//           [--gpus N]   (new: N > 1 = host level-0 split into N shards, one context + one host thread per GPU,
-//                         independent joins, counts summed — the structure of hjcp.cu:1503-1618 across GPUs)
+//           [--gpus N]   (new: N > 1 = every GPU starts with 1/N of R and S; level-0 split on the GPUs, all-to-all over xGMI
+//                         (RCCL, hj_dist.h), independent joins per GPU, counts all-reduced — the structure of
+//                         hjcp.cu:1503-1618 across GPUs; refused when fewer than N GPUs are visible)
 //           [--cpu-baseline]  (new: also time a CPU chained-hash join on the same columns, as a reported baseline)
 //           [--json]     (new: one machine-readable line with the counts and timings at the end)
 //
@@ -29,7 +30,10 @@
 #include <thread>
 #include <vector>
 
+#include <string>
+
 #include "hj.h"
+#include "hj_dist.h"
 #include "hj_reference_abi.h"
 
 #ifdef HJ_HOST_ONLY
@@ -188,53 +192,58 @@ CpuJoin cpu_join(const int32_t *R, uint64_t nR, const int32_t *S, uint64_t nS) {
 }
 
 #ifndef HJ_HOST_ONLY
-// --gpus N (N > 1): the reference joins level-0 partitions independently (hjcp.cu:1503-1618); here each of N GPUs gets
-// one level-0 shard of R and S (host split, hj_host_split), its own context and host thread, and the counts add up.
-struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0, split_gbs = 0; int status = 0; };
+// --gpus N (N > 1): the reference joins level-0 partitions independently (hjcp.cu:1503-1618); here every GPU starts with
+// 1/N of R and of S (contiguous slices of the host columns, uploaded untimed like hjcp.cu:874-879), and hj_dist_join does
+// the rest in C++: level-0 split on the GPUs, sliced all-to-all over xGMI (RCCL), local passes + build/probe, all-reduce.
+// Fewer than N visible GPUs: refused (non-zero), nothing is emulated on the host.
+struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = 0; std::string transport, path; hj_dist_stats st{}; };
 MultiResult multi_gpu_join(const args &ja, int gpus) {
     MultiResult out;
-    std::vector<int32_t> rk(ja.R_els + 32), sk(ja.S_els + 32);
-    std::vector<uint64_t> roff(gpus + 1), soff(gpus + 1);
-    double g1 = 0, g2 = 0;
-    int32_t *rka = rk.data() + ((64 - ((uintptr_t)rk.data() & 63)) & 63) / 4, *ska = sk.data() + ((64 - ((uintptr_t)sk.data() & 63)) & 63) / 4;
-    if (hj_host_split(ja.R, nullptr, ja.R_els, (uint32_t)gpus, 0, rka, nullptr, roff.data(), &g1) ||
-        hj_host_split(ja.S, nullptr, ja.S_els, (uint32_t)gpus, 0, ska, nullptr, soff.data(), &g2)) { out.status = -1; return out; }
-    out.split_gbs = (g1 + g2) / 2;
-    std::vector<unsigned long long> m(gpus, 0), a(gpus, 0);
-    std::vector<int> rc(gpus, 0);
-    std::vector<hj_ctx *> ctx(gpus, nullptr);
-    for (int g = 0; g < gpus; g++) { // untimed: contexts and H2D, like the reference (hjcp.cu:874-879)
-        rc[g] = hj_create(&ctx[g], g);
-        if (!rc[g]) rc[g] = hj_load_host(ctx[g], HJ_REL_R, rka + roff[g], nullptr, roff[g + 1] - roff[g], HJ_PAYLOAD_ONES);
-        if (!rc[g]) rc[g] = hj_load_host(ctx[g], HJ_REL_S, ska + soff[g], nullptr, soff[g + 1] - soff[g], HJ_PAYLOAD_ONES);
-        if (rc[g]) fprintf(stderr, "GPU Error: device %d: %s (code %d)\n", g, ctx[g] ? hj_error(ctx[g]) : "hj_create failed", rc[g]);
+    hj_dist *d = nullptr;
+    out.status = hj_dist_create(&d, gpus, nullptr);
+    if (out.status) { fprintf(stderr, "GPU Error: --gpus %d: hj_dist_create failed (code %d): fewer GPUs visible than ranks, or no GPU\n", gpus, out.status); return out; }
+    out.transport = hj_dist_transport(d);
+    std::vector<void *> bufs;
+    for (int g = 0; g < gpus && !out.status; g++) {
+        hj_ctx *c = hj_dist_context(d, g);
+        const uint64_t r0 = ja.R_els * g / gpus, r1 = ja.R_els * (g + 1) / gpus, s0 = ja.S_els * g / gpus, s1 = ja.S_els * (g + 1) / gpus;
+        void *col[4] = {nullptr, nullptr, nullptr, nullptr};
+        const uint64_t n[2] = {r1 - r0, s1 - s0};
+        const int32_t *src[2] = {ja.R + r0, ja.S + s0};
+        for (int x = 0; x < 2 && !out.status; x++) {
+            out.status = hj_device_malloc(c, &col[2 * x], (n[x] + 16) * 4);
+            if (!out.status) out.status = hj_device_malloc(c, &col[2 * x + 1], (n[x] + 16) * 4);
+            if (!out.status) { bufs.push_back(col[2 * x]); bufs.push_back(col[2 * x + 1]); }
+            if (!out.status && n[x]) out.status = hj_memcpy_h2d(c, col[2 * x], src[x], n[x] * 4);
+            if (!out.status) out.status = hj_fill_payload(c, (int32_t *)col[2 * x + 1], n[x], HJ_PAYLOAD_ONES, 0); // hjcp.cu:1994-1999
+            if (!out.status) out.status = hj_sync(c);
+            if (!out.status) out.status = hj_dist_bind(d, g, x, (const int32_t *)col[2 * x], (const int32_t *)col[2 * x + 1], n[x]);
+        }
+        if (out.status) fprintf(stderr, "GPU Error: device %d: %s (code %d)\n", g, hj_error(c), out.status);
     }
-    const double t0 = now_s();
-    std::vector<std::thread> th;
-    for (int g = 0; g < gpus; g++)
-        th.emplace_back([&, g] {
-            if (rc[g]) return;
-            uint64_t mm = 0, aa = 0;
-            rc[g] = hj_join(ctx[g], &mm, &aa);
-            m[g] = mm; a[g] = aa;
-        });
-    for (auto &x : th) x.join();
-    out.seconds = now_s() - t0;
-    for (int g = 0; g < gpus; g++) {
-        if (rc[g]) out.status = rc[g];
-        out.matches += m[g]; out.agg += a[g];
-        if (ctx[g]) hj_destroy(ctx[g]);
+    if (!out.status) {
+        uint64_t m = 0, a = 0;
+        out.status = hj_dist_join(d, &m, &a); // warm-up: buffers, communicators, the learned path
+        const double t0 = now_s();
+        if (!out.status) out.status = hj_dist_join(d, &m, &a);
+        out.seconds = now_s() - t0;
+        out.matches = m; out.agg = a;
+        if (out.status) fprintf(stderr, "GPU Error: %s (code %d)\n", hj_dist_error(d), out.status);
+        else { hj_dist_get_stats(d, 0, &out.st); out.path = out.st.path ? "exact" : "sliced"; }
     }
+    for (int g = 0, i = 0; g < gpus; g++)
+        for (int j = 0; j < 4 && i < (int)bufs.size(); j++, i++) hj_device_free(hj_dist_context(d, g), bufs[i]);
+    hj_dist_destroy(d);
     return out;
 }
-
 #else
-struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0, split_gbs = 0; int status = HJ_EHIP; };
+struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = HJ_EHIP; std::string transport, path; };
 MultiResult multi_gpu_join(const args &, int) { return MultiResult(); }
 #endif
 
 int32_t *alloc_col(uint64_t n, bool *pinned) {
     void *p = nullptr;
+    (void)p;
     size_t bytes = (size_t)(n ? n : 1) * sizeof(int32_t);
     // main.cu:181-183 (MEM_HOST): pinned, mapped host columns; plain malloc when no GPU is present (-b 8)
 #ifndef HJ_HOST_ONLY
@@ -353,13 +362,13 @@ int main(int argc, char **argv) {
     memset(&res, 0, sizeof res);
     MultiResult multi;
     if (in.option == 7 && in.gpus > 1) {
-        printf("%s : %d GPUs, one level-0 shard each\n", in.alg->name, in.gpus);
+        printf("%s : %d GPUs, level-0 split + all-to-all over xGMI (RCCL)\n", in.alg->name, in.gpus);
         fflush(stdout);
         multi = multi_gpu_join(ja, in.gpus);
         status = multi.status ? 10 : 0;
         if (!multi.status) {
             const double bytes = 2.0 * (double)(ja.R_els + ja.S_els) * sizeof(int);
-            printf("Host split Throughput %.1f GB/s\n", multi.split_gbs);
+            printf("Exchange: %s, %s path\n", multi.transport.c_str(), multi.path.c_str());
             printf("Total Throughput (%d GPUs) %f\n", in.gpus, bytes / multi.seconds / 1000 / 1000);
             printf("%llu results\n", multi.agg);
         }

@@ -504,6 +504,13 @@ int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     return 0;
 }
 
+// ... and without any host read: the count kernels are enqueued, matches / aggregate end up in scalars[1], [2]
+int hj_join_count_enqueue(hj_ctx *c) {
+    JoinArgs a;
+    bool tag16;
+    return run_count(c, a, tag16);
+}
+
 void hj_invalidate_all(hj_ctx *c) {
     invalidate(c);
     for (int r = 0; r < 2; r++) { c->rel[r].fast_tried = false; c->rel[r].flag_known_good = false; c->rel[r].bound = false; }

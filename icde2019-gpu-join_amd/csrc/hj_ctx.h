@@ -110,6 +110,7 @@ int kid_of(hj_ctx *c, const char *name);
 hipEvent_t get_event(hj_ctx *c);
 void resolve_completed(hj_ctx *c);
 int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg);
+int hj_join_count_enqueue(hj_ctx *c);
 void hj_invalidate_all(hj_ctx *c);
 
 // RAII: HIP events on a stream around one kernel launch (per-kernel statistics, hj_timings)

@@ -326,7 +326,8 @@ float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTi
 int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], const uint64_t nmax[2], uint64_t out[2], bool *flagged,
               bool *applicable) {
     hj_ctx *c = r->c;
-    const uint32_t G = (uint32_t)r->world, me = (uint32_t)r->rank;
+    const bool phantom = r->world == 1 && r->cfg.phantom_world > 1; // one-GPU measurement mode: the shape of a G-GPU job
+    const uint32_t G = phantom ? r->cfg.phantom_world : (uint32_t)r->world, me = (uint32_t)r->rank;
     *applicable = false;
     // radix bits from the nominal sizes (every rank computes the same)
     for (int x = 0; x < 2; x++) { c->rel[x].n = nmax[x]; c->rel[x].bound = true; }
@@ -343,6 +344,34 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     uint64_t *small = (uint64_t *)r->small.p; // [0..3] result block, [4..5] received, [8..] gathered flags, [64..] all-reduce scratch
     const size_t nev = 0;
     (void)nev;
+    // The relation that builds goes first.  The other one (the probe side) is joined in up to two GROUPS of slices — all but
+    // the last, and the last — each with its own pass 2 and its own build+probe against the finished build side: pass 2 and
+    // the join of the first group run while the last slice is still on the links, and what is left when the last byte has
+    // arrived is pass 1 + pass 2 + join of ONE slice (the build tables are rebuilt once more: hidden under the exchange).
+    const int first = c->build, second = 1 - c->build;
+    struct Grp { uint32_t s0, s1, NS, cap2; uint64_t sizeA, sizeB, offA, offB; size_t s1off, boff; };
+    std::vector<Grp> grp[2];
+    for (int x = 0; x < 2; x++) {
+        const SliceGeom &q = g[x];
+        std::vector<std::pair<uint32_t, uint32_t>> cuts;
+        if (x == second && q.K >= 2 && !r->cfg.single_group) { cuts.push_back({0, q.K - 1}); cuts.push_back({q.K - 1, q.K}); }
+        else cuts.push_back({0, q.K});
+        uint64_t offA = 0, offB = 0;
+        size_t s1off = 0, boff = 0;
+        for (auto &cu : cuts) {
+            Grp gr{};
+            gr.s0 = cu.first; gr.s1 = cu.second; gr.NS = (gr.s1 - gr.s0) * q.nsp;
+            const uint64_t share = (nmax[x] * (gr.s1 - gr.s0) + q.K - 1) / q.K;
+            gr.cap2 = fast_slot_cap((share + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
+            gr.sizeA = (uint64_t)P1 * gr.NS * q.cap1; gr.sizeB = (uint64_t)P1 * P2 * gr.cap2;
+            gr.offA = offA; gr.offB = offB; gr.s1off = s1off; gr.boff = boff;
+            offA += gr.sizeA + PAD; offB += gr.sizeB + PAD; s1off += (size_t)P1 * gr.NS; boff += (size_t)P1 * P2;
+            offA = (offA + 3) & ~(uint64_t)3; offB = (offB + 3) & ~(uint64_t)3;
+            const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
+            if (gr.sizeA >= lim || gr.sizeB >= lim) { *applicable = false; return 0; }
+            grp[x].push_back(gr);
+        }
+    }
     // buffers + events
     uint32_t maxK = std::max(g[0].K, g[1].K);
     while (r->ev_split.size() < 2 * (size_t)maxK) {
@@ -353,7 +382,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         r->ev_split.push_back(a); r->ev_xchg.push_back(b);
         r->ev_t.push_back(t0); r->ev_t.push_back(t1); r->ev_t.push_back(t2); r->ev_t.push_back(t3);
     }
-    while (r->ev_t.size() < 4 * 2 * (size_t)maxK + 4) { hipEvent_t t; DCHK(r, hipEventCreate(&t)); r->ev_t.push_back(t); }
+    while (r->ev_t.size() < 4 * 2 * (size_t)maxK + 8) { hipEvent_t t; DCHK(r, hipEventCreate(&t)); r->ev_t.push_back(t); }
     for (int x = 0; x < 2; x++) {
         const SliceGeom &q = g[x];
         const size_t el = (size_t)q.K * G * q.region + PAD;
@@ -364,17 +393,24 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         LRET(r, dist_ensure(r, r->r_end[x], slots * 8));
         LRET(r, dist_ensure(r, r->seg_beg[x], slots * 8)); LRET(r, dist_ensure(r, r->seg_end[x], slots * 8));
         hj_ctx::Rel &R = c->rel[x];
-        RET(ensure(c, R.a_k, (size_t)(q.sizeA + PAD) * 4)); RET(ensure(c, R.a_p, (size_t)(q.sizeA + PAD) * 4));
-        RET(ensure(c, R.b_k, (size_t)(q.sizeB + PAD) * 4)); RET(ensure(c, R.b_p, (size_t)(q.sizeB + PAD) * 4));
+        const Grp &lastg = grp[x].back();
+        const uint64_t totA = lastg.offA + lastg.sizeA + PAD, totB = lastg.offB + lastg.sizeB + PAD;
+        RET(ensure(c, R.a_k, (size_t)totA * 4)); RET(ensure(c, R.a_p, (size_t)totA * 4));
+        RET(ensure(c, R.b_k, (size_t)totB * 4)); RET(ensure(c, R.b_p, (size_t)totB * 4));
         RET(ensure(c, R.s1beg, (size_t)P1 * q.NS * 8)); RET(ensure(c, R.s1end, (size_t)P1 * q.NS * 8));
-        RET(ensure(c, R.beg, (size_t)P1 * P2 * 8)); RET(ensure(c, R.end, (size_t)P1 * P2 * 8));
+        RET(ensure(c, R.beg, (size_t)P1 * P2 * 8 * grp[x].size())); RET(ensure(c, R.end, (size_t)P1 * P2 * 8 * grp[x].size()));
         RET(ensure(c, R.root, 16));
     }
-    // flags of both relations down, received counters zero
+    // flags of both relations down, received counters and the per-group results zero
     for (int x = 0; x < 2; x++) { Timed t(c, "k_set_root"); DCHK(r, launch_set_root(cs, (uint64_t *)c->rel[x].root.p, nmax[x], reinterpret_cast<uint32_t *>(sc + 8 + x))); }
     DCHK(r, hipMemsetAsync(small + 4, 0, 16, cs));
+    DCHK(r, hipMemsetAsync(small + 20, 0, 32, cs));
     r->st.link_bytes = 0; r->st.payload_bytes = 0;
 
+    auto group_of = [&](int x, uint32_t i) -> const Grp & {
+        for (const Grp &gr : grp[x]) if (i >= gr.s0 && i < gr.s1) return gr;
+        return grp[x].back();
+    };
     auto split = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
         const uint64_t lo = std::min<uint64_t>((uint64_t)i * q.L, n[x]), hi = std::min<uint64_t>(lo + q.L, n[x]);
@@ -403,7 +439,8 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             int32_t *dk = (int32_t *)r->recv_k[x].p + base + (uint64_t)p * q.region, *dp = (int32_t *)r->recv_p[x].p + base + (uint64_t)p * q.region;
             const uint64_t *se = (const uint64_t *)r->s_end[x].p + eb + (size_t)p * q.nsp;
             uint64_t *de = (uint64_t *)r->r_end[x].p + eb + (size_t)p * q.nsp;
-            if (p == me && !r->cfg.self_via_link) { // own share: device copies, no link involved
+            if (p != me) r->st.link_bytes += (uint64_t)q.region * 8 + (uint64_t)q.nsp * 8; // phantom world: what WOULD cross a link
+            if (phantom || (p == me && !r->cfg.self_via_link)) { // own share (phantom world: every share): device copies, no link involved
                 DCHK(r, hipMemcpyAsync(dk, sk, q.region * 4, hipMemcpyDeviceToDevice, ms));
                 DCHK(r, hipMemcpyAsync(dp, sp, q.region * 4, hipMemcpyDeviceToDevice, ms));
                 DCHK(r, hipMemcpyAsync(de, se, (size_t)q.nsp * 8, hipMemcpyDeviceToDevice, ms));
@@ -412,12 +449,11 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             mk.push_back(Msg{(int)p, sk, (size_t)q.region * 4, dk, (size_t)q.region * 4});
             mp.push_back(Msg{(int)p, sp, (size_t)q.region * 4, dp, (size_t)q.region * 4});
             me_.push_back(Msg{(int)p, se, (size_t)q.nsp * 8, de, (size_t)q.nsp * 8});
-            if (p != me) r->st.link_bytes += (uint64_t)q.region * 8 + (uint64_t)q.nsp * 8;
         }
         std::vector<Msg> all(mk);
         all.insert(all.end(), mp.begin(), mp.end());
         all.insert(all.end(), me_.begin(), me_.end());
-        if (!all.empty() || G > 1) {
+        if (!phantom && (!all.empty() || G > 1)) {
             int rc = r->link->exchange(all, ms, r->err);
             if (rc) return rc;
         }
@@ -427,69 +463,86 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     auto pass1 = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
         hj_ctx::Rel &R = c->rel[x];
+        const Grp &gr = group_of(x, i);
         DCHK(r, hipStreamWaitEvent(cs, r->ev_xchg[x * maxK + i], 0));
         const size_t eb = (size_t)i * G * q.nsp;
         uint64_t *sb = (uint64_t *)r->seg_beg[x].p + eb, *se = (uint64_t *)r->seg_end[x].p + eb;
         DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 2], cs));
-        DCHK(r, launch_dist_segments(cs, (const uint64_t *)r->r_end[x].p + eb, G, q.nsp, q.cap0, me, (uint64_t)i * G * q.region, sb, se,
+        DCHK(r, launch_dist_segments(cs, (const uint64_t *)r->r_end[x].p + eb, G, q.nsp, q.cap0, phantom ? 0xFFFFFFFFu : me, (uint64_t)i * G * q.region, sb, se,
                                      reinterpret_cast<uint32_t *>(sc + 8 + x), small + 4 + x));
         FastArgs fb{};
         fb.keys = (const int32_t *)r->recv_k[x].p; fb.pays = (const int32_t *)r->recv_p[x].p;
         fb.sbeg = sb; fb.send = se; fb.nparents = q.nsp; fb.spp = G;
-        fb.shift = b2; fb.P = P1; fb.cap = q.cap1; fb.seg_pass1 = 1; fb.span0 = i * q.nsp; fb.nspans = q.NS;
-        fb.out_keys = (int32_t *)R.a_k.p; fb.out_pays = (int32_t *)R.a_p.p;
-        fb.obeg = (uint64_t *)R.s1beg.p; fb.oend = (uint64_t *)R.s1end.p;
+        fb.shift = b2; fb.P = P1; fb.cap = q.cap1; fb.seg_pass1 = 1; fb.span0 = (i - gr.s0) * q.nsp; fb.nspans = gr.NS;
+        fb.out_keys = (int32_t *)R.a_k.p + gr.offA; fb.out_pays = (int32_t *)R.a_p.p + gr.offA;
+        fb.obeg = (uint64_t *)R.s1beg.p + gr.s1off; fb.oend = (uint64_t *)R.s1end.p + gr.s1off;
         fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
         { Timed t(c, "k_part1_fast"); DCHK(r, launch_part2_fast(cs, fb)); }
         DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 3], cs));
         return 0;
     };
-    auto pass2 = [&](int x) -> int {
+    // pass 2 of one group of slices; the relation's Rel then describes that group's partitions
+    auto pass2 = [&](int x, const Grp &gr) -> int {
         const SliceGeom &q = g[x];
         hj_ctx::Rel &R = c->rel[x];
         FastArgs fb{};
-        fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
-        fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = q.NS;
-        fb.shift = 0; fb.P = P2; fb.cap = q.cap2;
-        fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
-        fb.obeg = (uint64_t *)R.beg.p; fb.oend = (uint64_t *)R.end.p;
+        fb.keys = (const int32_t *)R.a_k.p + gr.offA; fb.pays = (const int32_t *)R.a_p.p + gr.offA;
+        fb.sbeg = (const uint64_t *)R.s1beg.p + gr.s1off; fb.send = (const uint64_t *)R.s1end.p + gr.s1off; fb.nparents = P1; fb.spp = gr.NS;
+        fb.shift = 0; fb.P = P2; fb.cap = gr.cap2;
+        fb.out_keys = (int32_t *)R.b_k.p + gr.offB; fb.out_pays = (int32_t *)R.b_p.p + gr.offB;
+        fb.obeg = (uint64_t *)R.beg.p + gr.boff; fb.oend = (uint64_t *)R.end.p + gr.boff;
         fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
         { Timed t(c, "k_part2_fast"); DCHK(r, launch_part2_fast(cs, fb)); }
         R.nparts = P1 * P2;
-        R.part_k = (const int32_t *)R.b_k.p; R.part_p = (const int32_t *)R.b_p.p;
-        R.part_beg = (const uint64_t *)R.beg.p; R.part_end = (const uint64_t *)R.end.p;
+        R.part_k = (const int32_t *)R.b_k.p + gr.offB; R.part_p = (const int32_t *)R.b_p.p + gr.offB;
+        R.part_beg = (const uint64_t *)R.beg.p + gr.boff; R.part_end = (const uint64_t *)R.end.p + gr.boff;
         R.part_off = nullptr;
-        R.n_alloc = q.sizeB;
+        R.n_alloc = gr.sizeB;
         R.pb1 = b1; R.pb2 = b2;
         R.partitioned = true; R.fast_tried = true; R.flag_known_good = false;
-        R.n = (uint64_t)q.K * G * q.region; // upper bound of what this rank can have received (sizes the work-item list)
+        R.n = (uint64_t)(gr.s1 - gr.s0) * G * q.region; // upper bound of what this rank can hold here (sizes the work-item list)
         return 0;
     };
-    // ---- enqueue: the schedule of the header comment, R then S ----
+    hipEvent_t t_tail0 = r->ev_t[4 * 2 * maxK + 0], t_tail1 = r->ev_t[4 * 2 * maxK + 1];
+    uint32_t joined = 0, early_mask = 0;
+    // build + probe of one probe-side group against the build side; the result is parked on the device (no host read here)
+    auto join_group = [&]() -> int {
+        int rc = hj_join_count_enqueue(c);
+        if (rc) { r->err = hj_error(c); return rc; }
+        DCHK(r, hipMemcpyAsync(small + 20 + 2 * joined, sc + 1, 16, hipMemcpyDeviceToDevice, cs));
+        joined++;
+        return 0;
+    };
+    // after the pass 1 of slice (x, i): a finished group gets its pass 2, a finished probe-side group its join
+    auto after_pass1 = [&](int x, uint32_t i) -> int {
+        const Grp &gr = group_of(x, i);
+        if (i + 1 != gr.s1) return 0;
+        const bool last = x == second && gr.s1 == g[x].K;
+        // the last group's pass 2 + join are the tail (nothing is on the links any more); earlier ones run under the exchange
+        hipEvent_t e0 = last ? t_tail0 : r->ev_t[4 * 2 * maxK + 2 + 2 * (x == second)], e1 = last ? t_tail1 : r->ev_t[4 * 2 * maxK + 3 + 2 * (x == second)];
+        DCHK(r, hipEventRecord(e0, cs));
+        LRET(r, pass2(x, gr));
+        if (x == second) LRET(r, join_group());
+        DCHK(r, hipEventRecord(e1, cs));
+        if (!last) early_mask |= 1u << (x == second);
+        return 0;
+    };
+    // ---- enqueue: the schedule of the header comment, the build side first ----
     struct Step { int x; uint32_t i; };
     std::vector<Step> order;
-    for (int x = 0; x < 2; x++) for (uint32_t i = 0; i < g[x].K; i++) order.push_back(Step{x, i});
+    for (int x : {first, second}) for (uint32_t i = 0; i < g[x].K; i++) order.push_back(Step{x, i});
+    c->join_planned = false;
     for (size_t j = 0; j < order.size(); j++) {
         LRET(r, split(order[j].x, order[j].i));
         LRET(r, exchange(order[j].x, order[j].i));
-        if (j >= 1) LRET(r, pass1(order[j - 1].x, order[j - 1].i));
-        // the relation that finished its pass 1 takes its pass 2 while the other one is on the links
-        if (j >= 1 && order[j - 1].x == 0 && order[j].x == 1 && order[j - 1].i + 1 == g[0].K) LRET(r, pass2(0));
+        if (j >= 1) { LRET(r, pass1(order[j - 1].x, order[j - 1].i)); LRET(r, after_pass1(order[j - 1].x, order[j - 1].i)); }
     }
     LRET(r, pass1(order.back().x, order.back().i));
-    if (g[1].K == 0) LRET(r, pass2(0));
-    hipEvent_t t_tail0 = r->ev_t[4 * 2 * maxK + 0], t_tail1 = r->ev_t[4 * 2 * maxK + 1];
-    DCHK(r, hipEventRecord(t_tail0, cs));
-    LRET(r, pass2(1));
-    c->join_planned = false;
-    // build + probe on what this rank owns; its flags ride along in the result block
-    uint64_t m = 0, a = 0;
-    {
-        // hj_join_count would re-partition on a raised flag; here a raised flag must reach every rank first
-        int rc = hj_join_count_noretry(c, &m, &a);
-        if (rc) { r->err = hj_error(c); return rc; }
-    }
-    DCHK(r, hipEventRecord(t_tail1, cs));
+    LRET(r, after_pass1(order.back().x, order.back().i));
+    // the per-group results and, with the result block, the flags of this rank's kernels; [sync]
+    DCHK(r, hipMemcpyAsync(r->h_small + 16, small + 20, 32, hipMemcpyDeviceToHost, cs));
+    if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
+    uint64_t m = r->h_small[16] + r->h_small[18], a = r->h_small[17] + r->h_small[19];
     // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
     r->h_small[0] = m; r->h_small[1] = a; r->h_small[2] = c->h_scalars[8] & 0xFFFFFFFFu; r->h_small[3] = c->h_scalars[9] & 0xFFFFFFFFu;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 32, hipMemcpyHostToDevice, cs));
@@ -510,9 +563,13 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         }
         r->st.payload_bytes = 0;
     }
-    r->st.first_split_ms = ev_ms(r->ev_t[0], r->ev_t[1]);
-    r->st.last_pass1_ms = ev_ms(r->ev_t[4 * (1 * maxK + g[1].K - 1) + 2], r->ev_t[4 * (1 * maxK + g[1].K - 1) + 3]);
+    r->st.first_split_ms = ev_ms(r->ev_t[4 * (first * maxK) + 0], r->ev_t[4 * (first * maxK) + 1]);
+    r->st.last_pass1_ms = ev_ms(r->ev_t[4 * (second * maxK + g[second].K - 1) + 2], r->ev_t[4 * (second * maxK + g[second].K - 1) + 3]);
     r->st.pass2_join_ms = ev_ms(t_tail0, t_tail1);
+    r->st.early_pass2_join_ms = 0;
+    for (int k = 0; k < 2; k++)
+        if (early_mask & (1u << k)) r->st.early_pass2_join_ms += ev_ms(r->ev_t[4 * 2 * maxK + 2 + 2 * k], r->ev_t[4 * 2 * maxK + 3 + 2 * k]);
+    r->st.probe_groups = (uint32_t)grp[second].size();
     return 0;
 }
 
@@ -704,6 +761,7 @@ hj_ctx *hj_dist_context(hj_dist *d, int rank) { return (d && rank >= 0 && rank <
 int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg) {
     if (!d || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) { d->err = "at most 64 slices"; return HJ_EINVAL; }
+    if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && d->world != 1)) { d->err = "phantom_world needs world size 1 and <= 512 shards"; return HJ_EINVAL; }
     for (auto *k : d->ranks) k->cfg = *cfg;
     return HJ_OK;
 }
@@ -780,6 +838,7 @@ const char *hj_dist_rank_error(const hj_dist_rank *r) { return r ? r->err.c_str(
 int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg) {
     if (!r || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) return r->fail(HJ_EINVAL, "at most 64 slices");
+    if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && r->world != 1)) return r->fail(HJ_EINVAL, "phantom_world needs world size 1 and <= 512 shards");
     r->cfg = *cfg;
     return HJ_OK;
 }

@@ -747,13 +747,14 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
 // tuples, which arrived at keys[base + q*nsp*cap ...]; oend[q*nsp + s] = end position of that slot in the SENDER's buffer,
 // whose slot (me, s) started at (me*nsp + s)*cap.  Workgroup s of the local pass 1 reads the G segments (*, s):
 // sbeg/send[s*G + q].  A fill beyond cap (a corrupted message) raises the flag.
+// me == 0xFFFFFFFF (phantom world, a one-GPU measurement mode): region q holds this rank's OWN shard q, i.e. sender slot (q, s).
 __global__ void k_dist_segments(const uint64_t *__restrict__ oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
                                 uint64_t *__restrict__ sbeg, uint64_t *__restrict__ send, uint32_t *__restrict__ flag,
                                 unsigned long long *__restrict__ received) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * nsp) return;
     const uint32_t q = t / nsp, sidx = t % nsp;
-    const uint64_t sender_beg = ((uint64_t)me * nsp + sidx) * cap;
+    const uint64_t sender_beg = ((uint64_t)(me == 0xFFFFFFFFu ? q : me) * nsp + sidx) * cap;
     const uint64_t e = oend[t];
     uint64_t fill = e >= sender_beg ? e - sender_beg : 0;
     if (e < sender_beg || fill > cap) { *flag = 1u; fill = 0; }

@@ -40,7 +40,14 @@ typedef struct hj_dist_config {
     uint32_t slices;        /* K slices per relation; 0 = 4 (fewer when a slice would be smaller than 2^16 tuples) */
     uint32_t exact_only;    /* 1: always the exact-count exchange (what skewed inputs fall back to) */
     uint32_t self_via_link; /* 1 (tests): a rank's own share also travels through ncclSend/ncclRecv instead of a device copy */
-    uint32_t reserved[5];
+    uint32_t phantom_world; /* measurement on a one-GPU box (world size 1 only): run the sliced pipeline in the SHAPE of a
+                             * phantom_world-GPU job — split fan-out, region sizes, segments per local pass-1 workgroup — with
+                             * every region copied back locally instead of crossing a link (the rank then owns every shard, the
+                             * result is the full join).  The stage times in hj_dist_stats are then those of one rank of such a
+                             * job; bench.py models the link time beside them. */
+    uint32_t single_group;  /* 1 (A/B): one pass 2 + one join per relation after its last slice, instead of joining the probe side's
+                             * slices in two groups (all but the last under the exchange, the last in the tail) */
+    uint32_t reserved[3];
 } hj_dist_config;
 
 typedef struct hj_dist_stats {
@@ -52,11 +59,13 @@ typedef struct hj_dist_stats {
     /* device time of the local stages of the last join (HIP events), ms: what the links have to hide */
     float split_ms[2];         /* level-0 split of R, S: sum over the slices */
     float pass1_ms[2];         /* local pass 1 over the received slots: sum over the slices */
-    float pass2_join_ms;       /* pass 2 of both relations + build/probe */
+    float pass2_join_ms;       /* the tail: pass 2 + build/probe of the probe side's LAST group of slices (nothing left to overlap) */
     float first_split_ms;      /* split of the first slice (nothing to overlap it with) */
     float last_pass1_ms;       /* pass 1 of the last slice (the links are idle by then) */
     float wall_ms;             /* the whole hj_dist(_rank)_join call on this rank */
-    uint32_t reserved[8];
+    float early_pass2_join_ms; /* pass 2 of the build side + pass 2 and build/probe of the probe side's earlier slices (under the exchange) */
+    uint32_t probe_groups;
+    uint32_t reserved[6];
 } hj_dist_stats;
 
 /* ---- one process, G ranks ---- */
