@@ -21,7 +21,7 @@ class Config(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
                 ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
                 ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("materialize_two_pass", C.c_uint32),
-                ("lds_stage", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("lds_stage", C.c_uint32), ("graph", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class KernelTime(C.Structure):
@@ -73,6 +73,7 @@ SIGNATURES = {
     "hj_host_split": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, u64p, C.POINTER(C.c_double)]),
     "hj_host_split_throughput": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "hj_ubench": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
+    "hj_ubench_handoff": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
     "hj_partition_layout": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "hj_join_count": (C.c_int, [vp, u64p, u64p]),
     "hj_join_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),

@@ -416,11 +416,16 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    if (nparts <= 16384) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
+        Timed t(c, "k_join_plan");
+        HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, sc + 10, sc + 0));
+    } else {
     { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1, sc + 10)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
                                                                 (const uint64_t *)c->jchunk_prefix.p, (JoinItem *)c->items.p)); }
+    }
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
     return 0;
@@ -511,6 +516,12 @@ int hj_join_count_enqueue(hj_ctx *c) {
     return run_count(c, a, tag16);
 }
 
+void drop_graph(hj_ctx *c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+    c->graph_warm = false;
+}
+
 void hj_invalidate_all(hj_ctx *c) {
     invalidate(c);
     for (int r = 0; r < 2; r++) { c->rel[r].fast_tried = false; c->rel[r].flag_known_good = false; c->rel[r].bound = false; }
@@ -554,6 +565,7 @@ int hj_destroy(hj_ctx *c) {
     if (!c) return HJ_EINVAL;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     for (auto &s : c->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto &e : c->pool) (void)hipEventDestroy(e);
     for (int r = 0; r < 2; r++) {
@@ -566,6 +578,9 @@ int hj_destroy(hj_ctx *c) {
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
     if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d2h) (void)hipStreamDestroy(c->d2h);
     for (int i = 0; i < 2; i++) {
         release(c->out_k[i]); release(c->out_p1[i]); release(c->out_p2[i]);
@@ -591,6 +606,7 @@ int hj_set_stream(hj_ctx *c, void *s) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_stamps(c);
     c->stream = (s == HJ_OWN_STREAM) ? c->own_stream : (hipStream_t)s;
+    drop_graph(c);
     return HJ_OK;
 }
 
@@ -602,6 +618,7 @@ int hj_configure(hj_ctx *c, const hj_config *cfg) {
     if (cfg->lds_stage && (cfg->lds_stage < 64 || cfg->lds_stage > 16384)) return fail(c, HJ_EINVAL, "lds_stage must be in [64, 16384]");
     c->cfg = *cfg;
     invalidate(c);
+    drop_graph(c);
     return HJ_OK;
 }
 
@@ -616,6 +633,7 @@ int hj_get_config(const hj_ctx *c, hj_config *cfg) {
     cfg->exact_only = c->cfg.exact_only || !c->fast_path;
     cfg->materialize_two_pass = c->cfg.materialize_two_pass;
     cfg->lds_stage = c->cfg.lds_stage;
+    cfg->graph = c->cfg.graph;
     return HJ_OK;
 }
 
@@ -772,12 +790,107 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     return HJ_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// hj_config.graph: the whole step (partition R, partition S, plan, build+probe, result copy: ~14-22 launches) captured once
+// into a hipGraph and replayed with ONE host call per step — below ~2^24 tuples a step is bound by the host's launch rate, not
+// by the kernels.  The graph is tied to everything its launches captured: the bound columns and sizes, the configuration, the
+// stream, kernel events off, and the partition path each relation takes.  The first call on a binding runs eagerly (it
+// allocates and learns whether a relation is skewed), the second captures, later ones replay.
+// Both relations' partition passes.  Small inputs (a step is a chain of ~20 short dependent kernels there): S's passes go to a
+// second stream and run beside R's — the two chains overlap, the join waits for both.  Large inputs stay on one stream (every
+// pass kernel fills the chip on its own).  Works the same under stream capture (fork / join by events).
+int partition_both(hj_ctx *c) {
+    const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << 25) && c->events == 0;
+    if (!fork) {
+        RET(partition_rel(c, HJ_REL_R));
+        return partition_rel(c, HJ_REL_S);
+    }
+    if (!c->aux) HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    hipStream_t main = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev_fork, main));
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    c->stream = c->aux;
+    int rc = partition_rel(c, HJ_REL_S);
+    c->stream = main;
+    if (!rc) rc = partition_rel(c, HJ_REL_R);
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    HIPCHK(c, hipStreamWaitEvent(main, c->ev_join, 0));
+    return rc;
+}
+
+struct GraphKey { const int32_t *k[2], *p[2]; uint64_t n[2]; hipStream_t st; bool pe[2]; };
+bool same_key(const hj_ctx *c) {
+    for (int r = 0; r < 2; r++)
+        if (c->gkey_k[r] != c->rel[r].in_k || c->gkey_p[r] != c->rel[r].in_p || c->gkey_n[r] != c->rel[r].n || c->gkey_pe[r] != c->rel[r].prefer_exact) return false;
+    return c->gkey_st == c->stream;
+}
+void set_key(hj_ctx *c) {
+    for (int r = 0; r < 2; r++) { c->gkey_k[r] = c->rel[r].in_k; c->gkey_p[r] = c->rel[r].in_p; c->gkey_n[r] = c->rel[r].n; c->gkey_pe[r] = c->rel[r].prefer_exact; }
+    c->gkey_st = c->stream;
+}
+
+int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
+    *done = false;
+    if (!c->cfg.graph || c->events != 0 || !c->rel[0].bound || !c->rel[1].bound) return 0;
+    if (!same_key(c)) { drop_graph(c); return 0; } // new binding: an eager call first
+    if (!c->graph_warm) return 0;
+    if (!c->graph_exec) {
+        // capture: every buffer has its size from the eager call (ensure() is a no-op), no host read happens in between
+        hipGraph_t gr = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { // e.g. HIP's legacy default stream
+            (void)hipGetLastError();
+            drop_graph(c);
+            return 0;
+        }
+        int rc = partition_both(c);
+        JoinArgs a;
+        bool tag16 = false;
+        if (!rc) rc = run_count(c, a, tag16);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(c->h_scalars, c->scalars.p, 11 * 8, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &gr);
+        if (rc || e != hipSuccess || e2 != hipSuccess || !gr) { if (gr) (void)hipGraphDestroy(gr); drop_graph(c); return rc; } // not capturable: stay eager
+        e = hipGraphInstantiate(&c->graph_exec, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (e != hipSuccess) { c->graph_exec = nullptr; drop_graph(c); return 0; }
+        c->last_args = a; c->last_tag16 = tag16;
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->redo_mask = 0;
+    for (int r = 0; r < 2; r++) {
+        Rel &R = c->rel[r];
+        if (!R.fast_tried) continue;
+        if ((uint32_t)c->h_scalars[8 + r]) { R.prefer_exact = true; c->redo_mask |= 1u << r; } // the data under the binding changed: skewed now
+        else R.flag_known_good = true;
+    }
+    if (c->redo_mask) { drop_graph(c); return 0; } // the eager path redoes the flagged relation
+    if (matches) *matches = c->h_scalars[1];
+    if (agg) *agg = c->h_scalars[2];
+    c->last_matches = c->h_scalars[1]; c->last_agg = c->h_scalars[2];
+    c->join_planned = true;
+    *done = true;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
 int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    RET(partition_rel(c, HJ_REL_R));
-    RET(partition_rel(c, HJ_REL_S));
-    return hj_join_count(c, matches, agg);
+    bool done = false;
+    RET(join_graph(c, matches, agg, &done));
+    if (done) return HJ_OK;
+    RET(partition_both(c));
+    RET(hj_join_count(c, matches, agg));
+    if (c->cfg.graph) { set_key(c); c->graph_warm = true; } // the next call on this binding may capture
+    return HJ_OK;
 }
 
 int hj_device_malloc(hj_ctx *c, void **d_ptr, uint64_t bytes) {
@@ -1168,6 +1281,7 @@ int hj_enable_timings(hj_ctx *c, int level) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_stamps(c);
     c->events = level;
+    drop_graph(c);
     return HJ_OK;
 }
 
@@ -1294,6 +1408,29 @@ int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p,
     while (pow2 * 2 <= lines) pow2 *= 2;
     if (avg_ms) *avg_ms = (double)ms / reps;
     if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * 16; // 8 B read + 8 B written per tuple
+    return HJ_OK;
+}
+
+int hj_ubench_handoff(hj_ctx *c, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_ring_k, int32_t *d_ring_p, uint64_t n,
+                      uint64_t window_tuples, uint64_t ring_tuples, uint32_t reps, double *avg_ms, uint64_t *bytes_per_rep) {
+    if (!c || !reps) return HJ_EINVAL;
+    if (!d_in_k || !d_in_p || !d_ring_k || !d_ring_p) return fail(c, HJ_EINVAL, "hj_ubench_handoff needs four columns");
+    if (window_tuples < 4096 || (window_tuples & (window_tuples - 1)) || ring_tuples < window_tuples || ring_tuples % window_tuples || n < window_tuples)
+        return fail(c, HJ_EINVAL, "window: a power of two >= 4096 tuples; ring: a multiple of it; n >= window");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t a = get_event(c), b = get_event(c);
+    if (!a || !b) return fail(c, HJ_EHIP, "no HIP events");
+    uint64_t *sink = (uint64_t *)c->scalars.p + 4;
+    HIPCHK(c, launch_ubench_handoff(c->stream, d_in_k, d_in_p, d_ring_k, d_ring_p, n, window_tuples, ring_tuples, sink)); // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    for (uint32_t i = 0; i < reps; i++) HIPCHK(c, launch_ubench_handoff(c->stream, d_in_k, d_in_p, d_ring_k, d_ring_p, n, window_tuples, ring_tuples, sink));
+    HIPCHK(c, hipEventRecord(b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
+    c->pool.push_back(a); c->pool.push_back(b);
+    if (avg_ms) *avg_ms = (double)ms / reps;
+    if (bytes_per_rep) *bytes_per_rep = (n / window_tuples) * window_tuples * 24; // 8 B read (input) + 8 B written + 8 B read back per tuple
     return HJ_OK;
 }
 

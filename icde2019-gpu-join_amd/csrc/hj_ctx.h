@@ -87,6 +87,15 @@ struct hj_ctx {
     hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
     hipEvent_t out_ready[2] = {}, out_free[2] = {};
     hipEvent_t seg_ready[2] = {};
+    hipStream_t aux = nullptr;      // small inputs: S's partition passes run beside R's
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // hj_config.graph: the captured step and what it is tied to
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_warm = false;
+    const int32_t *gkey_k[2] = {nullptr, nullptr}, *gkey_p[2] = {nullptr, nullptr};
+    uint64_t gkey_n[2] = {0, 0};
+    bool gkey_pe[2] = {false, false};
+    hipStream_t gkey_st = nullptr;
     // timing
     int events = 0;                 // 0 none (default), 1 main kernels (partition passes / join), 2 every launch: hj_enable_timings, HJ_KERNEL_EVENTS
     std::vector<KStat> kstats;
@@ -112,6 +121,7 @@ void resolve_completed(hj_ctx *c);
 int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg);
 int hj_join_count_enqueue(hj_ctx *c);
 void hj_invalidate_all(hj_ctx *c);
+void drop_graph(hj_ctx *c);
 
 // RAII: HIP events on a stream around one kernel launch (per-kernel statistics, hj_timings)
 struct Timed {

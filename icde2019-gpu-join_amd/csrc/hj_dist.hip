@@ -24,6 +24,7 @@
 // Exact path: exact split (histogram + scatter), counts to the host, all-gather of the counts, messages of exact size,
 //   local partition + join (what dist.py did from Python in rounds 1-2).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -52,6 +53,51 @@ namespace {
 constexpr uint64_t PAD = 16;
 constexpr size_t MSG_CHUNK = (size_t)512 << 20; // RCCL 2.26 / ROCm 7 corrupted single messages of >= 2 GiB (tools/rccl_2gib_repro.py)
 
+// librccl is bound at run time, not at link time: a process that has PyTorch loaded already carries PyTorch's own copy of
+// librccl, and a second copy pulled in by libhj.so's dependency list gives two sets of RCCL globals in one process (observed:
+// "double free or corruption" at interpreter exit).  The copy that is already loaded is used; otherwise ROCm's is opened.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi &rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *n : {"librccl.so", "librccl.so.1"})
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy this process already has (PyTorch's)
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        bool all = true;
+        auto sym = [&](const char *n) { void *p = dlsym(h, n); all &= p != nullptr; return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.ok = all;
+    });
+    return api;
+}
+
 struct Msg {          // one peer's share of an exchange
     int peer;
     const void *src;  // what I send to peer
@@ -74,30 +120,30 @@ struct RcclLink : Link {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     bool own = true;
-    ~RcclLink() override { if (comm && own) (void)ncclCommDestroy(comm); }
+    ~RcclLink() override { if (comm && own) (void)rccl().CommDestroy(comm); }
     const char *name() const override { return "rccl"; }
     static int chk(ncclResult_t r, const char *what, std::string &err) {
         if (r == ncclSuccess) return 0;
-        err = std::string(what) + ": " + ncclGetErrorString(r);
+        err = std::string(what) + ": " + rccl().GetErrorString(r);
         return HJ_EHIP;
     }
     int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) override {
         // ONE group = one all-to-all-v: every ordered pair has its own xGMI link, nothing is relayed
-        int rc = chk(ncclGroupStart(), "ncclGroupStart", err);
+        int rc = chk(rccl().GroupStart(), "ncclGroupStart", err);
         for (const Msg &m : msgs) {
             for (size_t o = 0; o < m.sbytes && !rc; o += MSG_CHUNK)
-                rc = chk(ncclSend((const char *)m.src + o, std::min(MSG_CHUNK, m.sbytes - o), ncclInt8, m.peer, comm, st), "ncclSend", err);
+                rc = chk(rccl().Send((const char *)m.src + o, std::min(MSG_CHUNK, m.sbytes - o), ncclInt8, m.peer, comm, st), "ncclSend", err);
             for (size_t o = 0; o < m.rbytes && !rc; o += MSG_CHUNK)
-                rc = chk(ncclRecv((char *)m.dst + o, std::min(MSG_CHUNK, m.rbytes - o), ncclInt8, m.peer, comm, st), "ncclRecv", err);
+                rc = chk(rccl().Recv((char *)m.dst + o, std::min(MSG_CHUNK, m.rbytes - o), ncclInt8, m.peer, comm, st), "ncclRecv", err);
         }
-        const int rc2 = chk(ncclGroupEnd(), "ncclGroupEnd", err);
+        const int rc2 = chk(rccl().GroupEnd(), "ncclGroupEnd", err);
         return rc ? rc : rc2;
     }
     int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) override {
-        return chk(ncclAllGather(src, dst, bytes, ncclInt8, comm, st), "ncclAllGather", err);
+        return chk(rccl().AllGather(src, dst, bytes, ncclInt8, comm, st), "ncclAllGather", err);
     }
     int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *, hipStream_t st, std::string &err) override {
-        return chk(ncclAllReduce(inout, inout, n, ncclUint64, ncclSum, comm, st), "ncclAllReduce", err); // wraps mod 2^64
+        return chk(rccl().AllReduce(inout, inout, n, ncclUint64, ncclSum, comm, st), "ncclAllReduce", err); // wraps mod 2^64
     }
 };
 
@@ -720,7 +766,7 @@ int hj_dist_create(hj_dist **out, int nranks, const int *devices) {
     d->world = nranks;
     std::vector<ncclComm_t> comms(nranks, nullptr);
     if (distinct) {
-        if (ncclCommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { delete d; return HJ_EHIP; }
+        if (!rccl().ok || rccl().CommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { delete d; return HJ_EHIP; }
         d->transport = "rccl";
     } else {
         d->copy.reset(new CopyGroup(nranks));
@@ -804,7 +850,7 @@ int hj_dist_unique_id(void *id128) {
     if (!id128) return HJ_EINVAL;
     static_assert(sizeof(ncclUniqueId) == HJ_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return HJ_EHIP;
+    if (!rccl().ok || rccl().GetUniqueId(&id) != ncclSuccess) return HJ_EHIP;
     memcpy(id128, &id, sizeof id);
     return HJ_OK;
 }
@@ -818,7 +864,7 @@ int hj_dist_rank_create(hj_dist_rank **out, hj_ctx *ctx, int rank, int world, co
     memcpy(&id, id128, sizeof id);
     RcclLink *l = new RcclLink();
     l->rank = rank; l->world = world;
-    if (ncclCommInitRank(&l->comm, world, id, rank) != ncclSuccess) { delete l; return HJ_EHIP; }
+    if (!rccl().ok || rccl().CommInitRank(&l->comm, world, id, rank) != ncclSuccess) { delete l; return HJ_EHIP; }
     hj_dist_rank *k = new hj_dist_rank();
     k->c = ctx; k->rank = rank; k->world = world; k->link.reset(l);
     int rc = rank_init(k);

@@ -111,6 +111,8 @@ hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor);
+hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
+                                  uint64_t *n_items);
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items);
@@ -133,6 +135,8 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
                                     const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
+hipError_t launch_ubench_handoff(hipStream_t st, const int32_t *ik, const int32_t *ip, int32_t *rk, int32_t *rp, uint64_t n_total,
+                                 uint64_t window, uint64_t ring, uint64_t *sink);
 hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts);
 
 } // namespace hj

@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "hj_internal.h"
@@ -260,11 +261,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_hist(const int32_t *__restrict
 // The value of entry i is then data[i] + chunk_prefix[i >> 12].  L = (*len_ptr) * mul, or mul. ----
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ data, const uint32_t *__restrict__ len_ptr,
-                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums) {
+                                                             uint64_t mul, uint64_t *__restrict__ chunk_sums,
+                                                             uint64_t *__restrict__ single, uint64_t *__restrict__ total_out) {
     __shared__ T scratch[17];
     const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
     const uint64_t start = (uint64_t)blockIdx.x * SCAN_CHUNK;
-    if (start >= L) return;
+    if (start >= L) {
+        if (single && threadIdx.x == 0) { single[0] = 0; single[1] = 0; if (total_out) *total_out = 0; } // empty scan
+        return;
+    }
     const uint64_t i0 = start + (uint64_t)threadIdx.x * SCAN_PER;
     T v[SCAN_PER];
     T sum = 0;
@@ -280,7 +285,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(T *__restrict__ dat
         if (i0 + j < L) data[i0 + j] = ex;
         ex += v[j];
     }
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = (uint64_t)total;
+    if (threadIdx.x == 0) {
+        chunk_sums[blockIdx.x] = (uint64_t)total;
+        // a scan that fits one chunk needs no second kernel (launch_scan_*: one launch instead of two, small inputs)
+        if (single) { single[0] = 0; single[1] = (uint64_t)total; if (total_out) *total_out = (uint64_t)total; }
+    }
 }
 
 // Single workgroup: exclusive scan of the chunk sums; chunk_prefix[nchunks] and *total_out = total.
@@ -897,6 +906,43 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
     return hipGetLastError();
 }
 
+// ---- hand-off ceiling: does a producer -> consumer hand-off through a window that fits the Infinity Cache (256 MiB) run
+// faster than the same hand-off through HBM?  Producer = k_ubench<1> (streamed input, 128-byte lines scattered inside the
+// window); consumer streams the window back (16 bytes per lane) and folds it into one word per workgroup. ----
+__global__ __launch_bounds__(256) void k_ubench_consume(const int4 *__restrict__ wk, const int4 *__restrict__ wp, uint64_t n16,
+                                                        unsigned long long *__restrict__ sink) {
+    uint32_t acc = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 512; base < n16; base += (uint64_t)gridDim.x * 512) {
+        int4 a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u < n16) { a[j] = wk[u]; b[j] = wp[u]; } else { a[j] = make_int4(0, 0, 0, 0); b[j] = a[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc += (uint32_t)(a[j].x ^ a[j].y ^ a[j].z ^ a[j].w ^ b[j].x ^ b[j].y ^ b[j].z ^ b[j].w);
+    }
+    acc = (uint32_t)wave_sum64(acc);
+    if (lane_id() == 0 && acc == 0x9E3779B9u) atomicAdd(sink, 1ull); // practically never: keeps the loads alive
+}
+
+// one round: producer over [in + r*W, +W) -> window (r mod nwin); consumer over that window
+hipError_t launch_ubench_handoff(hipStream_t st, const int32_t *ik, const int32_t *ip, int32_t *rk, int32_t *rp, uint64_t n_total,
+                                 uint64_t window, uint64_t ring, uint64_t *sink) {
+    const uint64_t w16 = window / 4, lines = w16 / 8; // window: a power of two of tuples
+    const uint64_t mul = 0x9E3779B97F4A7C15ULL | 1;
+    const uint64_t nwin = ring / window;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(16384, (w16 + 511) / 512);
+    for (uint64_t r = 0; r * window + window <= n_total; r++) {
+        const uint64_t wo = (r % nwin) * window;
+        hipLaunchKernelGGL((k_ubench<1, 2>), dim3(blocks), dim3(256), 0, st, (const int4 *)(ik + r * window), (const int4 *)(ip + r * window),
+                           (int4 *)(rk + wo), (int4 *)(rp + wo), w16, lines - 1, mul, 0);
+        hipLaunchKernelGGL(k_ubench_consume, dim3(blocks), dim3(256), 0, st, (const int4 *)(rk + wo), (const int4 *)(rp + wo), w16,
+                           reinterpret_cast<unsigned long long *>(sink));
+    }
+    return hipGetLastError();
+}
+
 // partition ranges from an offsets array (single-pass / unpartitioned layouts): beg[i] = off[i], end[i] = off[i+1]
 __global__ void k_range_from_offsets(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ beg, uint64_t *__restrict__ end) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -956,6 +1002,44 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
         it.q1 = it.q0 + chunk < pend[p] ? it.q0 + chunk : pend[p];
         items[at + j] = it;
     }
+}
+
+// k_join_plan + scan + k_join_expand in ONE single-workgroup launch, for partition counts where three dependent launches
+// cost more than the work (a step at <= 2^24 tuples is launch-latency bound): chunks of 1024 partitions with a running carry.
+__global__ __launch_bounds__(1024) void k_join_plan_fused(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
+                                                          const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
+                                                          uint32_t nparts, uint32_t chunk, JoinItem *__restrict__ items,
+                                                          const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
+                                                          uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor,
+                                                          uint64_t *__restrict__ n_items) {
+    __shared__ uint32_t scratch[17];
+    if (threadIdx.x == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
+    const bool invalid = (bflag && *bflag) || (pflag && *pflag);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nparts; base += 1024) {
+        const uint32_t p = base + threadIdx.x;
+        uint64_t nb = 0, np = 0;
+        if (p < nparts && !invalid) { nb = bend[p] - bbeg[p]; np = pend[p] - pbeg[p]; }
+        const uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &total);
+        for (uint32_t j = 0; j < c; j++) {
+            JoinItem it;
+            it.b0 = bbeg[p]; it.nb = (uint32_t)nb; it.p = p;
+            it.q0 = pbeg[p] + (uint64_t)j * chunk;
+            it.q1 = it.q0 + chunk < pend[p] ? it.q0 + chunk : pend[p];
+            items[carry + ex + j] = it;
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) *n_items = carry;
+}
+
+hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
+                                  uint64_t *n_items) {
+    hipLaunchKernelGGL(k_join_plan_fused, dim3(1), dim3(1024), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items, a.bflag, a.pflag,
+                       zero2, zero_cursor, n_items);
+    return hipGetLastError();
 }
 
 // LDS layout (dynamic): head[nh] u32 | entries[cap] 8 bytes ({tag16 << 16 | next16, payload} or {key, payload}) | with full
@@ -1506,7 +1590,12 @@ hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_p
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    if (nchunks == 1) { // the whole scan in one workgroup: chunk_prefix[0..1] and the total come from the same launch
+        hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(1), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, chunk_prefix, total_out);
+        HJ_LAUNCH_CHECK();
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_scan_local<uint32_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, (uint64_t *)nullptr, (uint64_t *)nullptr);
     HJ_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
     HJ_LAUNCH_CHECK();
@@ -1517,7 +1606,12 @@ hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_p
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
     uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     if (nchunks == 0) nchunks = 1;
-    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums);
+    if (nchunks == 1) { // the whole scan in one workgroup: chunk_prefix[0..1] and the total come from the same launch
+        hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(1), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, chunk_prefix, total_out);
+        HJ_LAUNCH_CHECK();
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, (uint64_t *)nullptr, (uint64_t *)nullptr);
     HJ_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
     HJ_LAUNCH_CHECK();

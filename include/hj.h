@@ -62,7 +62,11 @@ typedef struct hj_config {
                             * order of the output is a function of the partitions alone. */
     uint32_t lds_stage;    /* one-probe materialisation: matches staged in LDS per flush (one output reservation each);
                             * 0 = what fits next to the hash table at two workgroups per CU (~4700) */
-    uint32_t reserved[6];
+    uint32_t graph;        /* 1: hj_join replays the whole step (both partition passes, plan, build+probe, result copy) from a
+                            * captured hipGraph — one host call per step instead of ~14-22 launches; pays below ~2^24 tuples,
+                            * where a step is bound by the host's launch rate.  The first call on a binding runs eagerly, the second
+                            * captures; re-binding, hj_configure, hj_set_stream or enabling kernel timings drop the graph. */
+    uint32_t reserved[5];
 } hj_config;
 
 /* Per-kernel device time of the most recent run of each kernel (HIP events on the context stream).
@@ -233,6 +237,13 @@ int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_
  *      flush).  avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
 int hj_ubench(hj_ctx *ctx, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p,
               uint64_t n, uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch);
+
+/* Hand-off ceiling: per round, a producer streams window_tuples of the input and stores them as scattered 128-byte lines into a
+ * window of a ring of ring_tuples (ring == window: the same window every round, small enough to stay in the 256 MiB Infinity
+ * Cache; ring >> cache: every round a window that has long left it), then a dependent consumer kernel streams that window back.
+ * n / window rounds per repetition; avg_ms per repetition, bytes = 24 per tuple (input read, window write, window read).  [sync] */
+int hj_ubench_handoff(hj_ctx *ctx, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_ring_k, int32_t *d_ring_p, uint64_t n,
+                      uint64_t window_tuples, uint64_t ring_tuples, uint32_t reps, double *avg_ms, uint64_t *bytes_per_rep);
 
 /* ---- generator_ETHZ drop-in (host side; src/generator_ETHZ.cuh:11-23) ----
  * Same generators, same raw-int32 .bin cache format; the time(NULL)/rand() global state of the

@@ -67,6 +67,10 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
             hj.partition(P.REL_R)
             hj.partition(P.REL_S)
             check(*hj.join_materialize(cap=em), "two probes, no count")
+        # the step replayed from a captured hipGraph (hj_config.graph): eager call, capturing call, replays
+        hj.configure(**dict(cfg or {}, graph=True))
+        for _ in range(4):
+            assert hj.join() == (em, eagg), ("graph", hj.config())
         return hj.config()
 
 
@@ -148,6 +152,35 @@ def test_reference_joinCpu_answers(P, join_answers, golden_dir, cfg):
     R, S = _load(golden_dir, "unique_4096.bin"), _load(golden_dir, "unique_fk10000_max4096.bin")
     r = P.hashJoinClusteredProbe(R, S)                     # the reference's entry point, same inputs
     assert r["matches"] == [a for a in join_answers if a["S"] == "unique_fk10000_max4096.bin"][0]["s"]
+
+
+def test_graph_replay_follows_the_data(P):
+    """hj_config.graph: the captured step is tied to the binding, not to the data under it.  New data in the same columns is
+    joined correctly by a replay; data that turns skewed raises the overflow flag inside the replay, the graph is dropped, the
+    relation redone with the exact passes, and the next calls capture again."""
+    rng = np.random.default_rng(12)
+    n = 1 << 18
+    with P.HashJoin(0) as hj:          # its own stream: HIP's legacy default stream cannot be captured
+        hj.configure(bits1=5, bits2=4, graph=True)
+        R = rng.permutation(n).astype(np.int32)
+        S = rng.integers(0, n, 3 * n).astype(np.int32)
+        hj.load_host(P.REL_R, R)
+        hj.load_host(P.REL_S, S)
+        for _ in range(3):
+            assert hj.join() == (3 * n, 3 * n)
+        S2 = rng.integers(0, n // 2, 3 * n).astype(np.int32)        # same size, other values: same device columns
+        hj.load_host(P.REL_S, S2)
+        for _ in range(3):
+            assert hj.join()[0] == 3 * n
+        S3 = S2.copy()
+        S3[: 2 * n] = 7                                               # now one key holds two thirds of S
+        hj.load_host(P.REL_S, S3)
+        for _ in range(4):
+            assert hj.join()[0] == 3 * n
+        assert hj.partition_layout(P.REL_S) == "exact"
+        # timings on: the graph is dropped, the eager path answers
+        hj.enable_timings(1)
+        assert hj.join()[0] == 3 * n and hj.timings()["k_join_count"]["launches"] == 1
 
 
 # ---- edge cases ----------------------------------------------------------------------------------------
