@@ -12,6 +12,7 @@
 
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <string>
 #include <system_error>
@@ -273,6 +274,212 @@ bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &
     return f.sizeA < lim && f.sizeB < lim;
 }
 
+// ---- the sampled path: a relation known to be skewed, on the probe side ----
+// One keys-only pass over every 8th 4096-tuple block gives a joint histogram of the final partition ids (the low b1+b2 key
+// bits); the host turns it into per-digit slot capacities (expected count + sampling error + 8 sigma), per-digit LDS lines
+// (k_scatter_wc's dealing rule, from the sample instead of an exact histogram), and — for pass 2 — a workgroup table that
+// cuts every pass-1 digit into pieces of about one span, so that the digit holding a heavy hitter is spread over many
+// workgroups.  Final partition p is then a LIST of ranges (one per piece of its parent): the join reads the probe side as
+// ranges (JoinArgs.rpart).  Once per binding: later partition calls reuse the tables, with no histogram and no host read.
+constexpr uint32_t SAMPLE_STRIDE = 8;
+
+int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
+    Rel::Sampled &sp = R.sp;
+    const uint32_t P1 = 1u << b1, P2 = 1u << b2, NP = P1 * P2;
+    hipStream_t st = c->stream;
+    // sample: device histogram -> host
+    Buf hist;
+    RET(ensure(c, hist, (size_t)NP * 4 + 8));
+    std::vector<uint32_t> h(NP);
+    uint64_t ns = 0;
+    int rc = 0;
+    do {
+        hipError_t e = hipMemsetAsync(hist.p, 0, (size_t)NP * 4 + 8, st);
+        if (e == hipSuccess) { Timed t(c, "k_sample_joint"); e = launch_sample_joint(st, R.in_k, R.n, b1 + b2, SAMPLE_STRIDE, (uint32_t *)hist.p, (uint64_t *)((uint32_t *)hist.p + NP)); }
+        if (e == hipSuccess) e = hipMemcpyAsync(h.data(), hist.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&ns, (uint32_t *)hist.p + NP, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "sampling pass: %s", hipGetErrorString(e));
+    } while (0);
+    release(hist);
+    if (rc) return rc;
+    if (ns == 0) return fail(c, HJ_EHIP, "empty sample");
+    // ---- geometry, all on the host ----
+    const double n = (double)R.n, tot = (double)ns + 0.5 * NP;
+    std::vector<double> f(NP), fd(P1, 0.0);
+    for (uint32_t i = 0; i < NP; i++) { f[i] = ((double)h[i] + 0.5) / tot; fd[i / P2] += f[i]; }
+    auto relerr = [](double samples) { return 4.0 / std::sqrt(std::max(1.0, samples)); }; // 4 sigma of the sampled share
+    const double ROUNDT = 8192.0; // tuples per write-combining round (WC_THREADS * 4 * U)
+    // lines of the 512 dealt to `cnt` digits with shares sh[]: a digit wants its expected arrivals per round + 30 %
+    auto deal = [&](const double *sh, uint32_t cnt, std::vector<uint32_t> &lt, std::vector<uint32_t> &own, std::vector<uint32_t> &lines) {
+        // every digit starts from what the uniform kernels give it (512/cnt lines) or what it needs, whichever is more; when
+        // that is more than 512 lines the lightest digits give theirs back first (down to one), then everybody scales
+        const uint32_t kdef = std::max<uint32_t>(1u, 512u / cnt);
+        std::vector<uint32_t> need(cnt);
+        uint32_t total = 0;
+        lines.assign(cnt, 0);
+        for (uint32_t d = 0; d < cnt; d++) {
+            need[d] = std::min<uint32_t>((uint32_t)(1.3 * ROUNDT * sh[d] / 32.0) + 1, 512u);
+            lines[d] = std::max(need[d], kdef);
+            total += lines[d];
+        }
+        if (total > 512) {
+            std::vector<uint32_t> by(cnt);
+            for (uint32_t d = 0; d < cnt; d++) by[d] = d;
+            std::stable_sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return sh[x] < sh[y]; });
+            for (uint32_t round = 0; round < kdef && total > 512; round++)
+                for (uint32_t i = 0; i < cnt && total > 512; i++) {
+                    const uint32_t d = by[i];
+                    if (lines[d] > need[d] && lines[d] > 1) { lines[d]--; total--; }
+                }
+        }
+        if (total > 512) { // the needs alone exceed the lines: one each, the rest in proportion to the wish beyond one
+            uint32_t tn = 0;
+            for (uint32_t d = 0; d < cnt; d++) tn += need[d];
+            for (uint32_t d = 0; d < cnt; d++) lines[d] = 1 + (uint32_t)((uint64_t)(need[d] - 1) * (512 - cnt) / (tn - cnt));
+        }
+        uint32_t first = 0;
+        for (uint32_t d = 0; d < cnt; d++) {
+            lt[d] = (lines[d] << 16) | first;
+            for (uint32_t j = 0; j < lines[d]; j++) own[first + j] = d;
+            first += lines[d];
+        }
+    };
+    // pass 1
+    // spans like the exact passes' (four per CU): the pieces are uneven under skew, many of them balance better than few
+    const uint32_t target = c->target_spans ? c->target_spans : TARGET_SPANS;
+    uint64_t span = (R.n + target - 1) / target;
+    span = ((span + TILE - 1) / TILE) * TILE;
+    uint64_t nspans = (R.n + span - 1) / span;
+    while (nspans > 1024) { span += TILE; nspans = (R.n + span - 1) / span; }
+    std::vector<uint32_t> lt1(P1), own1(512, 0xFFFFu), lines1, vbase1(P1), vcap1(P1);
+    deal(fd.data(), P1, lt1, own1, lines1);
+    uint64_t posA = 0;
+    double maxfd = 0;
+    for (uint32_t d = 0; d < P1; d++) {
+        double hd = 0;
+        for (uint32_t q = 0; q < P2; q++) hd += h[d * P2 + q];
+        const double E = (double)span * fd[d];
+        const uint64_t gran = (uint64_t)lines1[d] * 32;
+        uint64_t cap = (uint64_t)(E * (1.0 + relerr(hd)) + 8.0 * std::sqrt(E) + 64.0);
+        cap = ((cap + gran - 1) / gran) * gran + gran;
+        vbase1[d] = (uint32_t)posA; vcap1[d] = (uint32_t)cap;
+        posA += cap * nspans;
+        maxfd = std::max(maxfd, fd[d]);
+        if (posA >= ((uint64_t)1 << 32) - ((uint64_t)1 << 20)) return 1; // does not fit 32-bit positions: not plannable
+    }
+    // pass 2
+    std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * 512, 0xFFFFu), heavy2(P1, 0), wg, rpart;
+    uint64_t posB = 0;
+    bool any_heavy = false, any_light = false;
+    // parents in the order their workgroups should start: the slow ones (one dominant child: wave-aggregated ranking) and the
+    // big ones first, so that the tail of the launch is made of small pieces
+    std::vector<uint32_t> porder(P1);
+    for (uint32_t d = 0; d < P1; d++) porder[d] = d;
+    {
+        std::vector<double> mxs(P1, 0.0);
+        for (uint32_t d = 0; d < P1; d++) for (uint32_t q = 0; q < P2; q++) mxs[d] = std::max(mxs[d], f[d * P2 + q] / fd[d]);
+        std::stable_sort(porder.begin(), porder.end(), [&](uint32_t x, uint32_t y) {
+            const bool hx = mxs[x] > 0.25, hy = mxs[y] > 0.25;
+            if (hx != hy) return hx;
+            return fd[x] > fd[y];
+        });
+    }
+    for (uint32_t di = 0; di < P1; di++) {
+        const uint32_t d = porder[di];
+        const double Ed = n * fd[d];
+        uint32_t J = (uint32_t)std::min<double>((double)nspans, std::max(1.0, std::ceil(Ed / (double)span)));
+        const double maxshare = (double)((nspans + J - 1) / J) / (double)nspans;
+        std::vector<double> sh(P2);
+        double mx = 0;
+        for (uint32_t q = 0; q < P2; q++) { sh[q] = f[d * P2 + q] / fd[d]; mx = std::max(mx, sh[q]); }
+        std::vector<uint32_t> lt(P2), own(512, 0xFFFFu), lines;
+        deal(sh.data(), P2, lt, own, lines);
+        heavy2[d] = mx > 0.25;
+        (heavy2[d] ? any_heavy : any_light) = true;
+        uint64_t W = 0;
+        for (uint32_t q = 0; q < P2; q++) {
+            const double E = maxshare * Ed * sh[q];
+            const uint64_t gran = (uint64_t)lines[q] * 32;
+            uint64_t cap = (uint64_t)(E * (1.0 + relerr((double)h[d * P2 + q])) + 8.0 * std::sqrt(E) + 64.0);
+            cap = ((cap + gran - 1) / gran) * gran + gran;
+            cbase2[d * P2 + q] = (uint32_t)W; cap2[d * P2 + q] = (uint32_t)cap; lt2[d * P2 + q] = lt[q];
+            W += cap;
+        }
+        for (uint32_t i = 0; i < 512; i++) own2[(size_t)d * 512 + i] = own[i];
+        for (uint32_t j = 0; j < J; j++) {
+            const uint32_t s0 = (uint32_t)((uint64_t)j * nspans / J), s1 = (uint32_t)((uint64_t)(j + 1) * nspans / J);
+            wg.push_back(d); wg.push_back(s0); wg.push_back(s1 - s0); wg.push_back((uint32_t)posB);
+            for (uint32_t q = 0; q < P2; q++) rpart.push_back(d * P2 + q);
+            posB += W;
+            if (posB >= ((uint64_t)1 << 32) - ((uint64_t)1 << 20)) return 1;
+        }
+    }
+    // upload: one table buffer
+    const uint32_t nwg = (uint32_t)(wg.size() / 4), heavy1 = maxfd > 0.25 ? 1u : 0u;
+    std::vector<uint32_t> tab;
+    auto put = [&](const std::vector<uint32_t> &v) { while (tab.size() & 3) tab.push_back(0); const size_t at = tab.size(); tab.insert(tab.end(), v.begin(), v.end()); return at; };
+    const size_t o_vb1 = put(vbase1), o_vc1 = put(vcap1), o_lt1 = put(lt1), o_ow1 = put(own1), o_h1 = put(std::vector<uint32_t>{heavy1});
+    const size_t o_cb2 = put(cbase2), o_c2 = put(cap2), o_lt2 = put(lt2), o_ow2 = put(own2), o_h2 = put(heavy2), o_wg = put(wg), o_rp = put(rpart);
+    RET(ensure(c, sp.tab, tab.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(sp.tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st)); // tab is pageable
+    const uint32_t *T = (const uint32_t *)sp.tab.p;
+    sp.vbase1 = T + o_vb1; sp.vcap1 = T + o_vc1; sp.lt1 = T + o_lt1; sp.own1 = T + o_ow1; sp.heavy1_d = T + o_h1;
+    sp.cbase2 = T + o_cb2; sp.cap2 = T + o_c2; sp.lt2 = T + o_lt2; sp.own2 = T + o_ow2; sp.heavy2 = T + o_h2; sp.wg2 = T + o_wg; sp.rpart = T + o_rp;
+    sp.n = R.n; sp.b1 = b1; sp.b2 = b2; sp.span = (uint32_t)span; sp.nspans = (uint32_t)nspans; sp.nwg2 = nwg; sp.nranges = nwg * P2;
+    sp.sizeA = posA; sp.sizeB = posB; sp.heavy1 = heavy1 != 0; sp.any_heavy2 = any_heavy; sp.any_light2 = any_light; sp.sample_size = ns;
+    sp.valid = true;
+    return 0;
+}
+
+// the two launches; *done = false when the relation cannot take this path (the caller goes on to the exact passes)
+int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag, bool *done) {
+    Rel &R = c->rel[r];
+    Rel::Sampled &sp = R.sp;
+    *done = false;
+    if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2) {
+        sp.valid = false;
+        const int rc = plan_sampled(c, R, b1, b2);
+        if (rc < 0) return rc;
+        if (rc > 0 || !sp.valid) { R.sampled_failed = true; return 0; }
+    }
+    const uint32_t P1 = 1u << b1, P2 = 1u << b2;
+    hipStream_t st = c->stream;
+    RET(ensure(c, R.a_k, (size_t)(sp.sizeA + PAD) * 4)); RET(ensure(c, R.a_p, (size_t)(sp.sizeA + PAD) * 4));
+    RET(ensure(c, R.b_k, (size_t)(sp.sizeB + PAD) * 4)); RET(ensure(c, R.b_p, (size_t)(sp.sizeB + PAD) * 4));
+    RET(ensure(c, R.s1beg, (size_t)P1 * sp.nspans * 8)); RET(ensure(c, R.s1end, (size_t)P1 * sp.nspans * 8));
+    RET(ensure(c, sp.rbeg, (size_t)sp.nranges * 8)); RET(ensure(c, sp.rend, (size_t)sp.nranges * 8));
+    FastArgs fa{};
+    fa.keys = R.in_k; fa.pays = R.in_p; fa.n = R.n; fa.span = sp.span; fa.nspans = sp.nspans;
+    fa.shift = b2; fa.P = P1;
+    fa.out_keys = (int32_t *)R.a_k.p; fa.out_pays = (int32_t *)R.a_p.p;
+    fa.obeg = (uint64_t *)R.s1beg.p; fa.oend = (uint64_t *)R.s1end.p; fa.ovf = flag;
+    VarArgs va{};
+    va.vbase = sp.vbase1; va.vcap = sp.vcap1; va.lt = sp.lt1; va.own = sp.own1; va.heavy = sp.heavy1_d; va.wg = nullptr;
+    { Timed t(c, "k_part1_var"); HIPCHK(c, launch_part1_var(st, fa, va, sp.heavy1)); }
+    FastArgs fb{};
+    fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
+    fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = sp.nspans;
+    fb.shift = 0; fb.P = P2;
+    fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
+    fb.obeg = (uint64_t *)sp.rbeg.p; fb.oend = (uint64_t *)sp.rend.p; fb.ovf = flag;
+    VarArgs vb{};
+    vb.vbase = sp.cbase2; vb.vcap = sp.cap2; vb.lt = sp.lt2; vb.own = sp.own2; vb.heavy = sp.heavy2; vb.wg = reinterpret_cast<const uint4 *>(sp.wg2);
+    { Timed t(c, "k_part2_var"); HIPCHK(c, launch_part2_var(st, fb, vb, sp.nwg2, sp.any_heavy2, sp.any_light2)); }
+    R.nparts = P1 * P2;
+    R.nranges = sp.nranges; R.rpart = sp.rpart;
+    R.part_k = (const int32_t *)R.b_k.p; R.part_p = (const int32_t *)R.b_p.p;
+    R.part_beg = (const uint64_t *)sp.rbeg.p; R.part_end = (const uint64_t *)sp.rend.p;
+    R.part_off = nullptr;
+    R.n_alloc = sp.sizeB;
+    R.pb1 = b1; R.pb2 = b2;
+    R.partitioned = true; R.fast_tried = true; R.sampled = true;
+    c->join_planned = false;
+    *done = true;
+    return 0;
+}
+
 int partition_rel(hj_ctx *c, int r) {
     Rel &R = c->rel[r];
     if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
@@ -291,8 +498,16 @@ int partition_rel(hj_ctx *c, int r) {
     R.fast_tried = false;
     R.flag_known_good = false;
     R.part_off = nullptr;
+    R.sampled = false; R.rpart = nullptr;
+    // known to be skewed, and on the probe side (the build side needs one range per partition): the sampled path
+    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 15 && c->fast_path && !c->cfg.exact_only && r != c->build &&
+        R.n >= ((uint64_t)1 << 20)) {
+        bool done = false;
+        RET(partition_sampled(c, r, b1, b2, flag, &done));
+        if (done) return 0;
+    }
     if (b1 == 0) { // nothing to partition: one partition = the input itself
-        R.part_k = R.in_k; R.part_p = R.in_p; R.nparts = 1; R.n_alloc = R.n;
+        R.part_k = R.in_k; R.part_p = R.in_p; R.nparts = 1; R.nranges = 1; R.n_alloc = R.n;
         R.part_off = (const uint64_t *)R.root.p;
         R.part_beg = R.part_off; R.part_end = R.part_off + 1;
         R.pb1 = R.pb2 = 0;
@@ -350,6 +565,7 @@ int partition_rel(hj_ctx *c, int r) {
         }
     }
     R.nparts = nparts;
+    R.nranges = nparts;
     R.part_k = (const int32_t *)R.b_k.p;
     R.part_p = (const int32_t *)R.b_p.p;
     R.part_beg = beg; R.part_end = end;
@@ -369,12 +585,24 @@ int resolve_layout(hj_ctx *c, Rel &R) {
     HIPCHK(c, hipMemcpyAsync(&ovf, (uint64_t *)c->scalars.p + 8 + (&R - c->rel), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (ovf) {
+        if (R.sampled) R.sampled_failed = true;
         R.prefer_exact = true;
         RET(partition_rel(c, (int)(&R - c->rel)));
+        if (R.fast_tried) return resolve_layout(c, R); // fast -> sampled -> exact: at most twice
     } else {
         R.flag_known_good = true;
     }
     return 0;
+}
+
+// introspection wants one gap-free range per partition: a sampled layout is redone with the exact passes
+int exact_for_introspection(hj_ctx *c, Rel &R) {
+    RET(resolve_layout(c, R));
+    if (!R.sampled) return 0;
+    R.force_exact = true;
+    const int rc = partition_rel(c, (int)(&R - c->rel));
+    R.force_exact = false;
+    return rc;
 }
 
 // work-item list of the current partitions: k_join_plan + scan + k_join_expand (decompose_chains, jp.cu:843-874)
@@ -386,7 +614,8 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
         return fail(c, HJ_EINVAL, "relations were partitioned with different radix bits (%u+%u vs %u+%u): partition both after loading both",
                     B.pb1, B.pb2, Pb.pb1, Pb.pb2);
     hipStream_t st = c->stream;
-    const uint32_t nparts = B.nparts;
+    if (B.sampled) return fail(c, HJ_EHIP, "internal: the build side must have one range per partition");
+    const uint32_t nparts = Pb.nranges; // probe RANGES (== partitions unless the probe side took the sampled path)
     const uint32_t rbits = B.pb1 + B.pb2;
     tag16 = (32 - rbits) <= 16; // the tag shortcut of jp.cu:1029 is exact only then (D2)
     const uint64_t max_items64 = (uint64_t)nparts + Pb.n / c->chunk + 1;
@@ -410,13 +639,14 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     a = JoinArgs{};
     a.bk = B.part_k; a.bp = B.part_p; a.bbeg = B.part_beg; a.bend = B.part_end; a.b_nalloc = B.n_alloc;
     a.pk = Pb.part_k; a.pp = Pb.part_p; a.pbeg = Pb.part_beg; a.pend = Pb.part_end; a.p_nalloc = Pb.n_alloc;
+    a.rpart = Pb.sampled ? Pb.rpart : nullptr;
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
-    if (nparts <= 16384) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
+    if (nparts <= 16384 && !a.rpart) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
         Timed t(c, "k_join_plan");
         HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, sc + 10, sc + 0));
     } else {
@@ -474,7 +704,10 @@ int fetch_scalars(hj_ctx *c) {
     for (int r = 0; r < 2; r++) {
         Rel &R = c->rel[r];
         if (!R.fast_tried || R.flag_known_good) continue;
-        if ((uint32_t)c->h_scalars[8 + r]) { R.prefer_exact = true; c->redo_mask |= 1u << r; } // slots overflowed: ranges invalid
+        if ((uint32_t)c->h_scalars[8 + r]) { // slots overflowed: ranges invalid
+            if (R.sampled) R.sampled_failed = true; // even the sampled capacities: the exact passes are what is left
+            R.prefer_exact = true; c->redo_mask |= 1u << r;
+        }
         else R.flag_known_good = true;
     }
     resolve_completed(c); // every [sync] entry point folds finished stamps: the event backlog stays bounded
@@ -486,13 +719,13 @@ int fetch_scalars(hj_ctx *c) {
 int count_and_fetch(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullptr) {
     RET(run_count(c, a, tag16, late));
     RET(fetch_scalars(c));
-    if (c->redo_mask) {
+    for (int attempt = 0; c->redo_mask; attempt++) { // histogram-free -> sampled capacities -> exact passes: at most two redos
+        if (attempt == 2) return fail(c, HJ_EHIP, "exact passes reported an overflow");
         const uint32_t m = c->redo_mask;
         for (int r = 0; r < 2; r++)
             if (m & (1u << r)) RET(partition_rel(c, r));
         RET(run_count(c, a, tag16, late));
         RET(fetch_scalars(c));
-        if (c->redo_mask) return fail(c, HJ_EHIP, "exact passes reported an overflow");
     }
     return 0;
 }
@@ -574,6 +807,7 @@ int hj_destroy(hj_ctx *c) {
         release(R.off1); release(R.off2); release(R.root);
         release(R.beg); release(R.end); release(R.s1beg); release(R.s1end);
         release(R.comp_k); release(R.comp_p); release(R.comp_off);
+        release(R.sp.tab); release(R.sp.rbeg); release(R.sp.rend);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
@@ -664,6 +898,7 @@ int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, u
     R.n = n;
     R.bound = true;
     R.prefer_exact = false; // new data: the histogram-free passes get their chance again
+    R.sampled_failed = false; R.sp.valid = false;
     invalidate(c, rel);
     return HJ_OK;
 }
@@ -674,7 +909,7 @@ int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_p
     if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
     Rel &R = c->rel[rel];
     // re-binding the same columns keeps what the last run learned about them (skewed keys: exact passes at once)
-    if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) R.prefer_exact = false;
+    if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) { R.prefer_exact = false; R.sampled_failed = false; R.sp.valid = false; }
     R.in_k = d_keys; R.in_p = d_pays; R.n = n; R.bound = true;
     invalidate(c, rel);
     return HJ_OK;
@@ -745,7 +980,7 @@ int materialize_two_pass(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_
 
 // ONE probe: plan the work items, k_join_mat stages + reserves + writes; the cursor comes back with the result block
 int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         JoinArgs a;
         bool tag16;
         if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
@@ -765,8 +1000,8 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
         c->join_planned = false;
         RET(fetch_scalars(c)); // [sync]
         if (!c->redo_mask) break;
-        if (attempt) return fail(c, HJ_EHIP, "exact passes reported an overflow");
-        const uint32_t m = c->redo_mask; // slots overflowed (skew): the kernel did nothing; exact passes, then once more
+        if (attempt == 2) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+        const uint32_t m = c->redo_mask; // slots overflowed (skew): the kernel did nothing; sampled capacities / exact passes, then again
         for (int r = 0; r < 2; r++)
             if (m & (1u << r)) RET(partition_rel(c, r));
     }
@@ -865,7 +1100,10 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
     for (int r = 0; r < 2; r++) {
         Rel &R = c->rel[r];
         if (!R.fast_tried) continue;
-        if ((uint32_t)c->h_scalars[8 + r]) { R.prefer_exact = true; c->redo_mask |= 1u << r; } // the data under the binding changed: skewed now
+        if ((uint32_t)c->h_scalars[8 + r]) { // the data under the binding changed: skewed now
+            if (R.sampled) R.sampled_failed = true;
+            R.prefer_exact = true; c->redo_mask |= 1u << r;
+        }
         else R.flag_known_good = true;
     }
     if (c->redo_mask) { drop_graph(c); return 0; } // the eager path redoes the flagged relation
@@ -1021,6 +1259,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
     }
     bool out_used[2] = {false, false};
     c->rel[HJ_REL_S].prefer_exact = false; // every call streams new data: the histogram-free passes get their chance again
+    c->rel[HJ_REL_S].sampled_failed = false; c->rel[HJ_REL_S].sp.valid = false;
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
@@ -1234,7 +1473,7 @@ int hj_get_partitions(hj_ctx *c, int rel, const int32_t **d_keys, const int32_t 
     Rel &R = c->rel[rel];
     if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
     HIPCHK(c, hipSetDevice(c->device));
-    RET(resolve_layout(c, R));
+    RET(exact_for_introspection(c, R));
     if (R.fast_tried) {
         // slotted layout (histogram-free passes): hand out a gap-free copy with contiguous offsets
         const uint32_t np = R.nparts;
@@ -1272,7 +1511,7 @@ int hj_partition_layout(hj_ctx *c, int rel, int *slotted) {
     if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
     HIPCHK(c, hipSetDevice(c->device));
     RET(resolve_layout(c, R));
-    if (slotted) *slotted = R.fast_tried ? 1 : 0;
+    if (slotted) *slotted = R.sampled ? 2 : (R.fast_tried ? 1 : 0);
     return HJ_OK;
 }
 
@@ -1459,7 +1698,7 @@ int hj_verify_partitions(hj_ctx *c, int rel, uint64_t *misplaced, uint64_t *d_di
     Rel &R = c->rel[rel];
     if (!R.partitioned) return fail(c, HJ_EINVAL, "relation %d not partitioned", rel);
     HIPCHK(c, hipSetDevice(c->device));
-    RET(resolve_layout(c, R));
+    RET(exact_for_introspection(c, R));
     uint64_t *sc = (uint64_t *)c->scalars.p;
     HIPCHK(c, hipMemsetAsync(sc + 4, 0, 8, c->stream));
     HIPCHK(c, launch_verify_partitions(c->stream, R.part_k, R.part_p, R.part_beg, R.part_end, R.nparts, 0, 0, sc + 4, d_digests, nullptr));

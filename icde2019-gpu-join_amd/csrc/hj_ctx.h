@@ -46,6 +46,24 @@ struct Rel {
     bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
     bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
     bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
+    // the sampled path (a relation known to be skewed, on the probe side): histogram-free passes with per-digit capacities
+    bool sampled = false;         // the current partitions came from it: ranges, not one range per partition
+    bool sampled_failed = false;  // it overflowed on this binding: exact passes from now on
+    bool force_exact = false;     // introspection calls want one gap-free range per partition
+    uint32_t nranges = 0;         // ranges of the partitioned relation (== nparts unless sampled)
+    const uint32_t *rpart = nullptr; // sampled: partition id of every range
+    struct Sampled {
+        bool valid = false;
+        uint64_t n = 0;
+        uint32_t b1 = 0, b2 = 0, span = 0, nspans = 0, nwg2 = 0, nranges = 0;
+        uint64_t sizeA = 0, sizeB = 0;
+        bool heavy1 = false, any_heavy2 = false, any_light2 = false;
+        uint64_t sample_size = 0;
+        Buf tab;                  // every table below, one allocation
+        const uint32_t *vbase1 = nullptr, *vcap1 = nullptr, *lt1 = nullptr, *own1 = nullptr, *heavy1_d = nullptr;
+        const uint32_t *cbase2 = nullptr, *cap2 = nullptr, *lt2 = nullptr, *own2 = nullptr, *heavy2 = nullptr, *wg2 = nullptr, *rpart = nullptr;
+        Buf rbeg, rend;           // ranges written by pass 2 [nranges]
+    } sp;
 };
 
 } // namespace hjx

@@ -539,7 +539,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         fb.obeg = (uint64_t *)R.beg.p + gr.boff; fb.oend = (uint64_t *)R.end.p + gr.boff;
         fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);
         { Timed t(c, "k_part2_fast"); DCHK(r, launch_part2_fast(cs, fb)); }
-        R.nparts = P1 * P2;
+        R.nparts = P1 * P2; R.nranges = P1 * P2; R.sampled = false; R.rpart = nullptr;
         R.part_k = (const int32_t *)R.b_k.p + gr.offB; R.part_p = (const int32_t *)R.b_p.p + gr.offB;
         R.part_beg = (const uint64_t *)R.beg.p + gr.boff; R.part_end = (const uint64_t *)R.end.p + gr.boff;
         R.part_off = nullptr;

@@ -77,6 +77,7 @@ struct JoinArgs {
     const uint64_t *pbeg, *pend;
     uint64_t p_nalloc;
     const uint32_t *bflag, *pflag; // overflow flags of histogram-free partitions (nullptr: ranges known good)
+    const uint32_t *rpart;   // probe side given as RANGES (sampled path): partition id of range i; nullptr: range i = partition i
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
@@ -104,6 +105,16 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
+// the sampled path of skewed relations (hj_kernels.hip: k_part1_var, k_part2_var)
+struct VarArgs {
+    const uint32_t *vbase, *vcap; // pass 1: per digit [P]; pass 2: per (parent, child) [nparents*P]
+    const uint32_t *lt, *own;     // lines dealt: (lines << 16 | first line) per digit [P] (pass 2: per parent row), owner digit per LDS line [512]
+    const uint32_t *heavy;        // pass 1: [1]; pass 2: per parent — one digit holds more than a quarter of the input
+    const uint4 *wg;              // pass 2: per workgroup {parent d, first pass-1 span, spans, output position of its sub-slots}
+};
+hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled);
+hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy);
+hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, uint32_t nwg, bool any_heavy, bool any_light);
 hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
                                 uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received);
 hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag);

@@ -38,6 +38,9 @@
 
 namespace hj {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (device, function) pair: high-water marks are kept under this lock
+static std::mutex g_attr_mutex;
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +381,18 @@ struct WfLds {
     uint32_t *lt, *own;          // exact pass under skew: lines << 16 | first line per digit; owner digit per line
 };
 
-struct FastGeom { uint32_t slotA, slotB, cap; }; // digit d's output slot = slotA + d*slotB, at slot*cap
+// digit d's output slot has index slotA + d*slotB (that is where its range [beg, end) is written) and, with uniform capacities,
+// lies at index*cap.  Variable capacities (the sampled path of skewed relations): the slot of digit d starts at
+// voff + vbase[d] + vs*vcap[d] and holds vcap[d] tuples.
+struct FastGeom {
+    uint32_t slotA, slotB, cap;
+    const uint32_t *vbase = nullptr, *vcap = nullptr;
+    uint32_t voff = 0, vs = 0;
+};
+__device__ __forceinline__ uint32_t slot_base(const FastGeom &g, uint32_t d) {
+    return g.vbase ? g.voff + g.vbase[d] + g.vs * g.vcap[d] : (g.slotA + d * g.slotB) * g.cap;
+}
+__device__ __forceinline__ uint32_t slot_cap(const FastGeom &g, uint32_t d) { return g.vbase ? g.vcap[d] : g.cap; }
 
 // One workgroup, one input stream, P digits with K = 512/P LDS lines each.  Per round of 8192 tuples:
 //   A  kept tuples of the previous round open their digit's next line; digit owners advance the output position by
@@ -469,7 +483,8 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
     for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
     // the digit this thread owns (tid < P): slot geometry
-    const uint32_t my_base = (g.slotA + tid * g.slotB) * g.cap, my_lim = my_base + g.cap;
+    const uint32_t my_base = tid < P ? slot_base(g, tid) : 0u, my_lim = my_base + (tid < P ? slot_cap(g, tid) : 0u);
+    const uint32_t my_gran = (VAR && tid < P) ? (L_.lt[tid] >> 16) * WC_LINE : capS; // a slot counts as full one granule (the digit's LDS lines) early
     const uint32_t trash = MAX_PARTS * WC_LINE + tid;
     uint32_t par = 0;
     for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
@@ -490,7 +505,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
             if (full) {
                 uint32_t nl = line[tid] + full;
-                if (!EXACT && nl + capS > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
+                if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
                 line[tid] = nl;
                 if (EXACT) L_.lo[tid] = 0; // only the run's first line starts mid-line
             }
@@ -546,7 +561,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
                         if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
                             const uint32_t o = line[d] + q;
-                            if (EXACT || o < (g.slotA + d * g.slotB + 1) * g.cap) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
+                            if (EXACT || o < slot_base(g, d) + slot_cap(g, d)) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
                             else *ovf = 1u;
                         }
                     }
@@ -612,7 +627,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
         if (full) {
             uint32_t nl = line[tid] + full;
-            if (!EXACT && nl + capS > my_lim) { *ovf = 1u; nl = my_base; }
+            if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u; nl = my_base; }
             line[tid] = nl;
             if (EXACT) L_.lo[tid] = 0;
         }
@@ -644,12 +659,12 @@ __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32 + 4; // + the "stop" word
     L_.sb = L_.pc4 + WF_MAXSEG + 4;
     L_.lo = L_.pc4;
-    L_.lt = L_.pc4 + MAX_PARTS;
-    L_.own = L_.pc4 + 2 * MAX_PARTS;
+    L_.lt = L_.sb + WF_MAXSEG;       // lines dealt by need: an area of their own (the segment tables of pass 2 are in use then)
+    L_.own = L_.lt + MAX_PARTS;
 }
 size_t fast_lds_bytes_impl() {
     return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
-           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4;
+           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2;
 }
 
 // The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
@@ -720,7 +735,8 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
     __syncthreads();
     if (tid < P) L_.hh[tid] = lo0 << 16; // round 0 starts at the fill the run's first line already has
     __syncthreads();
-    const FastGeom g{0, 0, 0};
+    FastGeom g{};
+    g.slotA = 0; g.slotB = 0; g.cap = 0;
     // block_excl_scan hands the workgroup totals to every thread: the branches are workgroup-uniform
 #define HJ_WC(KF, HV, VR) wc_fast<U, KF, 0, true, HV, VR, MODE>(L_, keys, pays, si.lo, si.hi, nalloc, 0, shift, P, g, out_keys, out_pays, nullptr, nullptr, nullptr, remap)
     if (var) { if (any_heavy) HJ_WC(0, true, true); else HJ_WC(0, false, true); }
@@ -745,11 +761,109 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
     FastGeom g{s, a.nspans, a.cap};
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap;
+    if (tid < a.P) L_.line[tid] = slot_base(g, tid);
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     if (MODE == 0 && a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, false, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 0, false, FEW, false, MODE>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+// ---- the sampled path of skewed relations: histogram-free passes with per-digit slot capacities and LDS lines dealt by
+// need, both derived (on the host, once per binding) from a joint sample histogram of the final partition ids.  The
+// reference partitions any distribution in one launch per pass (bump-allocated buckets, jp.cu:138-192); here a skewed
+// relation keeps the one-launch passes of the uniform case, with slots sized to what the sample says each digit receives.
+// A slot that still overflows raises the flag: the exact passes are the fallback. ----
+__global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict__ keys, uint64_t n, uint32_t mask, uint32_t stride,
+                                                       uint32_t *__restrict__ hist, unsigned long long *__restrict__ sampled) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t i = threadIdx.x; i <= mask; i += 1024) h[i] = 0;
+    __syncthreads();
+    // blocks of 4096 tuples, every stride-th one; the heavy key would serialise a wave's LDS atomics: aggregated rank
+    uint64_t cnt = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * stride; b * 4096 < n; b += (uint64_t)gridDim.x * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = b * 4096 + (uint64_t)u * 1024 + threadIdx.x;
+            const bool valid = i < n;
+            (void)rank_in_digit(h, valid ? ((uint32_t)keys[i] & mask) : 0u, valid);
+            cnt += valid;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= mask; i += 1024)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+    cnt = wave_sum64(cnt);
+    if (lane_id() == 0 && cnt) atomicAdd(sampled, (unsigned long long)cnt);
+}
+
+hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled) {
+    static bool set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t lds = ((size_t)1 << bits) * 4;
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        if (dev < 0 || dev >= 64 || !set[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_joint), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_sample_joint, dim3(256), dim3(1024), lds, st, keys, n, (1u << bits) - 1, stride, hist, reinterpret_cast<unsigned long long *>(sampled));
+    return hipGetLastError();
+}
+
+template <int U, bool HEAVY>
+__global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WfLds L_;
+    wf_carve(L_, smem);
+    if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const uint32_t tid = threadIdx.x, s = blockIdx.x;
+    const uint64_t lo = (uint64_t)s * a.span < a.n ? (uint64_t)s * a.span : a.n;
+    const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
+    FastGeom g{s, a.nspans, 0};
+    g.vbase = v.vbase; g.vcap = v.vcap; g.voff = 0; g.vs = s;
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
+    if (tid < a.P) { L_.line[tid] = slot_base(g, tid); L_.lt[tid] = v.lt[tid]; }
+    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
+    __syncthreads();
+    wc_fast<U, 0, 0, false, HEAVY, true, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (*a.ovf) return;
+    const uint4 w = v.wg[blockIdx.x]; // {parent, first span, spans, output position}
+    WfLds L_;
+    wf_carve(L_, smem);
+    const uint32_t tid = threadIdx.x, d = w.x;
+    FastGeom g{blockIdx.x * a.P, 1u, 0};
+    g.vbase = v.vbase + (uint64_t)d * a.P; g.vcap = v.vcap + (uint64_t)d * a.P; g.voff = w.w; g.vs = 0;
+    uint32_t *scratch = L_.hh;
+    uint32_t units = 0;
+    if (tid < w.z) {
+        const uint64_t b = a.sbeg[(uint64_t)d * a.spp + w.y + tid], e = a.send[(uint64_t)d * a.spp + w.y + tid];
+        const uint32_t cnt = (uint32_t)(e - b);
+        units = (cnt + 3) >> 2;
+        L_.sb[tid] = (uint32_t)b | (units * 4 - cnt);
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
+    if (tid < w.z) L_.pc4[tid] = ex;
+    if (tid == 0) L_.pc4[w.z] = total;
+    __syncthreads();
+    for (uint32_t i = tid; i < 2 * WC_HSTRIDE; i += WC_THREADS) L_.hh[i] = 0;
+    if (tid < a.P) { L_.line[tid] = slot_base(g, tid); L_.lt[tid] = v.lt[(uint64_t)d * a.P + tid]; }
+    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[(uint64_t)d * MAX_PARTS + tid];
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
+    __syncthreads();
+    // workgroup-uniform: parents dominated by one child rank with the wave-aggregated atomic (as k_scatter_wc does per span)
+    if (v.heavy[d]) wc_fast<U, 0, 1, false, true, true, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 1, false, false, true, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
 // multi-GPU: segment table of one received slice.  Peer q's split wrote its slots (me, s) into a region of nsp slots of cap
@@ -817,7 +931,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     if (tid == 0) L_.pc4[a.spp] = total;
     __syncthreads();
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) L_.line[tid] = (g.slotA + tid * g.slotB) * g.cap;
+    if (tid < a.P) L_.line[tid] = slot_base(g, tid);
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
@@ -972,13 +1086,15 @@ __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *_
                             const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                             uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt,
                             const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
-                            uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
-    if (p >= nparts) return;
-    if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[p] = 0; return; }
-    uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
-    items_cnt[p] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
+                            uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor, const uint32_t *__restrict__ rpart) {
+    // nparts = probe RANGES; the build partition of range i is rpart[i] (sampled path) or i
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
+    if (i >= nparts) return;
+    if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[i] = 0; return; }
+    const uint32_t p = rpart ? rpart[i] : i;
+    uint64_t nb = bend[p] - bbeg[p], np = pend[i] - pbeg[i];
+    items_cnt[i] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
 }
 
 // items_cnt has been scanned (local + chunk prefix): write the item list and the item count.
@@ -986,20 +1102,21 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
                               const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                               uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
                               const uint64_t *__restrict__ chunk_prefix, JoinItem *__restrict__ items,
-                              const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nparts) return;
+                              const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag, const uint32_t *__restrict__ rpart) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) return; // ranges not valid (k_join_plan counted no items)
-    uint64_t nb = bend[p] - bbeg[p], np = pend[p] - pbeg[p];
+    const uint32_t p = rpart ? rpart[i] : i;
+    uint64_t nb = bend[p] - bbeg[p], np = pend[i] - pbeg[i];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
-    uint64_t at = (uint64_t)items_scanned[p] + chunk_prefix[p >> SCAN_CHUNK_LOG];
+    uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
     // a self-contained descriptor per item: the join workgroup reads ONE 32-byte record and goes straight to the data
     // (not item -> partition -> four range loads: every dependent global load is ~2 us under load)
     for (uint32_t j = 0; j < c; j++) {
         JoinItem it;
         it.b0 = bbeg[p]; it.nb = (uint32_t)nb; it.p = p;
-        it.q0 = pbeg[p] + (uint64_t)j * chunk;
-        it.q1 = it.q0 + chunk < pend[p] ? it.q0 + chunk : pend[p];
+        it.q0 = pbeg[i] + (uint64_t)j * chunk;
+        it.q1 = it.q0 + chunk < pend[i] ? it.q0 + chunk : pend[i];
         items[at + j] = it;
     }
 }
@@ -1560,7 +1677,6 @@ __global__ __launch_bounds__(256) void k_verify_partitions(const int32_t *__rest
 // ------------------------------------------------------------------------------------------------
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (device, function) pair, not to a context: the
 // high-water marks are kept per device and only ever raised, under a lock (one context per host thread).
-static std::mutex g_attr_mutex;
 
 #define HJ_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -1656,7 +1772,7 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
 
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor) {
     hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt,
-                       a.bflag, a.pflag, zero2, zero_cursor);
+                       a.bflag, a.pflag, zero2, zero_cursor, a.rpart);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1664,7 +1780,7 @@ hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, 
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items) {
     hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
-                       items_scanned, chunk_prefix, items, a.bflag, a.pflag);
+                       items_scanned, chunk_prefix, items, a.bflag, a.pflag, a.rpart);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1921,6 +2037,30 @@ hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
         if ((e = fast_attr(fn, set[2])) != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy) {
+    static bool set[2][64] = {};
+    hipError_t e;
+    if (heavy) {
+        auto fn = k_part1_var<2, true>;
+        if ((e = fast_attr(fn, set[0])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va);
+    } else {
+        auto fn = k_part1_var<2, false>;
+        if ((e = fast_attr(fn, set[1])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, uint32_t nwg, bool, bool) {
+    static bool set[64] = {};
+    auto fn = k_part2_var<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va);
     return hipGetLastError();
 }
 

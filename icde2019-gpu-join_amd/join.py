@@ -117,10 +117,11 @@ class HashJoin:
         self._ck(self._L.hj_partition(self._h, rel))
 
     def partition_layout(self, rel):
-        """'slotted' if the histogram-free passes produced the partitions, 'exact' if the histogram passes did."""
+        """'slotted' if the histogram-free passes produced the partitions, 'sampled' if their variable-capacity form for a
+        skewed probe side did, 'exact' if the histogram passes did."""
         v = C.c_int()
         self._ck(self._L.hj_partition_layout(self._h, rel, C.byref(v)))
-        return "slotted" if v.value else "exact"
+        return {0: "exact", 1: "slotted", 2: "sampled"}[v.value]
 
     def join_count(self):
         m, a = C.c_uint64(), C.c_uint64()

@@ -189,7 +189,9 @@ int hj_memcpy_h2d(hj_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes); 
  * returns a gap-free copy owned by the context.  [sync] */
 int hj_get_partitions(hj_ctx *ctx, int rel, const int32_t **d_keys, const int32_t **d_pays,
                       const uint64_t **d_offsets, uint64_t *nparts);
-/* *slotted = 1 if the relation's partitions came from the histogram-free passes, 0 if from the exact passes. [sync] */
+/* *slotted = 1 if the relation's partitions came from the histogram-free passes, 2 if from the sampled path of a skewed
+ * probe-side relation (histogram-free passes with capacities from a sample; a partition is then a list of ranges), 0 if from
+ * the exact passes. [sync] */
 int hj_partition_layout(hj_ctx *ctx, int rel, int *slotted);
 int hj_enable_timings(hj_ctx *ctx, int level); /* 0 off, 1 data-moving kernels, 2 every launch.  [sync] */
 int hj_timings_reset(hj_ctx *ctx);

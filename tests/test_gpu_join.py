@@ -177,7 +177,7 @@ def test_graph_replay_follows_the_data(P):
         hj.load_host(P.REL_S, S3)
         for _ in range(4):
             assert hj.join()[0] == 3 * n
-        assert hj.partition_layout(P.REL_S) == "exact"
+        assert hj.partition_layout(P.REL_S) in ("exact", "sampled")
         # timings on: the graph is dropped, the eager path answers
         hj.enable_timings(1)
         assert hj.join()[0] == 3 * n and hj.timings()["k_join_count"]["launches"] == 1

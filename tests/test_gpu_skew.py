@@ -95,8 +95,9 @@ def test_config4_full_size_properties(P):
         assert hj.digest_pairs(k, p, nS) == before
         # the first join found S skewed (its histogram-free attempt overflowed); the second goes straight to the exact
         # passes, splits the radix bits evenly and deals the LDS lines by need — same partitions, same result
-        assert hj.partition_layout(P.REL_S) == "exact" and hj.partition_layout(P.REL_R) == "slotted"
+        assert hj.partition_layout(P.REL_S) == "exact" and hj.partition_layout(P.REL_R) == "slotted"   # (introspection redid S exact)
         assert hj.join() == (m, agg)
+        assert hj.partition_layout(P.REL_S) == "sampled"   # the skewed probe side: histogram-free passes, capacities from a sample
         bad, _ = hj.verify_partitions(P.REL_S)
         assert bad == 0
         k, p, off, nparts = hj.partition_pointers(P.REL_S)
@@ -130,4 +131,59 @@ def test_skewed_exact_passes_deal_lines_by_need(P, cfg):
             ok, op, ooff = o.radix_partition(keys, pays, 0, bits)
             assert np.array_equal(goff, ooff)
             assert np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+            assert hj.partition_layout(P.REL_S) == "exact"
+
+
+@pytest.mark.parametrize("cfg,nR,nS", [(dict(bits1=5, bits2=4), 1 << 16, 1 << 20), (dict(bits1=8, bits2=7), 1 << 18, 3 << 20),
+                                       (None, 1 << 22, 1 << 23)])
+def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
+    """A skewed relation on the probe side: the first join finds its slots overflowing, samples the key distribution once and
+    from then on partitions it with the histogram-free passes at per-digit capacities (layout 'sampled': a partition is a list
+    of ranges, the heavy digit is spread over many pass-2 workgroups).  Count, aggregate and the materialised multiset must
+    equal the oracle's in both materialising paths; introspection still hands out oracle-identical gap-free partitions; data
+    that changes under the binding so that the capacities no longer hold falls back to the exact passes."""
+    import torch
+    rng = np.random.default_rng(92)
+    R = rng.permutation(nR).astype(np.int32)
+    u = rng.random(nS)
+    S = np.where(u < 0.40, R[3], np.where(u < 0.55, R[11], np.where(u < 0.60, R[12], R[rng.integers(0, nR, nS)]))).astype(np.int32)
+    Pr = np.arange(nR, dtype=np.int32)
+    Ps = (np.arange(nS, dtype=np.int64) * 7 % 1000003).astype(np.int32)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    dR, dPr, dS, dPs = (torch.from_numpy(x).cuda() for x in (R, Pr, S, Ps))
+    with P.HashJoin(0) as hj:
+        if cfg:
+            hj.configure(**cfg)
+        hj.bind_device(P.REL_R, dR, dPr)
+        hj.bind_device(P.REL_S, dS, dPs)
+        for i in range(3):     # overflow -> sample -> sampled passes; then twice from the remembered tables
+            hj.bind_device(P.REL_S, dS, dPs)
+            assert hj.join() == (em, eagg), i
+            assert hj.partition_layout(P.REL_S) == "sampled" and hj.partition_layout(P.REL_R) == "slotted"
+        k, pr, ps = hj.join_materialize()
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        if em <= 2_000_000:
+            for a, b in zip(sorted_triples(k, pr, ps), sorted_triples(*o.join_materialize(R, Pr, S, Ps))):
+                assert np.array_equal(a, b)
+        hj.partition(P.REL_R)
+        hj.partition(P.REL_S)
+        k, pr, ps = hj.join_materialize(cap=em)                       # one probe, no count before it
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        hj.configure(**dict(cfg or {}, materialize_two_pass=True))   # configure keeps what was learned about the binding
+        assert hj.join() == (em, eagg)
+        k, pr, ps = hj.join_materialize()
+        assert o.triples_checksum(k, pr, ps) == echk
+        # introspection: gap-free partitions identical to the oracle's (the relation is redone with the exact passes for it)
+        c = hj.config()
+        bits = c["bits1"] + c["bits2"]
+        gk, gp, goff = hj.partitions(P.REL_S, nS)
+        ok, op, ooff = o.radix_partition(S, Ps, 0, bits)
+        assert np.array_equal(goff, ooff) and np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+        assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
+        # the data changes under the binding: another key is heavy now, the sampled capacities overflow -> exact passes
+        S2 = np.where(u < 0.45, R[1000], R[rng.integers(0, nR, nS)]).astype(np.int32)
+        dS.copy_(torch.from_numpy(S2).cuda())
+        em2, eagg2, _ = o.join_count(R, Pr, S2, Ps, checksum=False)
+        for _ in range(2):
+            assert hj.join() == (em2, eagg2)
             assert hj.partition_layout(P.REL_S) == "exact"
