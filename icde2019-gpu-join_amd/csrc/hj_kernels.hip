@@ -1006,11 +1006,12 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
     while (pow2 * 2 <= lines) pow2 *= 2;
     const uint64_t used16 = kind == 1 ? pow2 * 8 : n16; // the scatter covers the largest power-of-two number of lines
     static int blocks = 0, unr = 0, nt = 0;
-    if (!blocks) {
+    static std::once_flag once; // experiment knobs, read once (contexts on several host threads may get here together)
+    std::call_once(once, [] {
         const char *e = getenv("HJ_UB_BLOCKS"); blocks = e ? atoi(e) : 16384;
         const char *f = getenv("HJ_UB_UNROLL"); unr = f ? atoi(f) : 2;
         const char *h = getenv("HJ_UB_NT"); nt = h ? atoi(h) : 0;
-    }
+    });
     dim3 g(blocks), b(256);
     const uint64_t mul = 0x9E3779B97F4A7C15ULL | 1;
 #define UB(K_, U_) hipLaunchKernelGGL((k_ubench<K_, U_>), g, b, 0, st, (const int4 *)ik, (const int4 *)ip, (int4 *)ok, (int4 *)op, used16, K_ ? pow2 - 1 : (uint64_t)0, mul, nt)

@@ -42,6 +42,11 @@ class ShardedJoin:
 
     def _get(self, name, n):
         """Reusable int32 column of at least n elements (HBM is plentiful: keep, do not re-allocate)."""
+        # positions inside the partition kernels are 32-bit: a receive side that skew has grown beyond that is refused here, with a
+        # message, instead of failing later inside hj_partition
+        if n >= (1 << 32) - (1 << 20):
+            raise RuntimeError("rank %d would hold %d tuples of one relation (limit 2^32 - 2^20 per GPU): use more GPUs or balance='size'"
+                               % (self.rank, n))
         t = self._buf.get(name)
         if t is None or t.numel() < n:
             t = torch.empty(max(int(n * 1.02) + 1024, 1024), dtype=torch.int32, device=self.dev)

@@ -1,31 +1,35 @@
 #!/bin/bash
-# round-2 evidence: bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/r2prof/
+# round-3 evidence: bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/r3prof/ (copy what should be judged
+# into profiles/).  --pmc runs are separate from --kernel-trace --stats runs and never combined with sys/runtime tracing.
 cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
-OUT=$ROOT/gpurun_out/r2prof
+OUT=$ROOT/gpurun_out/r3prof
 mkdir -p $OUT
 cd $ROOT
+sha256sum icde2019-gpu-join_amd/libhj.so > $OUT/libhj.sha256
 python bench.py --steps 10 --warmup 3 > $OUT/bench_2p30.json 2> $OUT/bench_2p30.err; echo "bench30 rc=$?"
 python bench.py --steps 10 --warmup 3 --log2n 27 > $OUT/bench_2p27.json 2>/dev/null; echo "bench27 rc=$?"
 python bench.py --steps 10 --warmup 3 --exact-only --no-cpu-baseline > $OUT/bench_2p30_exact.json 2>/dev/null
-python bench.py --steps 10 --warmup 3 --log2n 27 --exact-only --no-cpu-baseline > $OUT/bench_2p27_exact.json 2>/dev/null
 python bench.py --workload zipf --steps 5 --warmup 2 > $OUT/bench_zipf.json 2>/dev/null; echo "zipf rc=$?"
+python bench.py --workload zipf --steps 5 --warmup 2 --exact-only --no-cpu-baseline > $OUT/bench_zipf_exact.json 2>/dev/null; echo "zipf exact rc=$?"
 python bench.py --workload stream --steps 3 --warmup 1 > $OUT/bench_stream.json 2>/dev/null; echo "stream rc=$?"
 python bench.py --workload coprocess --log2n 27 --steps 3 --warmup 1 > $OUT/bench_coprocess.json 2>/dev/null; echo "coprocess rc=$?"
-python tools/split_bench.py > $OUT/shard_split.txt 2>/dev/null
-bash tools/gpu_sizes.sh > $OUT/sizes.txt 2>/dev/null
 python bench.py --steps 5 --warmup 2 --force-dist --no-cpu-baseline > $OUT/bench_forcedist.json 2>/dev/null; echo "forcedist rc=$?"
+for g in 2 4 8; do python bench.py --steps 5 --warmup 2 --force-dist --phantom $g --no-cpu-baseline > $OUT/bench_phantom$g.json 2>/dev/null; done
+python bench.py --steps 5 --warmup 2 --force-dist --phantom 8 --single-group --no-cpu-baseline > $OUT/bench_phantom8_single_group.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --force-dist --dist-impl torch --no-cpu-baseline > $OUT/bench_forcedist_torch.json 2>/dev/null
+python tools/step_vs_size.py 2>/dev/null > $OUT/step_vs_size.txt
+python tools/handoff_gate.py 2>/dev/null > $OUT/handoff_gate.txt
 for l in 24 27 30; do python bench.py --workload baselines --log2n $l --steps 3 --warmup 1 2>/dev/null; done > $OUT/bench_baselines.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats30 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats30.log 2>&1; echo "stats30 rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats27 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --log2n 27 --no-cpu-baseline > $OUT/stats27.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python3 $ROOT/bench.py --workload zipf --steps 5 --warmup 2 > $OUT/statszipf.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats30exact -- python3 $ROOT/bench.py --steps 10 --warmup 3 --exact-only --no-cpu-baseline > $OUT/stats30exact.log 2>&1
-for d in stats30 stats27 statszipf stats30exact; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python3 $ROOT/bench.py --workload zipf --steps 5 --warmup 2 --no-cpu-baseline > $OUT/statszipf.log 2>&1
+for d in stats30 stats27 statszipf; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; done
 cd $ROOT
-tools/pmc_collect.sh r2prof/pmc30
-tools/pmc_collect.sh r2prof/pmc30_exact --exact-only
-tools/pmc_collect.sh r2prof/pmc27 --log2n 27
-tools/pmc_collect.sh r2prof/pmczipf --workload zipf --warmup 1
-rm -rf $OUT/pmc30/p? $OUT/pmc30_exact/p? $OUT/pmc27/p? $OUT/pmczipf/p?
+tools/pmc_collect.sh r3prof/pmc30
+tools/pmc_collect.sh r3prof/pmc30_mat --with-materialize
+tools/pmc_collect.sh r3prof/pmc27 --log2n 27
+tools/pmc_collect.sh r3prof/pmczipf --workload zipf --warmup 1
+rm -rf $OUT/pmc30/p? $OUT/pmc30_mat/p? $OUT/pmc27/p? $OUT/pmczipf/p?
 ls -la $OUT

@@ -5,6 +5,8 @@
 # profiles/ to have it judged.  --pmc is never combined with sys/runtime tracing here.
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
+MAT=--no-materialize
+if [ "$1" = "--with-materialize" ]; then MAT=""; shift; fi
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,7 +16,7 @@ GROUPS_=("FETCH_SIZE" "WRITE_SIZE"
 i=0
 for grp in "${GROUPS_[@]}"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-materialize --no-extras "$@" > $OUT/p$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $MAT --no-extras "$@" > $OUT/p$i.log 2>&1
   echo "== pass $i ($grp): rc=$?"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT "$@" > $OUT/pmc.json && echo "wrote $OUT/pmc.json"
