@@ -1538,7 +1538,17 @@ __global__ __launch_bounds__(256) void k_sum2(const uint64_t *__restrict__ cnt, 
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (uint64_t)gridDim.x * blockDim.x) { s += cnt[i]; t += agg[i]; }
     s = wave_sum64(s);
     t = wave_sum64(t);
-    if (lane_id() == 0) { if (s) atomicAdd(out, (unsigned long long)s); if (t) atomicAdd(out + 1, (unsigned long long)t); }
+    // one pair of atomics per WORKGROUP: a single word takes ~88 returning atomics per microsecond, and 4096 of them (one pair
+    // per wave of a 512-workgroup grid) cost this kernel ~50 us whatever the input size
+    __shared__ uint64_t red[2][4];
+    if (lane_id() == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = t; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        t = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (s) atomicAdd(out, (unsigned long long)s);
+        if (t) atomicAdd(out + 1, (unsigned long long)t);
+    }
 }
 
 // sum of a device-sized uint64 array (per-wave aggregates) into *out (zeroed by the caller)
@@ -1944,7 +1954,7 @@ hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *b
 }
 
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2) {
-    hipLaunchKernelGGL(k_sum2, dim3(512), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2));
+    hipLaunchKernelGGL(k_sum2, dim3(256), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2));
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
