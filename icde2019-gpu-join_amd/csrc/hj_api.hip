@@ -179,7 +179,7 @@ void choose_bits(hj_ctx *c) {
     // fewer than 16 radix bits: the LDS table stores full 4-byte keys (no 16-bit tags), 10 instead of 8 bytes per build
     // tuple.  With the default shape that is 62 KiB = 2 workgroups per CU; 4352 tuples + 2048 heads is 51.5 KiB = 3 per CU
     // (measured at 2^26-2^27: k_join_count 0.476 -> 0.439 ms, -8 %).
-    if (c->bits1 + c->bits2 < 16 && !g.lds_capacity && !g.lds_heads) {
+    if (c->bits1 + c->bits2 < 16 - c->tag_extra_max && !g.lds_capacity && !g.lds_heads) { // (with HJ_TAG_EXTRA: 14 / 15 bits keep 16-bit tags)
         c->cap = 4352;
         if (c->nh > 2048) c->nh = 2048;
     }
@@ -617,7 +617,11 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     if (B.sampled) return fail(c, HJ_EHIP, "internal: the build side must have one range per partition");
     const uint32_t nparts = Pb.nranges; // probe RANGES (== partitions unless the probe side took the sampled path)
     const uint32_t rbits = B.pb1 + B.pb2;
-    tag16 = (32 - rbits) <= 16; // the tag shortcut of jp.cu:1029 is exact only then (D2)
+    // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2).  At 14 and 15 radix bits the 1-2 key bits a 16-bit tag
+    // cannot hold select the upper part of the bucket index instead (k_join: hidx), which keeps the comparison exact and the 8-byte
+    // table entries; below that the table stores full keys.
+    const uint32_t tag_extra = (32 - rbits) > 16 ? (32 - rbits) - 16 : 0;
+    tag16 = tag_extra <= (uint32_t)c->tag_extra_max && c->nh >= 16 && (tag_extra == 0 || c->cap < 8192);
     const uint64_t max_items64 = (uint64_t)nparts + Pb.n / c->chunk + 1;
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
@@ -642,7 +646,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     a.rpart = Pb.sampled ? Pb.rpart : nullptr;
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
-    a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
+    a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk; a.tag_extra = tag16 ? tag_extra : 0;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
@@ -790,6 +794,7 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
+    if (const char *te = getenv("HJ_TAG_EXTRA")) c->tag_extra_max = std::max(0, std::min(2, atoi(te)));
     *out = c;
     return HJ_OK;
 }

@@ -81,6 +81,7 @@ struct JoinArgs {
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
+    uint32_t tag_extra;      // 16-bit tags at 14 / 15 radix bits: 2 / 1 key bits beyond the tag, folded into the bucket index
     uint64_t *wave_counts, *wave_agg;                     // count kernel outputs [items * JOIN_WAVES]
     const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
     int32_t *out_key, *out_bpay, *out_ppay;

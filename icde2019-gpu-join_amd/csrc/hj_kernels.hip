@@ -1179,6 +1179,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     const JoinItem it = a.items[item];
     const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    // 16-bit tags with fewer than 16 radix bits (tag_extra = 1 or 2 more key bits than a tag holds): the top tag_extra bits of
+    // the key pick the upper part of the bucket index, so every chain holds keys that agree on them and comparing the 16 stored
+    // bits is exact (the reference's tag shortcut, jp.cu:1029, is exact only at >= 16 radix bits, D2)
+    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1;
+    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
 
     uint64_t my_matches = 0, my_agg = 0;
     uint64_t cur = 0; // MAT: next output slot of this wave
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         uint64_t idx = i + e;
                         if (idx >= gb && idx < gb + nbc) {
                             const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                            const uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                            const uint32_t old = atomicExch(&head[hidx(key)], slot);
                             if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
                             else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
                         }
@@ -1248,7 +1253,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 for (int e = 0; e < 4; e++) {
                     const uint64_t idx = i + e;
                     const bool valid = idx >= q0 && idx < q1;
-                    pos4[e] = (valid ? head[((uint32_t)elem(kv, e) >> bits) & nhm] : 0xFFFFFFFFu) & 0xFFFFu;
+                    pos4[e] = (valid ? head[hidx((uint32_t)elem(kv, e))] : 0xFFFFFFFFu) & 0xFFFFu;
                 }
                 while ((pos4[0] & pos4[1] & pos4[2] & pos4[3]) != 0xFFFFu) {
 #pragma unroll
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         if (pos != 0xFFFFu) {
                             const uint32_t key = (uint32_t)elem(kv, e);
                             const uint2 en = ent[pos];
-                            const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
+                            const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
                             if (eq) {
                                 my_matches++;
                                 my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)elem(pv, e));
@@ -1273,12 +1278,12 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 const bool valid = idx >= q0 && idx < q1;
                 const uint32_t key = (uint32_t)elem(kv, e);
                 const int32_t ppay = elem(pv, e);
-                uint32_t pos = valid ? head[(key >> bits) & nhm] : 0xFFFFFFFFu;
+                uint32_t pos = valid ? head[hidx(key)] : 0xFFFFFFFFu;
                 pos &= 0xFFFFu; // chain links are 16 bit; 0xFFFF = end
                 if (!MAT) {
                     while (pos != 0xFFFFu) {
                         const uint2 en = ent[pos];
-                        const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
+                        const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
                         if (eq) {
                             my_matches++;
                             if (JM == 2) {
@@ -1302,7 +1307,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         uint2 en = make_uint2(0, 0);
                         while (pos != 0xFFFFu) {
                             en = ent[pos];
-                            const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
+                            const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
                             if (eq) break;
                             pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                         }
@@ -1367,6 +1372,9 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
     const JoinItem it = a.items[item];
     const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
+    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
+    const uint32_t smask = tx ? 0x1FFFu : 0xFFFFu; // staged slot word: slot | (top tag_extra key bits << 13) (cap < 8192 then)
     const uint32_t plow = it.p; // the partition id is the low `bits` key bits: a 16-bit tag + the id give the key back
     const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
 
@@ -1399,7 +1407,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
                         const uint64_t idx = i + e;
                         if (idx >= gb && idx < gb + nbc) {
                             const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                            const uint32_t old = atomicExch(&head[(key >> bits) & nhm], slot);
+                            const uint32_t old = atomicExch(&head[hidx(key)], slot);
                             if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
                             else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
                         }
@@ -1428,7 +1436,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
                     for (int e = 0; e < 4; e++) {
                         const uint64_t idx = i + e;
                         const bool valid = idx >= q0 && idx < q1;
-                        pos4[e] = (valid ? head[((uint32_t)elem(kv, e) >> bits) & nhm] : 0xFFFFFFFFu) & 0xFFFFu;
+                        pos4[e] = (valid ? head[hidx((uint32_t)elem(kv, e))] : 0xFFFFFFFFu) & 0xFFFFu;
                     }
                     fresh = false;
                 }
@@ -1445,7 +1453,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
                                 const uint32_t key = (uint32_t)elem(kv, e);
                                 const uint2 en = ent[pos];
                                 const uint32_t nx = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
-                                const bool eq = TAG16 ? ((en.x >> 16) == (key >> bits)) : (en.x == key);
+                                const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
                                 if (eq) { om |= 1u << e; nx4[e] = nx; }
                                 else { pos4[e] = nx; walking |= nx != 0xFFFFu; }
                             }
@@ -1466,7 +1474,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
                         const uint32_t idx = b + before[e] + (uint32_t)__popcll(m4[e] & lt_mask);
                         if (((om >> e) & 1u) && idx < S) {
                             sp[idx] = (uint32_t)elem(pv, e);
-                            ss[idx] = (uint16_t)pos4[e];
+                            ss[idx] = (uint16_t)(pos4[e] | (tx ? (((uint32_t)elem(kv, e) >> bits) >> 16) << 13 : 0u));
                             pos4[e] = nx4[e]; // staged: move on
                         }
                     }
@@ -1494,8 +1502,9 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
             for (int r = 0; r < MAT_R; r++) {
                 const uint32_t i = tid + (uint32_t)r * JOIN_THREADS;
                 if (i < T) {
-                    const uint2 en = ent[ss[i]];
-                    rk[r] = TAG16 ? (((en.x >> 16) << bits) | plow) : en.x;
+                    const uint32_t sw = ss[i];
+                    const uint2 en = ent[sw & smask];
+                    rk[r] = TAG16 ? (((en.x >> 16) << bits) | plow | (tx ? (sw >> 13) << (bits + 16) : 0u)) : en.x;
                     rb[r] = en.y;
                     rp[r] = sp[i];
                 }
@@ -1514,10 +1523,11 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
             }
             if (T > (uint32_t)MAT_R * JOIN_THREADS) { // a larger staging block than the registers cover (hj_config.lds_stage)
                 for (uint32_t i = tid + (uint32_t)MAT_R * JOIN_THREADS; i < T; i += JOIN_THREADS) {
-                    const uint2 en = ent[ss[i]];
+                    const uint32_t sw = ss[i];
+                    const uint2 en = ent[sw & smask];
                     const uint64_t o = base + i;
                     if (o < a.out_cap) {
-                        a.out_key[o] = (int32_t)(TAG16 ? (((en.x >> 16) << bits) | plow) : en.x);
+                        a.out_key[o] = (int32_t)(TAG16 ? (((en.x >> 16) << bits) | plow | (tx ? (sw >> 13) << (bits + 16) : 0u)) : en.x);
                         a.out_bpay[o] = (int32_t)en.y;
                         a.out_ppay[o] = (int32_t)sp[i];
                     }

@@ -235,15 +235,28 @@ def test_skew_heavy_hitters(P):
         _check_join(P, R, np.arange(n, dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
 
 
-def test_tag16_vs_full_key_paths(P):
-    # 16+ radix bits → 16-bit tags (the reference's compression, jp.cu:1029); fewer → full keys.
+@pytest.mark.parametrize("tag_extra", [None, "2"])
+def test_tag16_vs_full_key_paths(P, monkeypatch, tag_extra):
+    # 16+ radix bits → 16-bit tags (the reference's compression, jp.cu:1029); fewer → full keys — or, with HJ_TAG_EXTRA (an
+    # experiment knob read at hj_create; measured no faster, profiles/r3_tag_extra_ab.txt), 16-bit tags also at 15 / 14 radix
+    # bits with the one / two key bits a tag cannot hold folded into the bucket index.
+    if tag_extra:
+        monkeypatch.setenv("HJ_TAG_EXTRA", tag_extra)
     rng = np.random.default_rng(11)
     R = rng.integers(-2**31, 2**31 - 1, 1 << 16).astype(np.int32)
     S = np.concatenate([R[: 1 << 15], rng.integers(-2**31, 2**31 - 1, 1 << 15).astype(np.int32)])
     # keys that agree in the low bits and in the hash slot bits but differ above must not match
     R[:4] = [0x00010000, 0x10010000, 0x20010000, 0x30010000]
     S[:2] = [0x40010000, 0x10010000]
-    for cfg in (dict(bits1=8, bits2=8), dict(bits1=9, bits2=9), dict(bits1=8, bits2=7), dict(bits1=2)):
+    # keys that differ ONLY in the one or two top bits a 16-bit tag cannot hold at 15 / 14 radix bits (folded into the bucket
+    # index there): same partition, same tag, same low bucket bits — must not match
+    R[4:8] = [0x00012345, -0x7FFEDCBB, 0x40012345, -0x3FFEDCBB]       # 0x00012345 | top bits 00, 10, 01, 11
+    S[2:5] = [-0x7FFEDCBB, 0x40012345, 0x00012345 | 0x20000000]
+    R[8:10] = [-2**31, 2**31 - 1]
+    S[5:7] = [2**31 - 1, -2**31]
+    for cfg in (dict(bits1=8, bits2=8), dict(bits1=9, bits2=9), dict(bits1=8, bits2=7), dict(bits1=7, bits2=7), dict(bits1=9, bits2=6),
+                dict(bits1=8, bits2=7, lds_heads=16, lds_capacity=256), dict(bits1=7, bits2=7, lds_heads=4, lds_capacity=100),
+                dict(bits1=7, bits2=6), dict(bits1=2)):
         _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
 
 
