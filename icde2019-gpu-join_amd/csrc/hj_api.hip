@@ -815,7 +815,8 @@ int hj_destroy(hj_ctx *c) {
         release(R.sp.tab); release(R.sp.rbeg); release(R.sp.rend);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
-    for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); }
+    for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); if (c->seg_joined[i]) (void)hipEventDestroy(c->seg_joined[i]); }
+    release(c->seg_res);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1286,6 +1287,54 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
         HIPCHK(c, hipEventRecord(c->seg_ready[b], c->copy));
         return 0;
     };
+    if (!h_out && !rc && nseg) {
+        // ---- count-only: the segment loop never blocks the host (the reference chains its segments with events the same way,
+        // hjcp.cu:1897-1965).  copy(i) waits for join(i-2) — the last reader of its staging buffer — by event; every segment's
+        // (matches, aggregate, overflow flag of S) is parked in a device array; ONE read-back at the end.  A segment whose slots
+        // overflowed (skew) contributed nothing: those few are redone afterwards through the blocking path. ----
+        if ((rc = resolve_layout(c, R))) goto done; // R's flag is read once, before the loop [sync]
+        for (int i = 0; i < 2; i++)
+            if (!c->seg_joined[i] && hipEventCreateWithFlags(&c->seg_joined[i], hipEventDisableTiming) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); goto done; }
+        if ((rc = ensure(c, c->seg_res, (size_t)nseg * 32))) goto done;
+        uint64_t *sc = (uint64_t *)c->scalars.p;
+        for (uint64_t i = 0; i < nseg && !rc; i++) {
+            const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
+            const int b = (int)(i & 1);
+            if (i >= 2 && hipStreamWaitEvent(c->copy, c->seg_joined[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
+            if ((rc = issue_copy(i))) break;
+            if (hipStreamWaitEvent(c->stream, c->seg_ready[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
+            if (payload_mode != HJ_PAYLOAD_GIVEN && launch_fill(c->stream, (int32_t *)c->seg_p[b].p, cnt, payload_mode, off) != hipSuccess) { rc = fail(c, HJ_EHIP, "fill"); break; }
+            Rel &S = c->rel[HJ_REL_S];
+            S.in_k = (const int32_t *)c->seg_k[b].p; S.in_p = (const int32_t *)c->seg_p[b].p; S.n = cnt; S.bound = true;
+            invalidate(c, HJ_REL_S);
+            if ((rc = partition_rel(c, HJ_REL_S))) break;
+            if ((rc = hj_join_count_enqueue(c))) break;
+            uint64_t *slot = (uint64_t *)c->seg_res.p + 4 * i;
+            if (hipMemcpyAsync(slot, sc + 1, 16, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(slot + 2, sc + 8 + HJ_REL_S, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipEventRecord(c->seg_joined[b], c->stream) != hipSuccess) { rc = fail(c, HJ_EHIP, "segment result"); break; }
+        }
+        std::vector<uint64_t> res((size_t)nseg * 4, 0);
+        if (!rc && hipMemcpyAsync(res.data(), c->seg_res.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(c, HJ_EHIP, "result read-back");
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(c, HJ_EHIP, "hipStreamSynchronize");
+        (void)hipStreamSynchronize(c->copy);
+        for (uint64_t i = 0; i < nseg && !rc; i++) {
+            if (!(uint32_t)res[4 * i + 2]) { tot_m += res[4 * i]; tot_a += res[4 * i + 1]; continue; }
+            // this segment's slots overflowed: blocking redo (hj_join_count re-partitions S along the skew ladder)
+            const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
+            if (hipMemcpy(c->seg_k[0].p, h_keys + off, cnt * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                (payload_mode == HJ_PAYLOAD_GIVEN && hipMemcpy(c->seg_p[0].p, h_pays + off, cnt * 4, hipMemcpyHostToDevice) != hipSuccess)) { rc = fail(c, HJ_EHIP, "H2D"); break; }
+            if (payload_mode != HJ_PAYLOAD_GIVEN && launch_fill(c->stream, (int32_t *)c->seg_p[0].p, cnt, payload_mode, off) != hipSuccess) { rc = fail(c, HJ_EHIP, "fill"); break; }
+            Rel &S = c->rel[HJ_REL_S];
+            S.in_k = (const int32_t *)c->seg_k[0].p; S.in_p = (const int32_t *)c->seg_p[0].p; S.n = cnt; S.bound = true;
+            invalidate(c, HJ_REL_S);
+            if ((rc = partition_rel(c, HJ_REL_S))) break;
+            uint64_t m = 0, a = 0;
+            if ((rc = hj_join_count(c, &m, &a))) break;
+            tot_m += m; tot_a += a;
+        }
+        goto done;
+    }
     if (!rc && nseg) rc = issue_copy(0);
     for (uint64_t i = 0; i < nseg && !rc; i++) {
         const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
@@ -1333,6 +1382,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
         }
         tot_m += m; tot_a += a;
     }
+done:
     // on every exit path: the H2D copy of the next segment may still be reading the caller's columns
     (void)hipStreamSynchronize(c->copy);
     if (c->d2h) (void)hipStreamSynchronize(c->d2h);

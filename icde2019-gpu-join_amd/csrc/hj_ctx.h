@@ -106,6 +106,8 @@ struct hj_ctx {
     hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
     hipEvent_t out_ready[2] = {}, out_free[2] = {};
     hipEvent_t seg_ready[2] = {};
+    hipEvent_t seg_joined[2] = {};  // streaming probe, count-only: the join of the segment in staging buffer b is done
+    Buf seg_res;                    // ... per segment {matches, aggregate, S's overflow flag, -}
     hipStream_t aux = nullptr;      // small inputs: S's partition passes run beside R's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // hj_config.graph: the captured step and what it is tied to

@@ -187,3 +187,23 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
         for _ in range(2):
             assert hj.join() == (em2, eagg2)
             assert hj.partition_layout(P.REL_S) == "exact"
+
+
+def test_stream_probe_segments_that_overflow_are_redone(P):
+    """The count-only streaming loop never blocks the host: every segment's result and overflow flag are parked on the device
+    and read once at the end; segments whose histogram-free slots overflowed (half of every segment is one key here)
+    contributed nothing and are redone through the blocking path.  Uniform segments in between take the fast road."""
+    rng = np.random.default_rng(93)
+    nR, nS, seg = 1 << 16, 1 << 21, 1 << 19
+    R = rng.permutation(nR).astype(np.int32)
+    S = R[rng.integers(0, nR, nS)].astype(np.int32)
+    S[: seg // 2] = R[5]                      # segment 0: skewed
+    S[2 * seg: 2 * seg + seg // 2] = R[9]     # segment 2: skewed; segments 1 and 3: uniform
+    Ps = np.arange(nS, dtype=np.int32)
+    em, eagg, _ = o.join_count(R, np.arange(nR, dtype=np.int32), S, Ps, checksum=False)
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=5, bits2=4)
+        hj.load_host(P.REL_R, R, np.arange(nR, dtype=np.int32))
+        for _ in range(2):
+            assert hj.join_stream_probe(S, Ps, segment_tuples=seg) == (em, eagg)
+        assert hj.join_stream_probe(S, None, "rowid", segment_tuples=seg) == (em, eagg)
