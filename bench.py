@@ -290,6 +290,7 @@ def bench_coprocess(a, pkg, torch, dev, local):
     print(json.dumps({"metric": "billion tuples/sec, CPU-GPU co-processing: R and S (2^%d each) in host memory" % (n.bit_length() - 1),
                       "value": round(2 * n / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2),
                       "host_split_GBs": round(sum(gbs) / len(gbs), 2), "cpu_model": cpu_model(),
+                      "numa": dict(zip(("nodes", "gpu_node", "workers_bound_to_cpus_of_that_node"), hj.coprocess_numa())),
                       "config": {"workload": "unique uniform int32, 16 level-0 partitions, host split on the box's CPU quota, "
                                              "double-buffered upload + GPU join per partition"}}))
 

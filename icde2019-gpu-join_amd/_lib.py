@@ -71,6 +71,7 @@ SIGNATURES = {
     "hj_enable_timings": (C.c_int, [vp, C.c_int]),
     "hj_join_stream_probe_materialize": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp, C.c_uint64, u64p, u64p]),
     "hj_host_split": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, u64p, C.POINTER(C.c_double)]),
+    "hj_coprocess_numa": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hj_host_split_throughput": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "hj_ubench": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
     "hj_ubench_handoff": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),

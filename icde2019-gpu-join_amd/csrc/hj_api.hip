@@ -4,6 +4,7 @@
 // result copy is enqueued on one HIP stream with no host read of device data (same discipline as
 // the reference's timed region, hjcp.cu:881-933: *buckets_used is only dereferenced on device).
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1442,6 +1443,29 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
+    // NUMA (partition-primitives.cu:129-253, hjcp.cu:1142-1149: partitions allocated per node, threads bound to sockets, staging
+    // near the GPU): hipHostMalloc places pinned memory on the node closest to the current device unless told otherwise; on a
+    // host with more than one node the split's workers are bound to that node's CPUs, so that the write-combining buffers,
+    // the non-temporal stores and the DMA reads all stay on the GPU's socket.  HJ_NUMA=0 leaves the threads where they are.
+    std::vector<int> pin;
+    c->numa_nodes = host_numa_nodes();
+    c->numa_gpu_node = -1;
+    {
+        int node = -1;
+        if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, c->device) == hipSuccess) c->numa_gpu_node = node;
+        else (void)hipGetLastError();
+        if (c->numa_gpu_node < 0) { // the runtime does not say: ask the PCI device in sysfs
+            char bus[32] = {0}, path[128];
+            if (hipDeviceGetPCIBusId(bus, sizeof bus, c->device) == hipSuccess) {
+                for (char *q = bus; *q; q++) *q = (char)tolower(*q);
+                snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+                if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) == 1) c->numa_gpu_node = node; fclose(f); }
+            } else (void)hipGetLastError();
+        }
+        const char *e = getenv("HJ_NUMA");
+        if (c->numa_nodes > 1 && c->numa_gpu_node >= 0 && !(e && atoi(e) == 0)) pin = host_node_cpus(c->numa_gpu_node);
+    }
+    c->numa_pinned_cpus = (int)pin.size();
     // host split; the partitioned copies are pinned so that the uploads are asynchronous.  The staging buffers belong
     // to the context and only ever grow: a caller that joins in a loop pins host memory once.
     int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
@@ -1462,7 +1486,7 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         }
         if (!rc) {
             pk[r] = c->host_k[r]; pp[r] = c->host_p[r];
-            if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r]))
+            if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r], pin.empty() ? nullptr : &pin))
                 rc = fail(c, HJ_ENOMEM, "could not start %u host threads for the level-0 split", host_threads);
         }
     }
@@ -1513,6 +1537,14 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     if (rc) return rc;
     if (matches) *matches = tot_m;
     if (agg) *agg = tot_a;
+    return HJ_OK;
+}
+
+int hj_coprocess_numa(const hj_ctx *c, int *nodes, int *gpu_node, int *pinned_cpus) {
+    if (!c) return HJ_EINVAL;
+    if (nodes) *nodes = c->numa_nodes;
+    if (gpu_node) *gpu_node = c->numa_gpu_node;
+    if (pinned_cpus) *pinned_cpus = c->numa_pinned_cpus;
     return HJ_OK;
 }
 

@@ -101,6 +101,7 @@ struct hj_ctx {
     Buf cop_k[2], cop_p[2];         // double-buffered level-0 R partitions (co-processing)
     int32_t *host_k[2] = {nullptr, nullptr}, *host_p[2] = {nullptr, nullptr}; // pinned staging of the host split (R, S): kept across calls
     size_t host_cap[2] = {0, 0};    // elements
+    int numa_nodes = 0, numa_gpu_node = -1, numa_pinned_cpus = 0; // co-processing: host topology seen by the last call
     double host_split_gbs = 0;      // throughput of the last host level-0 split (bytes read + written per second)
     Buf out_k[2], out_p1[2], out_p2[2]; // streamed materialisation: double-buffered device output columns
     hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)

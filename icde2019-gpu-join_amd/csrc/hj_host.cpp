@@ -1,7 +1,10 @@
 // hj_host.cpp — the host-only half of libhj.so: the level-0 write-combining split of the co-processing path and the
 // shard function.  Plain C++ (no HIP runtime): this file, gen_ethz.cpp and bench_main.cpp's option parsing are what
 // `make asan` builds with -fsanitize=address,undefined for the CPU test leg (tests/test_asan.py).
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -92,19 +95,61 @@ void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t
 } // namespace
 
 // false: a host thread could not be started (pids limit of the container): nothing usable was written
+int host_numa_nodes() {
+    int nodes = 0;
+    for (int i = 0; i < 64; i++) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", i);
+        if (FILE *f = fopen(path, "r")) { nodes++; fclose(f); }
+    }
+    return nodes;
+}
+
+std::vector<int> host_node_cpus(int node) {
+    std::vector<int> out;
+    char path[96], buf[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return out;
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return out;
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    const bool have_mask = sched_getaffinity(0, sizeof mine, &mine) == 0;
+    for (char *p = buf; *p && *p != '\n';) { // "0-63,128-191"
+        char *e;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (!have_mask || CPU_ISSET((int)c, &mine)) out.push_back((int)c);
+        p = (*e == ',') ? e + 1 : e;
+    }
+    return out;
+}
+
 bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
-                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off) {
+                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
     if (threads < 1) threads = 1;
     std::vector<uint64_t> hist((size_t)threads * parts, 0);
     auto chunk = [&](uint32_t t, uint64_t &lo, uint64_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
     // run f(t) for t = 0..threads-1 on that many host threads; thread 0's share runs on the caller
+    const bool pin = pin_cpus && !pin_cpus->empty();
+    auto bind_self = [&] { // the worker may run on any CPU of the staging buffers' node
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (int c : *pin_cpus) CPU_SET(c, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    };
     auto parallel = [&](auto f) -> bool {
         std::vector<std::thread> th;
         bool ok = true;
         try {
-            for (uint32_t t = 1; t < threads; t++) th.emplace_back(f, t);
+            for (uint32_t t = pin ? 0 : 1; t < threads; t++) // pinned: every share on a worker (the caller's affinity stays as it is)
+                th.emplace_back([&, t] { if (pin) bind_self(); f(t); });
         } catch (const std::system_error &) { ok = false; }
-        if (ok) f(0);
+        if (ok && !pin) f(0);
         for (auto &x : th) x.join();
         return ok;
     };

@@ -189,6 +189,12 @@ class HashJoin:
                                            C.byref(m), C.byref(a)))
         return m.value, a.value
 
+    def coprocess_numa(self):
+        """(NUMA nodes of the host, node closest to the GPU, CPUs of that node the split's workers were bound to)."""
+        a, b, d = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.hj_coprocess_numa(self._h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
     def host_split_throughput(self):
         v = C.c_double()
         self._ck(self._L.hj_host_split_throughput(self._h, C.byref(v)))

@@ -174,6 +174,10 @@ int hj_join_coprocess(hj_ctx *ctx, const int32_t *h_R, const int32_t *h_Pr, uint
  * second by the whole split (the reference prints its partition throughput, pp.cu:218).  No GPU involved. */
 int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
                   int32_t *out_keys, int32_t *out_pays, uint64_t *offsets, double *gbs);
+/* NUMA placement of the last hj_join_coprocess call (partition-primitives.cu:129-253 keeps partitions and threads per
+ * socket): NUMA nodes of the host, the node closest to the context's GPU (-1 unknown: pinned staging is allocated there by
+ * hipHostMalloc), and how many of that node's CPUs the split's workers were bound to (0: not bound — one node, HJ_NUMA=0). */
+int hj_coprocess_numa(const hj_ctx *ctx, int *nodes, int *gpu_node, int *pinned_cpus);
 /* GB/s of the host split inside the last hj_join_coprocess call of this context. */
 int hj_host_split_throughput(const hj_ctx *ctx, double *gbs);
 
