@@ -37,7 +37,7 @@ class Args(C.Structure):  # include/hj_reference_abi.h  (src/common-host.h:39-52
 
 class DistConfig(C.Structure):  # include/hj_dist.h
     _fields_ = [("slices", C.c_uint32), ("exact_only", C.c_uint32), ("self_via_link", C.c_uint32), ("phantom_world", C.c_uint32),
-                ("single_group", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("single_group", C.c_uint32), ("balance_size", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class DistStats(C.Structure):
@@ -45,7 +45,7 @@ class DistStats(C.Structure):
                 ("slices", C.c_uint32), ("spans_per_slice", C.c_uint32), ("slot_capacity", C.c_uint32 * 2),
                 ("split_ms", C.c_float * 2), ("pass1_ms", C.c_float * 2), ("pass2_join_ms", C.c_float),
                 ("first_split_ms", C.c_float), ("last_pass1_ms", C.c_float), ("wall_ms", C.c_float), ("early_pass2_join_ms", C.c_float), ("probe_groups", C.c_uint32),
-                ("reserved", C.c_uint32 * 6)]
+                ("balanced", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class LastResult(C.Structure):

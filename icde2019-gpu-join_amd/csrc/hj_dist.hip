@@ -262,7 +262,7 @@ struct hj_dist_rank {
     uint64_t *h_small = nullptr;         // pinned mirror
     std::vector<hipEvent_t> ev_split, ev_xchg, ev_t; // per (relation, slice); timing events
     hipEvent_t ev_misc[4] = {};
-    hj_ctx::Buf x_send_k[2], x_send_p[2], x_recv_k[2], x_recv_p[2], x_counts; // exact path
+    hj_ctx::Buf x_send_k[2], x_send_p[2], x_recv_k[2], x_recv_p[2], x_counts, x_bal; // exact path
 
     int fail(int code, const char *fmt, ...) {
         char buf[600];
@@ -302,9 +302,9 @@ int dist_ensure(hj_dist_rank *r, hj_ctx::Buf &b, size_t bytes) {
 int rank_init(hj_dist_rank *r) {
     DCHK(r, hipSetDevice(r->c->device));
     DCHK(r, hipStreamCreateWithFlags(&r->comm, hipStreamNonBlocking));
-    LRET(r, dist_ensure(r, r->small, 4096));
-    DCHK(r, hipMemset(r->small.p, 0, 4096));
-    DCHK(r, hipHostMalloc((void **)&r->h_small, 4096, hipHostMallocDefault));
+    LRET(r, dist_ensure(r, r->small, 16384));
+    DCHK(r, hipMemset(r->small.p, 0, 16384));
+    DCHK(r, hipHostMalloc((void **)&r->h_small, 16384, hipHostMallocDefault));
     for (auto &e : r->ev_misc) DCHK(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
@@ -319,6 +319,7 @@ void rank_free(hj_dist_rank *r) {
         release(r->x_send_k[x]); release(r->x_send_p[x]); release(r->x_recv_k[x]); release(r->x_recv_p[x]);
     }
     release(r->x_counts);
+    release(r->x_bal);
     release(r->small);
     if (r->h_small) (void)hipHostFree(r->h_small);
     for (auto e : r->ev_split) if (e) (void)hipEventDestroy(e);
@@ -620,7 +621,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
 }
 
 // ---- exact-count exchange: exact split, counts read by the host, messages of exact size, standard local path ----
-int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], uint64_t out[2]) {
+int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], uint64_t out[2], bool balance) {
     hj_ctx *c = r->c;
     const uint32_t G = (uint32_t)r->world, me = (uint32_t)r->rank;
     hipStream_t cs = c->stream, ms = r->comm;
@@ -628,11 +629,52 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     LRET(r, dist_ensure(r, r->x_counts, (size_t)G * G * 8 + (size_t)G * 8));
     uint64_t recv_tot[2] = {0, 0};
     r->st.link_bytes = 0;
+    // Skew across GPUs: a heavy hitter cannot be split, but its shard need not share a GPU with an average load.  8 virtual
+    // shards per GPU; both relations are counted per virtual shard (keys only), the counts summed over the ranks, the shards
+    // dealt to GPUs longest-first by |R|+|S| (the reference's size-aware placement idea, partition-primitives.cu:307-468), and the
+    // split writes them in owner order so that every peer still gets ONE contiguous run per column.  Deterministic: every rank
+    // computes the same assignment from the same summed counts.
+    const uint32_t V = 8, ns = balance ? G * V : G;
+    std::vector<uint32_t> owner(ns), position(ns);
+    for (uint32_t v = 0; v < ns; v++) { owner[v] = v % G; position[v] = v; }
+    if (balance) {
+        if (ns > 512) return r->fail(HJ_EINVAL, "size-aware assignment needs world <= 64");
+        std::vector<uint64_t> cr(ns), csz(ns), tot(ns);
+        DRET(r, hj_shard_count(c, cols[0], n[0], ns, cr.data()));
+        DRET(r, hj_shard_count(c, cols[2], n[1], ns, csz.data()));
+        for (uint32_t v = 0; v < ns; v++) r->h_small[256 + v] = cr[v] + csz[v];
+        LRET(r, dist_ensure(r, r->x_bal, (size_t)ns * 8 * (G + 1)));
+        uint64_t *d_cnt = (uint64_t *)r->x_bal.p;
+        DCHK(r, hipMemcpyAsync(d_cnt, r->h_small + 256, (size_t)ns * 8, hipMemcpyHostToDevice, cs));
+        LRET(r, r->link->allreduce_sum_u64(d_cnt, ns, d_cnt + ns, cs, r->err));
+        DCHK(r, hipMemcpyAsync(tot.data(), d_cnt, (size_t)ns * 8, hipMemcpyDeviceToHost, cs));
+        DCHK(r, hipStreamSynchronize(cs));
+        std::vector<uint32_t> by(ns);
+        for (uint32_t v = 0; v < ns; v++) by[v] = v;
+        std::stable_sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) { return tot[a] > tot[b]; });
+        std::vector<uint64_t> load(G, 0);
+        for (uint32_t v : by) {
+            uint32_t g = 0;
+            for (uint32_t q = 1; q < G; q++) if (load[q] < load[g]) g = q;
+            owner[v] = g; load[g] += tot[v];
+        }
+        std::vector<uint32_t> order(ns);
+        for (uint32_t v = 0; v < ns; v++) order[v] = v;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return owner[a] < owner[b]; });
+        for (uint32_t pos = 0; pos < ns; pos++) position[order[pos]] = pos;
+    }
     for (int x = 0; x < 2; x++) {
         LRET(r, dist_ensure(r, r->x_send_k[x], (size_t)(n[x] + PAD) * 4)); LRET(r, dist_ensure(r, r->x_send_p[x], (size_t)(n[x] + PAD) * 4));
         std::vector<uint64_t> cnt(G, 0);
         // level-0 split, one contiguous run per owner; [sync]: the run lengths come back to the host
-        DRET(r, hj_shard_split(c, cols[2 * x], cols[2 * x + 1], n[x], G, (int32_t *)r->x_send_k[x].p, (int32_t *)r->x_send_p[x].p, cnt.data()));
+        if (!balance) {
+            DRET(r, hj_shard_split(c, cols[2 * x], cols[2 * x + 1], n[x], G, (int32_t *)r->x_send_k[x].p, (int32_t *)r->x_send_p[x].p, cnt.data()));
+        } else {
+            std::vector<uint64_t> per_pos(ns, 0);
+            DRET(r, hj_shard_split_ordered(c, cols[2 * x], cols[2 * x + 1], n[x], ns, position.data(), (int32_t *)r->x_send_k[x].p,
+                                           (int32_t *)r->x_send_p[x].p, per_pos.data()));
+            for (uint32_t v = 0; v < ns; v++) cnt[owner[v]] += per_pos[position[v]];
+        }
         // every rank's counts to every rank
         uint64_t *d_mine = (uint64_t *)r->x_counts.p + (size_t)G * G, *d_all = (uint64_t *)r->x_counts.p;
         DCHK(r, hipMemcpyAsync(d_mine, cnt.data(), (size_t)G * 8, hipMemcpyHostToDevice, cs));
@@ -682,7 +724,7 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     DCHK(r, hipStreamSynchronize(ms));
     out[0] = r->h_small[8]; out[1] = r->h_small[9];
     r->st.received[0] = recv_tot[0]; r->st.received[1] = recv_tot[1];
-    r->st.path = 1; r->st.slices = 1;
+    r->st.path = 1; r->st.slices = 1; r->st.balanced = balance ? 1 : 0;
     r->st.payload_bytes = r->st.link_bytes;
     return 0;
 }
@@ -703,15 +745,17 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
     // one small all-gather, read by the host before anything is planned (sizes decide the geometry on every rank)
     uint64_t *small = (uint64_t *)r->small.p;
     r->h_small[0] = nR; r->h_small[1] = nS; r->h_small[2] = (r->prefer_exact || r->cfg.exact_only) ? 1 : 0;
-    DCHK(r, hipMemcpyAsync(small + 16, r->h_small, 24, hipMemcpyHostToDevice, c->stream));
-    LRET(r, r->link->allgather(small + 16, small + 128, 24, c->stream, r->err));
-    DCHK(r, hipMemcpyAsync(r->h_small + 32, small + 128, (size_t)r->world * 24, hipMemcpyDeviceToHost, c->stream));
+    r->h_small[3] = (r->prefer_exact || r->cfg.balance_size) ? 1 : 0; // skew was seen on these columns (or the caller asks): size-aware shards
+    DCHK(r, hipMemcpyAsync(small + 16, r->h_small, 32, hipMemcpyHostToDevice, c->stream));
+    LRET(r, r->link->allgather(small + 16, small + 128, 32, c->stream, r->err));
+    DCHK(r, hipMemcpyAsync(r->h_small + 32, small + 128, (size_t)r->world * 32, hipMemcpyDeviceToHost, c->stream));
     DCHK(r, hipStreamSynchronize(c->stream));
     uint64_t nmax[2] = {0, 0};
-    bool exact = false;
+    bool exact = false, balance = false;
     for (int q = 0; q < r->world; q++) {
-        nmax[0] = std::max(nmax[0], r->h_small[32 + 3 * q]); nmax[1] = std::max(nmax[1], r->h_small[32 + 3 * q + 1]);
-        exact |= r->h_small[32 + 3 * q + 2] != 0;
+        nmax[0] = std::max(nmax[0], r->h_small[32 + 4 * q]); nmax[1] = std::max(nmax[1], r->h_small[32 + 4 * q + 1]);
+        exact |= r->h_small[32 + 4 * q + 2] != 0;
+        balance |= r->h_small[32 + 4 * q + 3] != 0;
     }
     uint64_t out[2] = {0, 0};
     int rc = 0;
@@ -721,11 +765,11 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
         rc = join_fast(r, cols, n, nmax, out, &flagged, &applicable);
         if (rc) return rc;
         if (applicable && !flagged) done = true;
-        if (flagged) r->prefer_exact = true; // every rank saw the same summed flags: everybody goes exact together
+        if (flagged) { r->prefer_exact = true; balance = true; } // every rank saw the same summed flags: everybody goes exact together
     }
     if (!done) {
         hj_invalidate_all(c);
-        rc = join_exact(r, cols, n, out);
+        rc = join_exact(r, cols, n, out, balance && r->world > 1);
         if (rc) return rc;
     }
     r->st.wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

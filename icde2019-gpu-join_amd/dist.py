@@ -233,7 +233,7 @@ def _stats_dict(s):
             "slot_capacity": [int(s.slot_capacity[0]), int(s.slot_capacity[1])],
             "split_ms": [float(s.split_ms[0]), float(s.split_ms[1])], "pass1_ms": [float(s.pass1_ms[0]), float(s.pass1_ms[1])],
             "pass2_join_ms": float(s.pass2_join_ms), "first_split_ms": float(s.first_split_ms), "last_pass1_ms": float(s.last_pass1_ms),
-            "wall_ms": float(s.wall_ms), "early_pass2_join_ms": float(s.early_pass2_join_ms), "probe_groups": int(s.probe_groups)}
+            "wall_ms": float(s.wall_ms), "early_pass2_join_ms": float(s.early_pass2_join_ms), "probe_groups": int(s.probe_groups), "balanced": bool(s.balanced)}
 
 
 class GroupJoin:
@@ -285,9 +285,9 @@ class GroupJoin:
         hj.close = lambda: None   # never destroyed from here
         return hj
 
-    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False):
+    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False):
         cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link), phantom_world=phantom_world,
-                                single_group=int(single_group))
+                                single_group=int(single_group), balance_size=int(balance_size))
         self._ck(self._L.hj_dist_configure(self._h, _C.byref(cfg)))
 
     def bind(self, rank, rel, keys, pays, n=None):
@@ -340,9 +340,9 @@ class RankJoin:
             self._L.hj_dist_rank_destroy(self._h)
             self._h = None
 
-    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False):
+    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False):
         cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link), phantom_world=phantom_world,
-                                single_group=int(single_group))
+                                single_group=int(single_group), balance_size=int(balance_size))
         self._ck(self._L.hj_dist_rank_configure(self._h, _C.byref(cfg)))
 
     def join(self, Rk, Rp, Sk, Sp, verify=False):

@@ -47,7 +47,10 @@ typedef struct hj_dist_config {
                              * job; bench.py models the link time beside them. */
     uint32_t single_group;  /* 1 (A/B): one pass 2 + one join per relation after its last slice, instead of joining the probe side's
                              * slices in two groups (all but the last under the exchange, the last in the tail) */
-    uint32_t reserved[3];
+    uint32_t balance_size;  /* 1: size-aware shard assignment on the exact path even when no skew has been seen (8 virtual shards per
+                             * GPU, dealt longest-first by |R|+|S|).  It is switched on by itself once a join on the same columns
+                             * overflowed a slot somewhere. */
+    uint32_t reserved[2];
 } hj_dist_config;
 
 typedef struct hj_dist_stats {
@@ -65,7 +68,8 @@ typedef struct hj_dist_stats {
     float wall_ms;             /* the whole hj_dist(_rank)_join call on this rank */
     float early_pass2_join_ms; /* pass 2 of the build side + pass 2 and build/probe of the probe side's earlier slices (under the exchange) */
     uint32_t probe_groups;
-    uint32_t reserved[6];
+    uint32_t balanced;         /* exact path: 1 if the shards were assigned to GPUs by size */
+    uint32_t reserved[5];
 } hj_dist_stats;
 
 /* ---- one process, G ranks ---- */

@@ -98,6 +98,14 @@ def test_skew_sends_every_rank_to_the_exact_path(world):
     assert all(s["path"] == "exact" for s in stats), stats
     stats, _ = _run([0] * world, R, S, dist_cfg=dict(exact_only=True))
     assert all(s["path"] == "exact" for s in stats)
+    # ... where the shards are dealt to the GPUs by size once skew has been seen (or on request): the heavy key's shard no longer
+    # shares a GPU with an average load.  Received tuples per rank, hash sharding vs size-aware:
+    tot = lambda st: [a + b for a, b in (s["received"] for s in st)]
+    imb = lambda st: max(tot(st)) / (sum(tot(st)) / len(st))
+    plain, _ = _run([0] * world, R, S, dist_cfg=dict(exact_only=True))
+    sized, _ = _run([0] * world, R, S, dist_cfg=dict(exact_only=True, balance_size=True))
+    assert all(s["balanced"] for s in sized) and not any(s["balanced"] for s in plain)
+    assert imb(sized) < imb(plain) and imb(sized) < 1.12, (tot(plain), tot(sized))
 
 
 def test_small_relations_take_the_exact_path():
