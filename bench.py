@@ -465,11 +465,23 @@ def main():
         from importlib import import_module
         dmod = import_module(pkg.__name__ + ".dist")
         c_impl = a.dist_impl == "c" and backend != "gloo" and a.balance == "hash"
+        dist_fallback = None
         if c_impl:
-            # the exchange behind the C ABI: C++ host code over RCCL (ncclCommInitRank with an id broadcast over the control plane)
-            dj = dmod.RankJoin(hj, rank, world)
-            dj.configure(slices=a.slices, exact_only=a.exact_only, phantom_world=a.phantom if world == 1 else 0, single_group=a.single_group)
-        else:
+            # the exchange behind the C ABI: C++ host code over RCCL (ncclCommInitRank with an id broadcast over the control plane).
+            # If the communicator cannot be made (every rank agrees on that through an all-reduce), the torch.distributed driver of
+            # rounds 1-2 takes over and the line says so.
+            try:
+                dj = dmod.RankJoin(hj, rank, world)
+                dj.configure(slices=a.slices, exact_only=a.exact_only, phantom_world=a.phantom if world == 1 else 0, single_group=a.single_group)
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                ok, dist_fallback = 0, repr(e)
+            t_ok = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if int(t_ok.item()) == 0:
+                c_impl, dj = False, None
+                dist_fallback = dist_fallback or "another rank could not create its hj_dist_rank"
+        if not c_impl:
             dj = dmod.ShardedJoin(hj, pkg, dev, balance=a.balance)
             dj.force_exchange = a.force_dist
 
@@ -522,6 +534,7 @@ def main():
         dist.all_gather(allrecv, recv)
         dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                      "driver": "hj_dist (C++ over RCCL, include/hj_dist.h)" if c_impl else "dist.py (torch.distributed)",
+                     "driver_fallback_reason": dist_fallback,
                      "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
         if c_impl:
             st = dj.stats()

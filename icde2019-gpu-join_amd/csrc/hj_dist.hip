@@ -261,7 +261,7 @@ struct hj_dist_rank {
     hj_ctx::Buf small;                   // device scratch: sizes, flags, results (u64 words)
     uint64_t *h_small = nullptr;         // pinned mirror
     std::vector<hipEvent_t> ev_split, ev_xchg, ev_t; // per (relation, slice); timing events
-    hipEvent_t ev_misc[4] = {};
+    hipEvent_t ev_misc[4] = {}, ev_coll[2] = {};
     hj_ctx::Buf x_send_k[2], x_send_p[2], x_recv_k[2], x_recv_p[2], x_counts, x_bal; // exact path
 
     int fail(int code, const char *fmt, ...) {
@@ -306,6 +306,7 @@ int rank_init(hj_dist_rank *r) {
     DCHK(r, hipMemset(r->small.p, 0, 16384));
     DCHK(r, hipHostMalloc((void **)&r->h_small, 16384, hipHostMallocDefault));
     for (auto &e : r->ev_misc) DCHK(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : r->ev_coll) DCHK(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
 
@@ -326,10 +327,25 @@ void rank_free(hj_dist_rank *r) {
     for (auto e : r->ev_xchg) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_t) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_misc) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_coll) if (e) (void)hipEventDestroy(e);
     r->link.reset();
     if (r->comm) (void)hipStreamDestroy(r->comm);
     if (r->own_ctx && r->c) hj_destroy(r->c);
     delete r;
+}
+
+// One communicator, one stream: EVERY collective of a rank is issued on its communication stream (RCCL serialises a
+// communicator's operations; issuing them from two streams leaves their relative order to the library).  Small collectives that
+// belong to the compute stream's program order are bracketed by events: comm waits for compute, compute waits for comm.
+int coll_begin(hj_dist_rank *r) {
+    DCHK(r, hipEventRecord(r->ev_coll[0], r->c->stream));
+    DCHK(r, hipStreamWaitEvent(r->comm, r->ev_coll[0], 0));
+    return 0;
+}
+int coll_end(hj_dist_rank *r) {
+    DCHK(r, hipEventRecord(r->ev_coll[1], r->comm));
+    DCHK(r, hipStreamWaitEvent(r->c->stream, r->ev_coll[1], 0));
+    return 0;
 }
 
 // Geometry of the sliced exchange of one relation: a function of (n_max over the ranks, G, K) and the radix bits only —
@@ -593,7 +609,9 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
     r->h_small[0] = m; r->h_small[1] = a; r->h_small[2] = c->h_scalars[8] & 0xFFFFFFFFu; r->h_small[3] = c->h_scalars[9] & 0xFFFFFFFFu;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 32, hipMemcpyHostToDevice, cs));
-    LRET(r, r->link->allreduce_sum_u64(small, 4, small + 64, cs, r->err));
+    LRET(r, coll_begin(r));
+    LRET(r, r->link->allreduce_sum_u64(small, 4, small + 64, ms, r->err));
+    LRET(r, coll_end(r));
     DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 48, hipMemcpyDeviceToHost, cs));
     DCHK(r, hipStreamSynchronize(cs));
     DCHK(r, hipStreamSynchronize(ms));
@@ -646,7 +664,9 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         LRET(r, dist_ensure(r, r->x_bal, (size_t)ns * 8 * (G + 1)));
         uint64_t *d_cnt = (uint64_t *)r->x_bal.p;
         DCHK(r, hipMemcpyAsync(d_cnt, r->h_small + 256, (size_t)ns * 8, hipMemcpyHostToDevice, cs));
-        LRET(r, r->link->allreduce_sum_u64(d_cnt, ns, d_cnt + ns, cs, r->err));
+        LRET(r, coll_begin(r));
+        LRET(r, r->link->allreduce_sum_u64(d_cnt, ns, d_cnt + ns, ms, r->err));
+        LRET(r, coll_end(r));
         DCHK(r, hipMemcpyAsync(tot.data(), d_cnt, (size_t)ns * 8, hipMemcpyDeviceToHost, cs));
         DCHK(r, hipStreamSynchronize(cs));
         std::vector<uint32_t> by(ns);
@@ -679,7 +699,9 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         uint64_t *d_mine = (uint64_t *)r->x_counts.p + (size_t)G * G, *d_all = (uint64_t *)r->x_counts.p;
         DCHK(r, hipMemcpyAsync(d_mine, cnt.data(), (size_t)G * 8, hipMemcpyHostToDevice, cs));
         DCHK(r, hipStreamSynchronize(cs)); // cnt is pageable
-        LRET(r, r->link->allgather(d_mine, d_all, (size_t)G * 8, cs, r->err));
+        LRET(r, coll_begin(r));
+        LRET(r, r->link->allgather(d_mine, d_all, (size_t)G * 8, ms, r->err));
+        LRET(r, coll_end(r));
         std::vector<uint64_t> all((size_t)G * G);
         DCHK(r, hipMemcpyAsync(all.data(), d_all, (size_t)G * G * 8, hipMemcpyDeviceToHost, cs));
         DCHK(r, hipStreamSynchronize(cs));
@@ -718,7 +740,9 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     DRET(r, hj_join_count(c, &m, &a));
     r->h_small[0] = m; r->h_small[1] = a;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 16, hipMemcpyHostToDevice, cs));
-    LRET(r, r->link->allreduce_sum_u64(small, 2, small + 64, cs, r->err));
+    LRET(r, coll_begin(r));
+    LRET(r, r->link->allreduce_sum_u64(small, 2, small + 64, ms, r->err));
+    LRET(r, coll_end(r));
     DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 16, hipMemcpyDeviceToHost, cs));
     DCHK(r, hipStreamSynchronize(cs));
     DCHK(r, hipStreamSynchronize(ms));
@@ -747,7 +771,9 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
     r->h_small[0] = nR; r->h_small[1] = nS; r->h_small[2] = (r->prefer_exact || r->cfg.exact_only) ? 1 : 0;
     r->h_small[3] = (r->prefer_exact || r->cfg.balance_size) ? 1 : 0; // skew was seen on these columns (or the caller asks): size-aware shards
     DCHK(r, hipMemcpyAsync(small + 16, r->h_small, 32, hipMemcpyHostToDevice, c->stream));
-    LRET(r, r->link->allgather(small + 16, small + 128, 32, c->stream, r->err));
+    LRET(r, coll_begin(r));
+    LRET(r, r->link->allgather(small + 16, small + 128, 32, r->comm, r->err));
+    LRET(r, coll_end(r));
     DCHK(r, hipMemcpyAsync(r->h_small + 32, small + 128, (size_t)r->world * 32, hipMemcpyDeviceToHost, c->stream));
     DCHK(r, hipStreamSynchronize(c->stream));
     uint64_t nmax[2] = {0, 0};

@@ -314,15 +314,15 @@ class RankJoin:
         self._L = _hjlib.lib()
         self.e = engine
         idbuf = (_C.c_ubyte * 128)()
-        if rank == 0:
-            rc = self._L.hj_dist_unique_id(_C.cast(idbuf, _C.c_void_p))
-            if rc:
-                raise _HJError(rc, "hj_dist_unique_id failed")
+        if rank == 0 and self._L.hj_dist_unique_id(_C.cast(idbuf, _C.c_void_p)):
+            idbuf = (_C.c_ubyte * 128)()          # all zeros = "rank 0 could not make an id": every rank raises below, nobody waits
         t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
         if dist.get_backend(group) == "nccl":
             t = t.cuda()
         dist.broadcast(t, src=0, group=group)
         raw = bytes(t.cpu().tolist())
+        if not any(raw):
+            raise _HJError(-2, "hj_dist_unique_id failed on rank 0 (librccl not loadable?)")
         idbuf = (_C.c_ubyte * 128).from_buffer_copy(raw)
         h = _C.c_void_p()
         rc = self._L.hj_dist_rank_create(_C.byref(h), engine._h, rank, world, _C.cast(idbuf, _C.c_void_p))
