@@ -319,7 +319,12 @@ def launch_ranks(n):
     sys.exit(0)
 
 
-PROBE_TARGET_FRAC = 0.60  # stated probe-phase target: k_join_count >= 60 % of the 8 TB/s roofline
+# Stated probe-phase targets (north_star: "probe-phase achieved HBM bandwidth >= a stated fraction of the MI355X roofline on
+# 2^30 x 2^30"): k_join_count's 8 B x (|R|+|S|) over its launch time, as a fraction of 8 TB/s.  Round 3 raises the 2^30 target
+# from 0.60 to 0.70 (measured 0.72-0.74) and states one for the smaller configurations, where the launch is too short to
+# amortise its ramp-up and drain (2^27: measured 0.60-0.63, target 0.68 NOT met).
+PROBE_TARGET_FRAC = 0.70
+PROBE_TARGET_FRAC_SMALL = 0.68   # below 2^30 tuples per relation
 
 
 def lib_sha256():
@@ -604,7 +609,8 @@ def main():
         frac = 8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
         probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
                  "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1), "frac_of_8TBs": round(frac, 4),
-                 "target_frac": PROBE_TARGET_FRAC, "meets_target": bool(frac >= PROBE_TARGET_FRAC)}
+                 "target_frac": PROBE_TARGET_FRAC if a.log2n >= 30 else PROBE_TARGET_FRAC_SMALL,
+                 "meets_target": bool(frac >= (PROBE_TARGET_FRAC if a.log2n >= 30 else PROBE_TARGET_FRAC_SMALL))}
 
     # the reference's phase split (hjcp.cu:938-940: Partition / Joins / Total throughput in MB/s of 2*(|R|+|S|)*4 bytes)
     phase = None

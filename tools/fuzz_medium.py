@@ -28,7 +28,7 @@ for seed in range(n_cases):
         R = np.sort(rng.integers(0, 1 << 22, nR)); S = np.sort(rng.integers(0, 1 << 22, nS))
     R, S = R.astype(np.int32), S.astype(np.int32)
     Pr = rng.integers(-2**31, 2**31 - 1, len(R)).astype(np.int32); Ps = rng.integers(-2**31, 2**31 - 1, len(S)).astype(np.int32)
-    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
     for exact in (False, True):
         with P.HashJoin(0) as hj:
             hj.configure(exact_only=exact)
@@ -41,9 +41,17 @@ for seed in range(n_cases):
                 badp, dg = hj.verify_partitions(rel, with_digests=True)
                 a, b, off = o.radix_partition(kk, pp, 0, bits)
                 okc = okc and badp == 0 and np.array_equal(dg, o.partition_digest(a, b, off))
-            got2 = hj.join()   # second run: what the first learned (skew) is in effect
+            got2 = hj.join()   # second run: what the first learned (skew: sampled capacities / exact passes) is in effect
+            lay2 = (hj.partition_layout(P.REL_R), hj.partition_layout(P.REL_S))
             okc = okc and got2 == (em, eagg)
+            if em <= 60_000_000:   # materialise in one probe on fresh partitions, order-independent digest against the oracle's
+                hj.partition(P.REL_R); hj.partition(P.REL_S)
+                k, pr, ps = hj.join_materialize(cap=em)
+                okc = okc and len(k) == em and o.triples_checksum(k, pr, ps) == echk
+            hj.configure(exact_only=exact, graph=True)
+            for _ in range(3):
+                okc = okc and hj.join() == (em, eagg)
         if not okc:
             bad += 1; print("FAIL seed", seed, "kind", kind, "exact", exact, got, (em, eagg), lay, flush=True)
-    print("seed %d kind %d nR %d nS %d matches %d layouts %s" % (seed, kind, len(R), len(S), em, lay), flush=True)
+    print("seed %d kind %d nR %d nS %d matches %d layouts %s -> %s" % (seed, kind, len(R), len(S), em, lay, lay2), flush=True)
 print("medium fuzz: %d cases, %d failures, %.0f s" % (n_cases, bad, time.time() - t0))
