@@ -29,6 +29,7 @@ for seed in range(n_cases):
     R, S = R.astype(np.int32), S.astype(np.int32)
     Pr = rng.integers(-2**31, 2**31 - 1, len(R)).astype(np.int32); Ps = rng.integers(-2**31, 2**31 - 1, len(S)).astype(np.int32)
     em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    lays = []
     for exact in (False, True):
         with P.HashJoin(0) as hj:
             hj.configure(exact_only=exact)
@@ -43,6 +44,7 @@ for seed in range(n_cases):
                 okc = okc and badp == 0 and np.array_equal(dg, o.partition_digest(a, b, off))
             got2 = hj.join()   # second run: what the first learned (skew: sampled capacities / exact passes) is in effect
             lay2 = (hj.partition_layout(P.REL_R), hj.partition_layout(P.REL_S))
+            lays.append((lay, lay2))
             okc = okc and got2 == (em, eagg)
             if em <= 60_000_000:   # materialise in one probe on fresh partitions, order-independent digest against the oracle's
                 hj.partition(P.REL_R); hj.partition(P.REL_S)
@@ -53,5 +55,6 @@ for seed in range(n_cases):
                 okc = okc and hj.join() == (em, eagg)
         if not okc:
             bad += 1; print("FAIL seed", seed, "kind", kind, "exact", exact, got, (em, eagg), lay, flush=True)
-    print("seed %d kind %d nR %d nS %d matches %d layouts %s -> %s" % (seed, kind, len(R), len(S), em, lay, lay2), flush=True)
+    print("seed %d kind %d nR %d nS %d matches %d layouts (first join -> second join) default %s -> %s, exact_only %s -> %s"
+          % (seed, kind, len(R), len(S), em, lays[0][0], lays[0][1], lays[1][0], lays[1][1]), flush=True)
 print("medium fuzz: %d cases, %d failures, %.0f s" % (n_cases, bad, time.time() - t0))
