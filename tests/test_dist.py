@@ -77,14 +77,12 @@ def test_shard_function_is_balanced_and_total():
 def test_sharded_join_rccl_world1():
     """The same driver on the real engine over RCCL (one rank: what a 1-GPU box can run): once on the world-1
     short cut (no split, no exchange), once with the split + exchange machinery forced."""
-    res = _run(1, {"HJ_DIST_GPU": "1"}, 29642)
-    assert res["got"] == res["expect"]
     res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_CHUNK": "4096"}, 29644)
-    assert res["got"] == res["expect"]
-    res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_BIG": "26"}, 29645)   # device-generated inputs
     assert res["got"] == res["expect"]
     res = _run(1, {"HJ_DIST_GPU": "1", "HJ_DIST_FORCE_EXCHANGE": "1", "HJ_DIST_BALANCE": "size", "HJ_DIST_SKEW": "1"}, 29647)
     assert res["got"] == res["expect"]
+    # (the world-1 short cut and device-generated 2^26 inputs ran here in round 2; every launch of a rank costs a torch import,
+    #  minutes on a cold box — the C++ driver's tests in test_dist_c.py cover those shapes in-process now)
 
 
 @pytest.mark.gpu
