@@ -1000,10 +1000,14 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
         a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
         a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
         a.out_cap = cap;
-        a.stage_cap = stage_capacity(c, tag16);
-        const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap);
+        // default: matches held in registers (k_join_mat_reg, 3 workgroups per CU); hj_config.lds_stage / HJ_STAGE_CAP select the
+        // kernel that stages them in an LDS block of that many matches (k_join_mat, 2 per CU)
+        const bool staged = c->cfg.lds_stage || c->stage_cap;
+        a.stage_cap = staged ? stage_capacity(c, tag16) : 0;
+        const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap) + 96;
         if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table + staging block of %zu bytes exceed 160 KiB", lds);
-        { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join_mat(c->stream, a, c->max_items, tag16)); }
+        { Timed t(c, "k_join_materialize");
+          HIPCHK(c, staged ? launch_join_mat(c->stream, a, c->max_items, tag16) : launch_join_mat_reg(c->stream, a, c->max_items, tag16)); }
         c->join_planned = false;
         RET(fetch_scalars(c)); // [sync]
         if (!c->redo_mask) break;

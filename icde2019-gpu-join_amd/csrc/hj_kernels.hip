@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     }
 }
 
-// ---- materialisation in ONE probe ----
+// ---- materialisation in ONE probe, matches staged in LDS (hj_config.lds_stage; the default is k_join_mat_reg below) ----
 // The reference's lead timed run writes its output in the same probe that finds the matches: matching lanes are ranked
 // by a ballot into a small shared-memory staging block and one reservation on a global counter is taken per flush
 // (join_partitioned_results, jp.cu:1228-1261, 1358-1388: 16 pairs per warp, one atomicAdd per 32 ints).  Same idea sized
@@ -1535,6 +1535,184 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
                 __syncthreads(); // workgroup-uniform: the staging block is free again only now
             }
             if (!again) break;
+        }
+        __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
+    }
+}
+
+// ---- materialisation in one probe, matches held in REGISTERS (the default) ----
+// k_join_mat above pays for its LDS staging block with occupancy (2 workgroups per CU instead of the count kernel's 3:
+// +0.8 ms at 2^30 x 2^30) and with a resumable probe loop.  Here nothing is staged in LDS: a lane keeps the up to 12 probe
+// tuples of a 6144-tuple sub-chunk (three 16-byte loads per column) in registers and, per ROUND, the slot of the next match of
+// each of them.  A round = every tuple advances to its next match (four chains in lockstep) -> ballots rank the matches inside the
+// wave, the eight wave totals meet in LDS -> ONE exact reservation on the output cursor for the whole workgroup -> every wave
+// writes its matches as runs of coalesced 4-byte-per-lane stores (key and probe payload from registers, build payload from the
+// table entry, whose link is also where the next round starts).  Unique build keys: one productive round per sub-chunk and one
+// that finds nothing; duplicates take as many rounds as the longest run of equal keys.  LDS = the table alone: 3 workgroups per CU.
+// tuples per lane per sub-chunk: two 16-byte groups + one 8-byte group = 10 -> 5120 probe tuples per sub-chunk: a ~4096-tuple
+// partition plus 8 sigma (4608) in ONE sub-chunk (one reservation), at 30 state registers instead of the 36 that three 16-byte
+// groups need (which spill at 80 VGPRs = three workgroups per CU)
+constexpr int MR_IT = 3;
+#define MR_NE(t) ((t) == 2 ? 2 : 4)
+constexpr uint32_t MR_SUB = 2 * JOIN_THREADS * 4 + JOIN_THREADS * 2;
+template <bool TAG16>
+__global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { // 6 waves per SIMD = three workgroups per CU: <= 85 VGPRs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t item = blockIdx.x;
+    if (item >= *a.n_items) return;
+    uint32_t *head = reinterpret_cast<uint32_t *>(smem);
+    uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
+    uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
+    const size_t tbl = ((size_t)a.nh * 4 + (size_t)a.cap * 8 + (TAG16 ? 0 : (size_t)a.cap * 2) + 15) & ~(size_t)15;
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + tbl); // [2][JOIN_WAVES] wave totals (round parity) | [16],[17] base lo/hi
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
+    const JoinItem it = a.items[item];
+    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
+    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
+    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
+    const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
+    constexpr uint32_t END = 0xFFFFu;
+
+    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
+        const uint64_t gb = b0 + bc;
+        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+        bool built = false;
+        uint32_t par = 0;
+        for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)MR_SUB) {
+            // the sub-chunk's probe tuples: issued first, so that they fly while the table is built
+            // the first 2048 tuples are requested before the table is built (they fly during the build); the rest behind it — the
+            // build keeps four 16-byte loads of its own in flight and the register file is what limits the workgroups per CU
+            int4 kk[MR_IT], pp[MR_IT];
+            auto tuple_index = [&](int t, int e) -> uint64_t { // group t < 2: 4 tuples per lane; group 2: 2 tuples per lane
+                return t < 2 ? s0 + (uint64_t)t * JOIN_THREADS * 4 + (uint64_t)tid * 4 + e : s0 + (uint64_t)2 * JOIN_THREADS * 4 + (uint64_t)tid * 2 + e;
+            };
+            auto fetch = [&](int t) {
+                const uint64_t i = tuple_index(t, 0);
+                kk[t] = make_int4(0, 0, 0, 0); pp[t] = make_int4(0, 0, 0, 0);
+                if (i >= q1) return;
+                if (t < 2) { kk[t] = load4(a.pk, i, a.p_nalloc); pp[t] = load4(a.pp, i, a.p_nalloc); }
+                else { // 8-byte group (i is even; the second element may lie beyond the allocation)
+                    kk[t].x = a.pk[i]; pp[t].x = a.pp[i];
+                    if (i + 1 < a.p_nalloc) { kk[t].y = a.pk[i + 1]; pp[t].y = a.pp[i + 1]; }
+                }
+            };
+            fetch(0);
+            if (built) {
+#pragma unroll
+                for (int t = 1; t < MR_IT; t++) fetch(t);
+            }
+            if (!built) {
+                for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 2) {
+                    int4 bkv[2], bpv[2]; // two loads per column in flight (the probe tuples are live in registers already)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                        if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                        if (i < gb + nbc) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const uint64_t idx = i + e;
+                                if (idx >= gb && idx < gb + nbc) {
+                                    const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                                    const uint32_t old = atomicExch(&head[hidx(key)], slot);
+                                    if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                                    else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                built = true;
+#pragma unroll
+                for (int t = 1; t < MR_IT; t++) fetch(t);
+            }
+            // chain position of tuple j (END: exhausted): 16 bits each, two per register; mm bit j: tuple j sits ON a match that is
+            // not written yet.  (Packed: the register file, not LDS, is what limits this kernel to three workgroups per CU.)
+            uint32_t sp2[MR_IT * 2] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mm = 0;
+            auto getp = [&](int j) -> uint32_t { return (j & 1) ? sp2[j >> 1] >> 16 : sp2[j >> 1] & 0xFFFFu; };
+            auto setp = [&](int j, uint32_t v) { sp2[j >> 1] = (j & 1) ? ((sp2[j >> 1] & 0xFFFFu) | (v << 16)) : ((sp2[j >> 1] & 0xFFFF0000u) | v); };
+#pragma unroll
+            for (int t = 0; t < MR_IT; t++)
+#pragma unroll
+                for (int e = 0; e < MR_NE(t); e++) {
+                    const uint64_t idx = tuple_index(t, e);
+                    const bool valid = idx >= q0 && idx < q1;
+                    setp(t * 4 + e, (valid ? head[hidx((uint32_t)elem(kk[t], e))] : 0xFFFFFFFFu) & END);
+                }
+            for (;; par ^= 1u) { // rounds
+                // every tuple advances to its next match; the chains of a load group in lockstep
+#pragma unroll
+                for (int t = 0; t < MR_IT; t++) {
+                    for (;;) {
+                        bool walking = false;
+#pragma unroll
+                        for (int e = 0; e < MR_NE(t); e++) {
+                            const int j = t * 4 + e;
+                            const uint32_t s_ = getp(j);
+                            if (s_ != END && !((mm >> j) & 1u)) {
+                                const uint32_t key = (uint32_t)elem(kk[t], e);
+                                const uint2 en = ent[s_];
+                                const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
+                                if (eq) mm |= 1u << j;
+                                else {
+                                    const uint32_t nx = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[s_];
+                                    setp(j, nx);
+                                    walking |= nx != END;
+                                }
+                            }
+                        }
+                        if (!walking) break;
+                    }
+                }
+                // wave total -> LDS; every thread then knows its wave's offset and the workgroup's total
+                uint32_t wtot = (uint32_t)__popc(mm);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wtot += __shfl_xor(wtot, o, 64);
+                if (ln == 0) red[par * JOIN_WAVES + wave] = wtot;
+                __syncthreads();
+                uint32_t T = 0, wbase = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < (uint32_t)JOIN_WAVES; w++) { const uint32_t v = red[par * JOIN_WAVES + w]; wbase += w < wave ? v : 0u; T += v; }
+                if (!T) break; // workgroup-uniform: nobody found anything this round
+                if (tid == 0) {
+                    const unsigned long long base = atomicAdd(a.out_cursor, (unsigned long long)T); // ONE reservation per round
+                    red[16] = (uint32_t)base; red[17] = (uint32_t)(base >> 32);
+                }
+                __syncthreads();
+                uint64_t o = ((uint64_t)red[16] | ((uint64_t)red[17] << 32)) + wbase;
+#pragma unroll
+                for (int t = 0; t < MR_IT; t++)
+#pragma unroll
+                    for (int e = 0; e < MR_NE(t); e++) {
+                        const int j = t * 4 + e;
+                        const bool m = (mm >> j) & 1u;
+                        const uint64_t mask = __ballot(m);
+                        if (m) {
+                            const uint32_t slot = getp(j);
+                            const uint2 en = ent[slot];
+                            const uint64_t at = o + (uint64_t)__popcll(mask & lt_mask);
+                            if (at < a.out_cap) {
+                                a.out_key[at] = elem(kk[t], e);
+                                a.out_bpay[at] = (int32_t)en.y;
+                                a.out_ppay[at] = elem(pp[t], e);
+                            }
+                            setp(j, TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[slot]); // the next round starts behind the match
+                        }
+                        o += (uint64_t)__popcll(mask);
+                    }
+                mm = 0;
+                // red[16..17] are rewritten only behind the next round's first barrier; the totals alternate by parity
+            }
+            par ^= 1u;
         }
         __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
     }
@@ -1829,6 +2007,29 @@ hipError_t join_set_lds_limit(int device, size_t bytes) {
 size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16, uint32_t stage_cap) {
     const size_t tbl = ((size_t)nh * 4 + (size_t)cap * 8 + (tag16 ? 0 : (size_t)cap * 2) + 15) & ~(size_t)15;
     return tbl + (size_t)stage_cap * 4 + (((size_t)stage_cap * 2 + 15) & ~(size_t)15) + 32;
+}
+
+hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16) {
+    static size_t limit[64] = {};
+    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, 0) + 96;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mutex);
+        if (dev < 0 || dev >= 64 || lds > limit[dev]) {
+            const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat_reg<true>), reinterpret_cast<const void *>(&k_join_mat_reg<false>)};
+            for (const void *f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            if (dev >= 0 && dev < 64) limit[dev] = lds;
+        }
+    }
+    dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
+    if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_join_mat_reg<false>), g, b, lds, st, a);
+    HJ_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_join_mat(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16) {

@@ -60,8 +60,10 @@ typedef struct hj_config {
                             * reservation on a global output cursor per flush, as join_partitioned_results jp.cu:1228-1261 does
                             * per warp).  1: count, scan, second probe writing at the scanned positions — no output atomics, the
                             * order of the output is a function of the partitions alone. */
-    uint32_t lds_stage;    /* one-probe materialisation: matches staged in LDS per flush (one output reservation each);
-                            * 0 = what fits next to the hash table at two workgroups per CU (~4700) */
+    uint32_t lds_stage;    /* one-probe materialisation: 0 = matches are held in registers (10 probe tuples per lane, one output
+                            * reservation per round of a 5120-tuple sub-chunk; LDS holds the table alone: 3 workgroups per CU).
+                            * N in [64, 16384] = the variant that stages matches in an LDS block of N matches (one reservation per
+                            * flush; 2 workgroups per CU; measured 20 % slower at 2^30 x 2^30) */
     uint32_t graph;        /* 1: hj_join replays the whole step (both partition passes, plan, build+probe, result copy) from a
                             * captured hipGraph — one host call per step instead of ~14-22 launches; pays below ~2^24 tuples,
                             * where a step is bound by the host's launch rate.  The first call on a binding runs eagerly, the second

@@ -55,11 +55,13 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
             hj.partition(P.REL_R)
             hj.partition(P.REL_S)
             check(*hj.join_materialize(cap=em), "one probe, no count")
-            # ... with a staging block so small that every wave stops and resumes many times ...
-            hj.configure(**dict(cfg or {}, lds_stage=64))
-            hj.partition(P.REL_R)
-            hj.partition(P.REL_S)
-            check(*hj.join_materialize(cap=em), "one probe, 64-match staging block")
+            # ... with the LDS-staged variant of the kernel: a block of the default size, and one so small that every wave stops
+            # and resumes many times ...
+            for stage in (4608, 64):
+                hj.configure(**dict(cfg or {}, lds_stage=stage))
+                hj.partition(P.REL_R)
+                hj.partition(P.REL_S)
+                check(*hj.join_materialize(cap=em), "one probe, %d-match LDS staging block" % stage)
             # ... and the two-probe path (count, scan, second probe at scanned positions)
             hj.configure(**dict(cfg or {}, materialize_two_pass=True))
             assert hj.join() == (em, eagg)
