@@ -795,6 +795,7 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
+    if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
     if (const char *te = getenv("HJ_TAG_EXTRA")) c->tag_extra_max = std::max(0, std::min(2, atoi(te)));
     *out = c;
     return HJ_OK;
@@ -1045,11 +1046,14 @@ namespace {
 // by the kernels.  The graph is tied to everything its launches captured: the bound columns and sizes, the configuration, the
 // stream, kernel events off, and the partition path each relation takes.  The first call on a binding runs eagerly (it
 // allocates and learns whether a relation is skewed), the second captures, later ones replay.
-// Both relations' partition passes.  Small inputs (a step is a chain of ~20 short dependent kernels there): S's passes go to a
-// second stream and run beside R's — the two chains overlap, the join waits for both.  Large inputs stay on one stream (every
-// pass kernel fills the chip on its own).  Works the same under stream capture (fork / join by events).
+// Both relations' partition passes.  S's passes go to a second stream and run beside R's; the join waits for both.  At small
+// sizes the two chains of short dependent kernels overlap (2^20: 0.125 -> 0.103 ms); at large sizes every pass kernel is one or
+// two waves of 1-per-CU workgroups, and the other relation's kernel fills the CUs that one kernel's tail leaves idle (same-box
+// A/B, profiles/r3_fork_ab.txt: 2^26 -2 %, 2^27 -2.5...-5 %, 2^28 -1.2 %, 2^30 -1...-3.6 %).  HJ_FORK_LOG2 sets the largest
+// |R|+|S| (log2) that forks.  Not with kernel events on (the instrumented steps time serial kernels).  Works the same under
+// stream capture (fork / join by events).
 int partition_both(hj_ctx *c) {
-    const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << 25) && c->events == 0;
+    const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->fork_log2) && c->events == 0;
     if (!fork) {
         RET(partition_rel(c, HJ_REL_R));
         return partition_rel(c, HJ_REL_S);
