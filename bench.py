@@ -622,8 +622,7 @@ def main():
             hj.bind_device(pkg.REL_S, Sk, Sp)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            hj.partition(pkg.REL_R)
-            hj.partition(pkg.REL_S)
+            hj.partition_both()
             hj.sync()
             t3 = time.perf_counter()
             assert hj.join_count()[0] == expect
@@ -646,8 +645,7 @@ def main():
         def mat_step():
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, Sk, Sp)
-            hj.partition(pkg.REL_R)
-            hj.partition(pkg.REL_S)
+            hj.partition_both()
             return hj.join_materialize_into(ok, opr, ops, cap)
 
         assert mat_step() == expect   # warm-up (first touch of the output columns)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "hj_load_host": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64, C.c_int]),
     "hj_bind_device": (C.c_int, [vp, C.c_int, vp, vp, C.c_uint64]),
     "hj_partition": (C.c_int, [vp, C.c_int]),
+    "hj_partition_both": (C.c_int, [vp]),
     "hj_shard_count": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, u64p]),
     "hj_shard_split_ordered": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), vp, vp, u64p]),
     "hj_enable_timings": (C.c_int, [vp, C.c_int]),

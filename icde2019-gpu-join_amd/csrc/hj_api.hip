@@ -1134,6 +1134,12 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
 
 extern "C" {
 
+int hj_partition_both(hj_ctx *c) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return partition_both(c);
+}
+
 int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));

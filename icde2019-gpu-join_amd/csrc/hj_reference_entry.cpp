@@ -92,8 +92,7 @@ int run(args *in) {
 
         // ---- run 1: with materialisation (hjcp.cu:881-940) ----
         double t1 = cpu_seconds();
-        if ((rc = hj_partition(ctx, HJ_REL_R))) break;
-        if ((rc = hj_partition(ctx, HJ_REL_S))) break;
+        if ((rc = hj_partition_both(ctx))) break; // prepare_Relation_payload x 2 (hjcp.cu:883-889), the two relations side by side
         if ((rc = hj_sync(ctx))) break;
         double t3 = cpu_seconds();
         if ((rc = hj_join_materialize(ctx, out[0], out[1], out[2], matches, &nout))) break;
@@ -107,8 +106,7 @@ int run(args *in) {
 
         // ---- run 2: count only (hjcp.cu:944-991) ----
         t1 = cpu_seconds();
-        if ((rc = hj_partition(ctx, HJ_REL_R))) break;
-        if ((rc = hj_partition(ctx, HJ_REL_S))) break;
+        if ((rc = hj_partition_both(ctx))) break; // prepare_Relation_payload x 2 (hjcp.cu:883-889), the two relations side by side
         if ((rc = hj_sync(ctx))) break;
         t3 = cpu_seconds();
         if ((rc = hj_join_count(ctx, &matches, &agg))) break;

@@ -116,6 +116,10 @@ class HashJoin:
     def partition(self, rel):
         self._ck(self._L.hj_partition(self._h, rel))
 
+    def partition_both(self):
+        """hj_partition(R) + hj_partition(S), S's passes on a second stream beside R's."""
+        self._ck(self._L.hj_partition_both(self._h))
+
     def partition_layout(self, rel):
         """'slotted' if the histogram-free passes produced the partitions, 'sampled' if their variable-capacity form for a
         skewed probe side did, 'exact' if the histogram passes did."""

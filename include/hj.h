@@ -111,6 +111,10 @@ int hj_bind_device(hj_ctx *ctx, int rel, const int32_t *d_keys, const int32_t *d
  * fixed-capacity slots from the histogram-free passes or gap-free ranges from the exact passes (hj_config.exact_only);
  * the join reads either, hj_get_partitions always hands out the gap-free form. */
 int hj_partition(hj_ctx *ctx, int rel);
+/* hj_partition(R) and hj_partition(S) in one call: S's passes are enqueued on a second stream of the context and run beside R's
+ * (every pass kernel is one or two waves of one-per-CU workgroups: the other relation's kernel fills the CUs that a kernel's tail
+ * leaves idle, -1...-5 % per step); the context's stream waits for both (async).  hj_join does this itself. */
+int hj_partition_both(hj_ctx *ctx);
 /* Build+probe every partition pair, count only (join_partitioned_aggregate jp.cu:885-1095).
  * matches = |R ⋈ S|; agg = sum payR*payS mod 2^64 (low 32 bits = the reference's int32 aggregate,
  * jp.cu:1073,1092).  Either pointer may be NULL.  [sync] */

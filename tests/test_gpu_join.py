@@ -51,9 +51,8 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
 
             # materialisation in ONE probe (the default): behind a count (item list reused) ...
             check(*hj.join_materialize(), "one probe, after a count")
-            # ... on fresh partitions with no count before it (the timed shape: partition, partition, materialise) ...
-            hj.partition(P.REL_R)
-            hj.partition(P.REL_S)
+            # ... on fresh partitions with no count before it (the timed shape: partition both, materialise) ...
+            hj.partition_both()
             check(*hj.join_materialize(cap=em), "one probe, no count")
             # ... with the LDS-staged variant of the kernel: a block of the default size, and one so small that every wave stops
             # and resumes many times ...
