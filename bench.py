@@ -589,7 +589,10 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": (src + " (rocprofv3 --pmc passes of this command)") if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch}
+                "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch,
+                "measured": "instrumented steps: kernel events on, the passes of R and S on ONE stream (a kernel alone on the chip); the timed "
+                            "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
+                            "committed kernel stats are taken with HJ_FORK_LOG2=0)"}
         if not a.no_extras:
             # on-box ceilings, same run: what HBM gives this access pattern with no partitioning work at all
             tk, tp = torch.empty_like(Rk), torch.empty_like(Rp)

@@ -22,10 +22,15 @@ python tools/step_vs_size.py 2>/dev/null > $OUT/step_vs_size.txt
 python tools/handoff_gate.py 2>/dev/null > $OUT/handoff_gate.txt
 for l in 24 27 30; do python bench.py --workload baselines --log2n $l --steps 3 --warmup 1 2>/dev/null; done > $OUT/bench_baselines.json
 cd /tmp
+# per-kernel durations: the passes of R and S serialised (HJ_FORK_LOG2=0), as in bench.py's instrumented steps — with the two
+# relations' kernels overlapped on two streams (the timed steps) a kernel's start-to-end time includes the other kernel's share
+# of the chip.  The variable is exported here: no env/sh hop between rocprofv3 and python3.
+export HJ_FORK_LOG2=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats30 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats30.log 2>&1; echo "stats30 rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats27 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --log2n 27 --no-cpu-baseline > $OUT/stats27.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python3 $ROOT/bench.py --workload zipf --steps 5 --warmup 2 --no-cpu-baseline > $OUT/statszipf.log 2>&1
 for d in stats30 stats27 statszipf; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; done
+unset HJ_FORK_LOG2
 cd $ROOT
 tools/pmc_collect.sh r3prof/pmc30
 tools/pmc_collect.sh r3prof/pmc30_mat --with-materialize
