@@ -370,7 +370,7 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
         if (posA >= ((uint64_t)1 << 32) - ((uint64_t)1 << 20)) return 1; // does not fit 32-bit positions: not plannable
     }
     // pass 2
-    std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * 512, 0xFFFFu), heavy2(P1, 0), wg, rpart;
+    std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * 512, 0xFFFFu), heavy2(P1, 0), wg, rpart, pr0(NP), pnr(NP);
     uint64_t posB = 0;
     bool any_heavy = false, any_light = false;
     // parents in the order their workgroups should start: the slow ones (one dominant child: wave-aggregated ranking) and the
@@ -408,6 +408,7 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             W += cap;
         }
         for (uint32_t i = 0; i < 512; i++) own2[(size_t)d * 512 + i] = own[i];
+        for (uint32_t q = 0; q < P2; q++) { pr0[d * P2 + q] = (uint32_t)(wg.size() / 4) * P2 + q; pnr[d * P2 + q] = J; } // the partition's ranges: stride P2
         for (uint32_t j = 0; j < J; j++) {
             const uint32_t s0 = (uint32_t)((uint64_t)j * nspans / J), s1 = (uint32_t)((uint64_t)(j + 1) * nspans / J);
             wg.push_back(d); wg.push_back(s0); wg.push_back(s1 - s0); wg.push_back((uint32_t)posB);
@@ -421,13 +422,13 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     std::vector<uint32_t> tab;
     auto put = [&](const std::vector<uint32_t> &v) { while (tab.size() & 3) tab.push_back(0); const size_t at = tab.size(); tab.insert(tab.end(), v.begin(), v.end()); return at; };
     const size_t o_vb1 = put(vbase1), o_vc1 = put(vcap1), o_lt1 = put(lt1), o_ow1 = put(own1), o_h1 = put(std::vector<uint32_t>{heavy1});
-    const size_t o_cb2 = put(cbase2), o_c2 = put(cap2), o_lt2 = put(lt2), o_ow2 = put(own2), o_h2 = put(heavy2), o_wg = put(wg), o_rp = put(rpart);
+    const size_t o_cb2 = put(cbase2), o_c2 = put(cap2), o_lt2 = put(lt2), o_ow2 = put(own2), o_h2 = put(heavy2), o_wg = put(wg), o_rp = put(rpart), o_r0 = put(pr0), o_nr = put(pnr);
     RET(ensure(c, sp.tab, tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(sp.tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // tab is pageable
     const uint32_t *T = (const uint32_t *)sp.tab.p;
     sp.vbase1 = T + o_vb1; sp.vcap1 = T + o_vc1; sp.lt1 = T + o_lt1; sp.own1 = T + o_ow1; sp.heavy1_d = T + o_h1;
-    sp.cbase2 = T + o_cb2; sp.cap2 = T + o_c2; sp.lt2 = T + o_lt2; sp.own2 = T + o_ow2; sp.heavy2 = T + o_h2; sp.wg2 = T + o_wg; sp.rpart = T + o_rp;
+    sp.cbase2 = T + o_cb2; sp.cap2 = T + o_c2; sp.lt2 = T + o_lt2; sp.own2 = T + o_ow2; sp.heavy2 = T + o_h2; sp.wg2 = T + o_wg; sp.rpart = T + o_rp; sp.pr0 = T + o_r0; sp.pnr = T + o_nr;
     sp.n = R.n; sp.b1 = b1; sp.b2 = b2; sp.span = (uint32_t)span; sp.nspans = (uint32_t)nspans; sp.nwg2 = nwg; sp.nranges = nwg * P2;
     sp.sizeA = posA; sp.sizeB = posB; sp.heavy1 = heavy1 != 0; sp.any_heavy2 = any_heavy; sp.any_light2 = any_light; sp.sample_size = ns;
     sp.valid = true;
@@ -469,7 +470,7 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     vb.vbase = sp.cbase2; vb.vcap = sp.cap2; vb.lt = sp.lt2; vb.own = sp.own2; vb.heavy = sp.heavy2; vb.wg = reinterpret_cast<const uint4 *>(sp.wg2);
     { Timed t(c, "k_part2_var"); HIPCHK(c, launch_part2_var(st, fb, vb, sp.nwg2, sp.any_heavy2, sp.any_light2)); }
     R.nparts = P1 * P2;
-    R.nranges = sp.nranges; R.rpart = sp.rpart;
+    R.nranges = sp.nranges; R.rpart = sp.rpart; R.pr0 = sp.pr0; R.pnr = sp.pnr; R.rstride = P2;
     R.part_k = (const int32_t *)R.b_k.p; R.part_p = (const int32_t *)R.b_p.p;
     R.part_beg = (const uint64_t *)sp.rbeg.p; R.part_end = (const uint64_t *)sp.rend.p;
     R.part_off = nullptr;
@@ -499,7 +500,7 @@ int partition_rel(hj_ctx *c, int r) {
     R.fast_tried = false;
     R.flag_known_good = false;
     R.part_off = nullptr;
-    R.sampled = false; R.rpart = nullptr;
+    R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
     // known to be skewed, and on the probe side (the build side needs one range per partition): the sampled path
     if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 15 && c->fast_path && !c->cfg.exact_only && r != c->build &&
         R.n >= ((uint64_t)1 << 20)) {
@@ -616,14 +617,17 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
                     B.pb1, B.pb2, Pb.pb1, Pb.pb2);
     hipStream_t st = c->stream;
     if (B.sampled) return fail(c, HJ_EHIP, "internal: the build side must have one range per partition");
-    const uint32_t nparts = Pb.nranges; // probe RANGES (== partitions unless the probe side took the sampled path)
+    // sampled probe side: several ranges per partition.  Whole ranges are packed into list items (one table build for all of them);
+    // the LDS-staging kernel does not take list items: one item list per range there
+    const bool lists = Pb.sampled && Pb.pr0 && !(c->cfg.lds_stage || c->stage_cap);
+    const uint32_t nparts = lists ? Pb.nparts : Pb.nranges; // planning threads: partitions, or probe RANGES (== partitions unless sampled)
     const uint32_t rbits = B.pb1 + B.pb2;
     // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2).  At 14 and 15 radix bits the 1-2 key bits a 16-bit tag
     // cannot hold select the upper part of the bucket index instead (k_join: hidx), which keeps the comparison exact and the 8-byte
     // table entries; below that the table stores full keys.
     const uint32_t tag_extra = (32 - rbits) > 16 ? (32 - rbits) - 16 : 0;
     tag16 = tag_extra <= (uint32_t)c->tag_extra_max && c->nh >= 16 && (tag_extra == 0 || c->cap < 8192);
-    const uint64_t max_items64 = (uint64_t)nparts + Pb.n / c->chunk + 1;
+    const uint64_t max_items64 = (uint64_t)Pb.nranges + Pb.n / c->chunk + 1;
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
     RET(ensure(c, c->items_cnt, (size_t)nparts * 4));
@@ -644,14 +648,15 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     a = JoinArgs{};
     a.bk = B.part_k; a.bp = B.part_p; a.bbeg = B.part_beg; a.bend = B.part_end; a.b_nalloc = B.n_alloc;
     a.pk = Pb.part_k; a.pp = Pb.part_p; a.pbeg = Pb.part_beg; a.pend = Pb.part_end; a.p_nalloc = Pb.n_alloc;
-    a.rpart = Pb.sampled ? Pb.rpart : nullptr;
+    a.rpart = Pb.sampled && !lists ? Pb.rpart : nullptr;
+    if (lists) { a.pr0 = Pb.pr0; a.pnr = Pb.pnr; a.rstride = Pb.rstride; }
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk; a.tag_extra = tag16 ? tag_extra : 0;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
-    if (nparts <= 16384 && !a.rpart) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
+    if (nparts <= 16384 && !Pb.sampled) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
         Timed t(c, "k_join_plan");
         HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, sc + 10, sc + 0));
     } else {
@@ -991,7 +996,8 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
     for (int attempt = 0; attempt < 3; attempt++) {
         JoinArgs a;
         bool tag16;
-        if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
+        const bool staged = c->cfg.lds_stage || c->stage_cap;
+        if (c->join_planned && !(staged && c->last_args.pr0)) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
             a = c->last_args; tag16 = c->last_tag16;
             HIPCHK(c, hipMemsetAsync((uint64_t *)c->scalars.p + 10, 0, 8, c->stream));
         } else {
@@ -1003,7 +1009,6 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
         a.out_cap = cap;
         // default: matches held in registers (k_join_mat_reg, 3 workgroups per CU); hj_config.lds_stage / HJ_STAGE_CAP select the
         // kernel that stages them in an LDS block of that many matches (k_join_mat, 2 per CU)
-        const bool staged = c->cfg.lds_stage || c->stage_cap;
         a.stage_cap = staged ? stage_capacity(c, tag16) : 0;
         const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap) + 96;
         if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table + staging block of %zu bytes exceed 160 KiB", lds);

@@ -52,6 +52,8 @@ struct Rel {
     bool force_exact = false;     // introspection calls want one gap-free range per partition
     uint32_t nranges = 0;         // ranges of the partitioned relation (== nparts unless sampled)
     const uint32_t *rpart = nullptr; // sampled: partition id of every range
+    const uint32_t *pr0 = nullptr, *pnr = nullptr; // ... and per partition: first range, number of ranges (stride rstride)
+    uint32_t rstride = 0;
     struct Sampled {
         bool valid = false;
         uint64_t n = 0;
@@ -61,7 +63,7 @@ struct Rel {
         uint64_t sample_size = 0;
         Buf tab;                  // every table below, one allocation
         const uint32_t *vbase1 = nullptr, *vcap1 = nullptr, *lt1 = nullptr, *own1 = nullptr, *heavy1_d = nullptr;
-        const uint32_t *cbase2 = nullptr, *cap2 = nullptr, *lt2 = nullptr, *own2 = nullptr, *heavy2 = nullptr, *wg2 = nullptr, *rpart = nullptr;
+        const uint32_t *cbase2 = nullptr, *cap2 = nullptr, *lt2 = nullptr, *own2 = nullptr, *heavy2 = nullptr, *wg2 = nullptr, *rpart = nullptr, *pr0 = nullptr, *pnr = nullptr;
         Buf rbeg, rend;           // ranges written by pass 2 [nranges]
     } sp;
 };

@@ -64,10 +64,13 @@ struct FastArgs {
 };
 
 // one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
+// p bit 31 (JOIN_ITEM_LIST): the probe side of the item is a LIST of whole ranges — q0 = first range, q1 = number of ranges,
+// range j = q0 + j * JoinArgs.rstride — that share the one table build
 struct JoinItem {
     uint64_t b0, q0, q1;
     uint32_t nb, p;
 };
+constexpr uint32_t JOIN_ITEM_LIST = 0x80000000u;
 
 struct JoinArgs {
     const int32_t *bk, *bp;  // build side, partitioned
@@ -78,6 +81,8 @@ struct JoinArgs {
     uint64_t p_nalloc;
     const uint32_t *bflag, *pflag; // overflow flags of histogram-free partitions (nullptr: ranges known good)
     const uint32_t *rpart;   // probe side given as RANGES (sampled path): partition id of range i; nullptr: range i = partition i
+    const uint32_t *pr0, *pnr; // ... or PARTITIONS with a list of ranges each: first range, number of ranges (stride rstride)
+    uint32_t rstride;
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;

@@ -1083,16 +1083,48 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, 
 // bflag / pflag: overflow flags of relations whose histogram-free passes were queued (nullptr otherwise).  A raised
 // flag means the ranges are not valid: no items, the join kernels then do nothing and the host redoes the relation.
 // Thread 0 also zeroes the two result accumulators of k_sum2 and the output cursor of k_join_mat.
+// Probe side in RANGES with several ranges per partition (sampled path): the ranges of partition p are r0[p] + j * stride,
+// j < nr[p].  Whole ranges are packed into LIST items of <= chunk probe tuples (the table of the partition is built once for all
+// of them); a range longer than a chunk is cut into chunk items as above.  emit(index, list, q0, q1): list items carry
+// (first range, number of ranges) in (q0, q1).
+template <class F>
+__device__ inline uint32_t walk_ranges(const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend, uint32_t r0, uint32_t nr,
+                                       uint32_t stride, uint32_t chunk, F emit) {
+    uint32_t items = 0, run0 = 0, runlen = 0;
+    uint64_t acc = 0;
+    for (uint32_t j = 0; j < nr; j++) {
+        const uint32_t r = r0 + j * stride;
+        const uint64_t b = pbeg[r], e = pend[r], len = e - b;
+        if (len > chunk) {
+            if (runlen && acc) { emit(items, true, (uint64_t)run0, (uint64_t)runlen); items++; }
+            runlen = 0; acc = 0;
+            for (uint64_t q = b; q < e; q += chunk) { emit(items, false, q, q + chunk < e ? q + chunk : e); items++; }
+        } else {
+            if (acc + len > chunk) { emit(items, true, (uint64_t)run0, (uint64_t)runlen); items++; runlen = 0; acc = 0; }
+            if (!runlen) run0 = r;
+            runlen++; acc += len;
+        }
+    }
+    if (runlen && acc) { emit(items, true, (uint64_t)run0, (uint64_t)runlen); items++; }
+    return items;
+}
+
 __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
                             const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                             uint32_t nparts, uint32_t chunk, uint32_t *__restrict__ items_cnt,
                             const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
-                            uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor, const uint32_t *__restrict__ rpart) {
-    // nparts = probe RANGES; the build partition of range i is rpart[i] (sampled path) or i
+                            uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor, const uint32_t *__restrict__ rpart,
+                            const uint32_t *__restrict__ pr0, const uint32_t *__restrict__ pnr, uint32_t rstride) {
+    // nparts = probe RANGES; the build partition of range i is rpart[i] (sampled path, one item list per range) or i.
+    // pr0 != nullptr: nparts = PARTITIONS, each with a list of ranges (walk_ranges)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
     if (i >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[i] = 0; return; }
+    if (pr0) {
+        items_cnt[i] = bend[i] != bbeg[i] ? walk_ranges(pbeg, pend, pr0[i], pnr[i], rstride, chunk, [](uint32_t, bool, uint64_t, uint64_t) {}) : 0u;
+        return;
+    }
     const uint32_t p = rpart ? rpart[i] : i;
     uint64_t nb = bend[p] - bbeg[p], np = pend[i] - pbeg[i];
     items_cnt[i] = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
@@ -1103,14 +1135,26 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
                               const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
                               uint32_t nparts, uint32_t chunk, const uint32_t *__restrict__ items_scanned,
                               const uint64_t *__restrict__ chunk_prefix, JoinItem *__restrict__ items,
-                              const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag, const uint32_t *__restrict__ rpart) {
+                              const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag, const uint32_t *__restrict__ rpart,
+                              const uint32_t *__restrict__ pr0, const uint32_t *__restrict__ pnr, uint32_t rstride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) return; // ranges not valid (k_join_plan counted no items)
+    uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
+    if (pr0) {
+        const uint64_t b0 = bbeg[i], nb = bend[i] - b0;
+        if (!nb) return;
+        walk_ranges(pbeg, pend, pr0[i], pnr[i], rstride, chunk, [&](uint32_t idx, bool list, uint64_t q0, uint64_t q1) {
+            JoinItem it;
+            it.b0 = b0; it.nb = (uint32_t)nb; it.p = i | (list ? JOIN_ITEM_LIST : 0u);
+            it.q0 = q0; it.q1 = q1;
+            items[at + idx] = it;
+        });
+        return;
+    }
     const uint32_t p = rpart ? rpart[i] : i;
     uint64_t nb = bend[p] - bbeg[p], np = pend[i] - pbeg[i];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
-    uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
     // a self-contained descriptor per item: the join workgroup reads ONE 32-byte record and goes straight to the data
     // (not item -> partition -> four range loads: every dependent global load is ~2 us under load)
     for (uint32_t j = 0; j < c; j++) {
@@ -1120,6 +1164,13 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
         it.q1 = it.q0 + chunk < pend[i] ? it.q0 + chunk : pend[i];
         items[at + j] = it;
     }
+}
+
+// the probe ranges of an item: one chunk [q0, q1), or (list items) range rr of it.q1 whole ranges starting at range it.q0
+__device__ inline uint32_t item_nranges(const JoinItem &it) { return (it.p & JOIN_ITEM_LIST) ? (uint32_t)it.q1 : 1u; }
+__device__ inline void item_range(const JoinArgs &a, const JoinItem &it, uint32_t rr, uint64_t &q0, uint64_t &q1) {
+    if (it.p & JOIN_ITEM_LIST) { const uint32_t r = (uint32_t)it.q0 + rr * a.rstride; q0 = a.pbeg[r]; q1 = a.pend[r]; }
+    else { q0 = it.q0; q1 = it.q1; }
 }
 
 // k_join_plan + scan + k_join_expand in ONE single-workgroup launch, for partition counts where three dependent launches
@@ -1175,9 +1226,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
     uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
 
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // scalar: the probe stream state stays in SGPRs
     const JoinItem it = a.items[item];
-    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
+    const uint64_t b0 = it.b0, nb = it.nb;
+    const uint32_t nr = item_nranges(it); // probe ranges of the item (list items: several whole ranges share one table build)
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
     // 16-bit tags with fewer than 16 radix bits (tag_extra = 1 or 2 more key bits than a tag holds): the top tag_extra bits of
     // the key pick the upper part of the bucket index, so every chain holds keys that agree on them and comparing the 16 stored
@@ -1196,12 +1248,20 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     for (uint64_t bc = 0; bc < nb; bc += a.cap) {
         const uint64_t gb = b0 + bc;
         const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
-        // the first probe iteration's loads are issued before the table is built: they fly during the build
-        const uint64_t wfirst = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256;
+        // the wave's probe stream: 256 tuples at w0, w0 + 2048, ... of range rr, then on into the item's next range (list items) —
+        // (rr, nq0, nq1, w0) is wave-uniform.  The loads of the NEXT position are always in flight while the current one is probed.
+        uint32_t rr = 0;
+        uint64_t nq0, nq1;
+        item_range(a, it, 0, nq0, nq1);
+        uint64_t w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256;
+        auto skip_empty = [&]() { // this wave has nothing (left) in range rr: on to the next one
+            while (w0 >= nq1 && rr + 1 < nr) { rr++; item_range(a, it, rr, nq0, nq1); w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256; }
+        };
+        skip_empty();
         int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
-        if (wfirst + (uint64_t)lane_id() * 4 < q1) {
-            nk = load4(a.pk, wfirst + (uint64_t)lane_id() * 4, a.p_nalloc);
-            np = load4(a.pp, wfirst + (uint64_t)lane_id() * 4, a.p_nalloc);
+        if (w0 + (uint64_t)lane_id() * 4 < nq1) {
+            nk = load4(a.pk, w0 + (uint64_t)lane_id() * 4, a.p_nalloc);
+            np = load4(a.pp, w0 + (uint64_t)lane_id() * 4, a.p_nalloc);
         }
         for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
         __syncthreads();
@@ -1237,13 +1297,15 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
         // the loop bound is wave-uniform (w0), so every lane of a wave stays in the loop together:
         // the ballot ranks and the wave's output cursor depend on it.  The next iteration's loads are issued before
         // this iteration's chains are walked.
-        for (uint64_t w0 = wfirst; w0 < q1; w0 += (uint64_t)JOIN_THREADS * 4) {
-            const uint64_t i = w0 + (uint64_t)lane_id() * 4;
+        while (w0 < nq1) {
+            const uint64_t i = w0 + (uint64_t)lane_id() * 4, q0 = nq0, q1 = nq1;
             const int4 kv = nk, pv = np;
             {
-                const uint64_t inext = i + (uint64_t)JOIN_THREADS * 4;
+                w0 += (uint64_t)JOIN_THREADS * 4;
+                skip_empty();
+                const uint64_t inext = w0 + (uint64_t)lane_id() * 4;
                 nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
-                if (inext < q1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
+                if (inext < nq1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
             }
             if (JM == 0) {
                 // count-only: the four bucket heads of this lane's four tuples are fetched first and the four
@@ -1375,7 +1437,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
     const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
     auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
     const uint32_t smask = tx ? 0x1FFFu : 0xFFFFu; // staged slot word: slot | (top tag_extra key bits << 13) (cap < 8192 then)
-    const uint32_t plow = it.p; // the partition id is the low `bits` key bits: a 16-bit tag + the id give the key back
+    const uint32_t plow = it.p & ~JOIN_ITEM_LIST; // (list items never reach this kernel) the partition id is the low `bits` key bits: a 16-bit tag + the id give the key back
     const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
 
     for (uint64_t bc = 0; bc < nb; bc += a.cap) {
@@ -1555,7 +1617,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4
 constexpr int MR_IT = 3;
 #define MR_NE(t) ((t) == 2 ? 2 : 4)
 constexpr uint32_t MR_SUB = 2 * JOIN_THREADS * 4 + JOIN_THREADS * 2;
-template <bool TAG16>
+template <bool TAG16, bool LISTS> // LISTS: the items may be list items (sampled probe side)
 __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { // 6 waves per SIMD = three workgroups per CU: <= 85 VGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t item = blockIdx.x;
@@ -1568,7 +1630,8 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
     const JoinItem it = a.items[item];
-    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
+    const uint64_t b0 = it.b0, nb = it.nb;
+    const uint32_t nr = LISTS ? item_nranges(it) : 1u;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
     const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
     auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
@@ -1580,6 +1643,10 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
         const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
         bool built = false;
         uint32_t par = 0;
+        for (uint32_t rr = 0; rr < nr; rr++) { // list items: whole ranges, one after the other, against the same table
+        uint64_t q0, q1;
+        if (LISTS) item_range(a, it, rr, q0, q1);
+        else { q0 = it.q0; q1 = it.q1; }
         for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)MR_SUB) {
             // the sub-chunk's probe tuples: issued first, so that they fly while the table is built
             // the first 2048 tuples are requested before the table is built (they fly during the build); the rest behind it — the
@@ -1713,6 +1780,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
                 // red[16..17] are rewritten only behind the next round's first barrier; the totals alternate by parity
             }
             par ^= 1u;
+        }
         }
         __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
     }
@@ -1971,7 +2039,7 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
 
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor) {
     hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt,
-                       a.bflag, a.pflag, zero2, zero_cursor, a.rpart);
+                       a.bflag, a.pflag, zero2, zero_cursor, a.rpart, a.pr0, a.pnr, a.rstride);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -1979,7 +2047,7 @@ hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, 
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items) {
     hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
-                       items_scanned, chunk_prefix, items, a.bflag, a.pflag, a.rpart);
+                       items_scanned, chunk_prefix, items, a.bflag, a.pflag, a.rpart, a.pr0, a.pnr, a.rstride);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2017,7 +2085,8 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
     {
         std::lock_guard<std::mutex> lock(g_attr_mutex);
         if (dev < 0 || dev >= 64 || lds > limit[dev]) {
-            const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat_reg<true>), reinterpret_cast<const void *>(&k_join_mat_reg<false>)};
+            const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat_reg<true, false>), reinterpret_cast<const void *>(&k_join_mat_reg<false, false>),
+                                 reinterpret_cast<const void *>(&k_join_mat_reg<true, true>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true>)};
             for (const void *f : fns) {
                 hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
@@ -2026,8 +2095,13 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
         }
     }
     dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
-    if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_join_mat_reg<false>), g, b, lds, st, a);
+    if (a.pr0) {
+        if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true, true>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join_mat_reg<false, true>), g, b, lds, st, a);
+    } else {
+        if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true, false>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join_mat_reg<false, false>), g, b, lds, st, a);
+    }
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }
