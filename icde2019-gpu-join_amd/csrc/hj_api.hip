@@ -306,7 +306,10 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     if (rc) return rc;
     if (ns == 0) return fail(c, HJ_EHIP, "empty sample");
     // ---- geometry, all on the host ----
-    const double n = (double)R.n, tot = (double)ns + 0.5 * NP;
+    // shares: (count + 1/2) / samples — the half count keeps unseen partitions alive.  NOT renormalised to sum 1: with few samples
+    // per partition (small inputs) that would scale every observed share down by NP / (2 * samples), 4 % at 3 * 2^20 tuples and
+    // 2^15 partitions — more than the margins of a large piece.  The shares sum to slightly more than 1: capacities err upwards.
+    const double n = (double)R.n, tot = (double)ns;
     std::vector<double> f(NP), fd(P1, 0.0);
     for (uint32_t i = 0; i < NP; i++) { f[i] = ((double)h[i] + 0.5) / tot; fd[i / P2] += f[i]; }
     auto relerr = [](double samples) { return 4.0 / std::sqrt(std::max(1.0, samples)); }; // 4 sigma of the sampled share
@@ -386,10 +389,25 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             return fd[x] > fd[y];
         });
     }
+    // Pieces: a pass-2 workgroup takes one parent's slots of a run of spans, and the launch runs ONE workgroup per CU (128 KiB of
+    // LDS lines), handed out in index order.  Equal pieces of ~one span (the first version) left the launch at the mercy of
+    // 803 pieces / 256 CUs = 3.14 rounds (78% busy).  Guided sizing instead: a piece is (work still to hand out) / (guide * CUs),
+    // never below 2^18 tuples — large pieces first, small ones to level the tail (list scheduling: the makespan exceeds the ideal
+    // by at most one of the last pieces).
+    double remaining = n;
+    const double guide = c->var_guide, cus = (double)std::max(1, c->ncu);
     for (uint32_t di = 0; di < P1; di++) {
         const uint32_t d = porder[di];
         const double Ed = n * fd[d];
-        uint32_t J = (uint32_t)std::min<double>((double)nspans, std::max(1.0, std::ceil(Ed / (double)span)));
+        double target = (double)span;
+        if (guide > 0) {
+            target = std::max(262144.0, remaining / (guide * cus));
+            double mxs = 0;
+            for (uint32_t q = 0; q < P2; q++) mxs = std::max(mxs, f[d * P2 + q] / fd[d]);
+            if (mxs > 0.25) target *= 0.5; // wave-aggregated ranking: slower per tuple
+        }
+        remaining -= Ed;
+        uint32_t J = (uint32_t)std::min<double>((double)nspans, std::max(1.0, std::ceil(Ed / target)));
         const double maxshare = (double)((nspans + J - 1) / J) / (double)nspans;
         std::vector<double> sh(P2);
         double mx = 0;
@@ -408,6 +426,11 @@ int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             W += cap;
         }
         for (uint32_t i = 0; i < 512; i++) own2[(size_t)d * 512 + i] = own[i];
+        if (getenv("HJ_DEBUG") && J > 1) {
+            uint32_t qm = 0;
+            for (uint32_t q = 0; q < P2; q++) if (sh[q] > sh[qm]) qm = q;
+            fprintf(stderr, "[hj] parent %u Ed %.0f J %u maxshare %.4f first wg %zu heavy %u child %u share %.4f cap %u lines %u W %llu\n", d, Ed, J, maxshare, wg.size() / 4, heavy2[d], qm, sh[qm], cap2[d * P2 + qm], lines[qm], (unsigned long long)W);
+        }
         for (uint32_t q = 0; q < P2; q++) { pr0[d * P2 + q] = (uint32_t)(wg.size() / 4) * P2 + q; pnr[d * P2 + q] = J; } // the partition's ranges: stride P2
         for (uint32_t j = 0; j < J; j++) {
             const uint32_t s0 = (uint32_t)((uint64_t)j * nspans / J), s1 = (uint32_t)((uint64_t)(j + 1) * nspans / J);
@@ -715,6 +738,7 @@ int fetch_scalars(hj_ctx *c) {
         Rel &R = c->rel[r];
         if (!R.fast_tried || R.flag_known_good) continue;
         if ((uint32_t)c->h_scalars[8 + r]) { // slots overflowed: ranges invalid
+            if (getenv("HJ_DEBUG")) fprintf(stderr, "[hj] rel %d overflow flag 0x%x (sampled %d) nwg2 %u nspans %u\n", r, (uint32_t)c->h_scalars[8 + r], (int)R.sampled, R.sp.nwg2, R.sp.nspans);
             if (R.sampled) R.sampled_failed = true; // even the sampled capacities: the exact passes are what is left
             R.prefer_exact = true; c->redo_mask |= 1u << r;
         }
@@ -801,6 +825,8 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
     if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
+    if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
+    (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
     if (const char *te = getenv("HJ_TAG_EXTRA")) c->tag_extra_max = std::max(0, std::min(2, atoi(te)));
     *out = c;
     return HJ_OK;

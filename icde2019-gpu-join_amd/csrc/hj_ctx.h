@@ -93,6 +93,8 @@ struct hj_ctx {
     uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     uint32_t fork_log2 = 40;        // inputs up to 2^fork_log2 tuples (= always): S's partition passes on a second stream beside R's (HJ_FORK_LOG2)
+    int ncu = 256;                  // CUs of the device
+    double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
     int tag_extra_max = 0;          // HJ_TAG_EXTRA=1|2: 16-bit tags also at 15 / 14 radix bits (exact: the extra key bits go into the bucket index); measured no faster than full keys
     uint32_t stage_cap = 0;         // experiment knob (HJ_STAGE_CAP): staged matches per flush of the one-probe materialising kernel
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size

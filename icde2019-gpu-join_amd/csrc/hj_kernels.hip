@@ -505,7 +505,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
             if (full) {
                 uint32_t nl = line[tid] + full;
-                if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u; nl = my_base; } // slot full: give up (the exact passes redo it)
+                if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u | (tid << 8) | (round << 20); nl = my_base; } // slot full: give up (the exact passes redo it)
                 line[tid] = nl;
                 if (EXACT) L_.lo[tid] = 0; // only the run's first line starts mid-line
             }
@@ -562,7 +562,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
                             const uint32_t o = line[d] + q;
                             if (EXACT || o < slot_base(g, d) + slot_cap(g, d)) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
-                            else *ovf = 1u;
+                            else *ovf = 2u;
                         }
                     }
                 }
@@ -627,7 +627,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
         if (full) {
             uint32_t nl = line[tid] + full;
-            if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u; nl = my_base; }
+            if (!EXACT && nl + my_gran > my_lim) { *ovf = 3u | (tid << 8) | (blockIdx.x << 16); nl = my_base; }
             line[tid] = nl;
             if (EXACT) L_.lo[tid] = 0;
         }
