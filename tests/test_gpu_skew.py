@@ -173,6 +173,18 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
         assert hj.join() == (em, eagg)
         k, pr, ps = hj.join_materialize()
         assert o.triples_checksum(k, pr, ps) == echk
+        # the LDS-staging kernel takes no list items: the plan falls back to one item list per range
+        hj.configure(**dict(cfg or {}, lds_stage=4608))
+        assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
+        k, pr, ps = hj.join_materialize()
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        # small probe chunks: runs of whole ranges are closed when the next range would not fit, long ranges are cut
+        hj.configure(**dict(cfg or {}, probe_chunk=3000))
+        assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
+        k, pr, ps = hj.join_materialize(cap=em)
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        hj.configure(**(cfg or {}))
+        assert hj.join() == (em, eagg)
         # introspection: gap-free partitions identical to the oracle's (the relation is redone with the exact passes for it)
         c = hj.config()
         bits = c["bits1"] + c["bits2"]

@@ -1,0 +1,14 @@
+#!/bin/bash
+# the full GPU suite, smoke(), then the extended differential runs — the parity evidence of a round
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/final
+mkdir -p $OUT
+timeout 2400 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "tests rc=$?"
+tail -3 $OUT/gpu_tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+{ echo "# tools/fuzz_medium.py 36 on one MI355X: differential runs against the oracle, 2^18-2^23-tuple relations, six key distributions,"
+  echo "# default and exact_only, second join with the learned skew, one-probe materialisation digest, three joins with hj_config.graph"
+  timeout 900 python tools/fuzz_medium.py 36 2>&1
+  timeout 600 python tools/fuzz_more.py 40 400 2>&1 | tail -1; } > $OUT/fuzz.txt
+tail -2 $OUT/fuzz.txt
+sha256sum icde2019-gpu-join_amd/libhj.so
