@@ -510,13 +510,22 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 if (EXACT) L_.lo[tid] = 0; // only the run's first line starts mid-line
             }
         }
+        // the kept tuples are stored: this round's tuples move to (kk, pp) — the ranks below and phase B work from there, phase A of
+        // the next round stores the kept ones — and the NEXT round's loads are issued right away: they fly through the rest of
+        // A, B and C (round 3; they used to be issued at the end of B and had only C to arrive)
+        uint32_t vmc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            kk[u] = kv[u]; pp[u] = pv[u]; vmc[u] = vm[u];
+            fetch(round + 1, u, kv[u], pv[u], vm[u]);
+        }
         uint32_t code[U * 4]; // digit << 16 | slot in the digit's lines ; WF_NONE = not a tuple
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const bool valid = (vm[u] >> e) & 1u;
-                const uint32_t d = MODE == 0 ? (((uint32_t)elem(kv[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kv[u], e), 0, P, remap);
+                const bool valid = (vmc[u] >> e) & 1u;
+                const uint32_t d = MODE == 0 ? (((uint32_t)elem(kk[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kk[u], e), 0, P, remap);
                 const uint32_t old = HEAVY ? rank_in_digit(h, d, valid, P <= 2)
                                            : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
@@ -546,7 +555,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t capd = VAR ? (lt >> 16) * WC_LINE : capS, based = VAR ? (lt & 0xFFFFu) * WC_LINE : d * capS;
                 const bool now = valid && (leaves ? q < capd : full == 0);
                 any_bypass |= valid && leaves && q >= capd;
-                buf[now ? based + q : trash] = make_int2(elem(kv[u], e), elem(pv[u], e));
+                buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
                 keep[j] = (valid && !leaves && full != 0) ? based + (q - full) : WF_NONE;
             }
         if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
@@ -561,16 +570,11 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
                         if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
                             const uint32_t o = line[d] + q;
-                            if (EXACT || o < slot_base(g, d) + slot_cap(g, d)) { out_keys[o] = elem(kv[u], e); out_pays[o] = elem(pv[u], e); }
+                            if (EXACT || o < slot_base(g, d) + slot_cap(g, d)) { out_keys[o] = elem(kk[u], e); out_pays[o] = elem(pp[u], e); }
                             else *ovf = 2u;
                         }
                     }
                 }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            kk[u] = kv[u]; pp[u] = pv[u];
-            fetch(round + 1, u, kv[u], pv[u], vm[u]); // next round's loads fly while the lines are flushed
         }
         __syncthreads();
         // ---- C: the wave owns 32 of the 512 LDS lines (line ls belongs to digit ls >> kshift); the full ones are
