@@ -1252,6 +1252,19 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     for (uint64_t bc = 0; bc < nb; bc += a.cap) {
         const uint64_t gb = b0 + bc;
         const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+        // ---- build: tuple j of the chunk lives in slot j; LIFO chain insert by atomic exchange on
+        // the bucket head (jp.cu:1021-1048).  Loads of three iterations (6144 tuples: a whole default-size table) are
+        // in flight at a time; the first three are issued BEFORE the heads are initialised (they need no LDS) ----
+        uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4;
+        int4 bkv[3], bpv[3];
+        auto bload = [&]() {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
+            }
+        };
+        bload();
         // the wave's probe stream: 256 tuples at w0, w0 + 2048, ... of range rr, then on into the item's next range (list items) —
         // (rr, nq0, nq1, w0) is wave-uniform.  The loads of the NEXT position are always in flight while the current one is probed.
         uint32_t rr = 0;
@@ -1269,16 +1282,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
         }
         for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
         __syncthreads();
-        // ---- build: tuple j of the chunk lives in slot j; LIFO chain insert by atomic exchange on
-        // the bucket head (jp.cu:1021-1048).  Loads of three iterations (6144 tuples: a whole default-size table) are
-        // issued before the first insert ----
-        for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 3) {
-            int4 bkv[3], bpv[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
-            }
+        while (i0 < gb + nbc) {
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
@@ -1295,6 +1299,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                     }
                 }
             }
+            i0 += (uint64_t)JOIN_THREADS * 4 * 3;
+            if (i0 < gb + nbc) bload();
         }
         __syncthreads();
         // ---- probe ----
