@@ -1,14 +1,12 @@
-"""Per-step times of the headline step over the first N steps of a fresh process (is there a settling phase?).
+"""Per-step times of the headline step over the first N steps of a fresh process (is there a settling phase?), with the device
+addresses of the input columns (does the level of a process follow where its buffers landed?).
 usage: python tools/step_trace.py [N=60] [log2n=30]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import importlib.util
 import torch
-spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+from tests.hjtest import pkg
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from tests.hjtest import pkg
 P = pkg()
 n = 1 << L
 dev = torch.device("cuda:0")
@@ -24,4 +22,9 @@ for i in range(N):
     m = hj.join()[0]
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 assert m == n
-print("steps ms:", " ".join("%.2f" % t for t in ts))
+hj.enable_timings(1); hj.timings_reset()
+for i in range(5): hj.join()
+kt = hj.timings()
+print("median %.3f ms; first steps:" % sorted(ts)[len(ts) // 2], " ".join("%.2f" % t for t in ts[:6]),
+      "| kernels", {k: round(v["total_ms"] / v["launches"], 3) for k, v in kt.items() if v["launches"] and v["total_ms"] > 0.5},
+      "| inputs at", " ".join("%x" % t.data_ptr() for t in (Rk, Rp, Sk, Sp)))
