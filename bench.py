@@ -174,7 +174,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     achieved = 16.0 * tuples / (avg_ms * 1e-3) / 1e9
     traffic = None
     try:
-        pmf = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_zipf.json")))
+        pmf = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_zipf.json")))
         key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
         if key and pmf.get("lib_sha256") == lib_sha256():
             traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
@@ -189,18 +189,62 @@ def bench_zipf(a, pkg, torch, dev, local):
         avg = jc["total_ms"] / jc["launches"]
         probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4), "achieved_GBs": round(8.0 * (nR + nS) / (avg * 1e-3) / 1e9, 1),
                  "frac_of_8TBs": round(8.0 * (nR + nS) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # the materialising variant (north_star: count AND materialised (key,payR,payS) tuples; the reference's lead timed run,
+    # hjcp.cu:913,937-940): partition both, then ONE probe writing ~2^31 output tuples (24 GiB) — the sampled probe side makes
+    # the items LIST items (k_join_mat_reg<.,LISTS>)
+    mat = None
+    if not a.no_materialize:
+        cap = expect
+        ok, opr, ops = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
+
+        def mat_step():
+            hj.partition_both()
+            return hj.join_materialize_into(ok, opr, ops, cap)
+
+        assert mat_step() == expect   # warm-up (first touch of the output columns)
+        torch.cuda.synchronize()
+        reps = max(1, a.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            nout = mat_step()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / reps
+        assert nout == expect
+        # full-size property check, outside the timed region: R's keys are unique and every payload is 1, so the output multiset
+        # is {(k,1,1) : S tuples whose key occurs in R} = all of S except the tuples with key nR (the generator's alphabet is
+        # 1..nR, R holds 0..nR-1); the digest is a sum of per-tuple mixes mod 2^64, so the missing tuples are subtracted
+        miss = nS - expect
+        want = (hj.digest_triples(Sk, Sp, Sp, nS) - miss * mix_triple(nR, 1, 1)) % (1 << 64)
+        assert hj.digest_triples(ok, opr, ops, nout) == want, "materialised output digest"
+        hj.enable_timings(2)
+        hj.timings_reset()
+        assert mat_step() == expect
+        km = hj.timings()
+        hj.enable_timings(0)
+        mk = km.get("k_join_materialize", {"launches": 0, "total_ms": 0.0})
+        mat = {"value": round((nR + nS) / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3),
+               "output_tuples": int(nout), "digest_checked": True,
+               "probes_per_step": sum(v["launches"] for k, v in km.items() if k.startswith("k_join_count") or k.startswith("k_join_mat")),
+               "launches_of_one_step": {k: v["launches"] for k, v in km.items() if v["launches"]}}
+        if mk["launches"]:
+            avg = mk["total_ms"] / mk["launches"]
+            gbs = (8.0 * (nR + nS) + 12.0 * nout) / (avg * 1e-3) / 1e9
+            mat.update({"k_join_materialize_ms": round(avg, 4), "k_join_materialize_GBs": round(gbs, 1),
+                        "k_join_materialize_frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": 8.0 * (nR + nS) + 12.0 * nout})
+        del ok, opr, ops
     cpu = None if a.no_cpu_baseline else zipf_cpu_baseline(hj, torch, dev)
     print(json.dumps({"metric": "billion tuples/sec (build+probe), PK-FK 2^27 x 2^31 Zipf theta=1.0, 1 GPU",
                       "value": round((nR + nS) * a.steps / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                       "dtype": "int32", "data": "synthetic", "vs_baseline": None,
-                      "first_call_ms": round(first_ms, 3),
+                      "first_call_ms": round(first_ms, 3), "first_call_split_ms": first_split,
                       "first_call": "optimistic histogram-free attempt on S (overflows) + sampling pass + host-side capacity tables + the step itself; "
                                     "later steps on the same binding reuse the tables",
                       "config": {"workload": "PK-FK 2^27 x 2^31, Zipf(1.0) foreign keys (device generator), payload=1, count-only",
                                  "matches": int(got), "radix_bits": [hj.config()["bits1"], hj.config()["bits2"]],
                                  "partition_layout_R_S": layout},
-                      "roofline": roof, "probe_phase": probe, "kernels": kernels, "cpu_baseline": cpu, "lib_sha256": lib_sha256()}))
+                      "roofline": roof, "probe_phase": probe, "kernels": kernels, "materialize": mat, "cpu_baseline": cpu, "lib_sha256": lib_sha256()}))
 
 
 def bench_baselines(a, pkg, torch, dev, local):
@@ -325,6 +369,23 @@ def launch_ranks(n):
 # amortise its ramp-up and drain (2^27: measured 0.60-0.63, target 0.68 NOT met).
 PROBE_TARGET_FRAC = 0.70
 PROBE_TARGET_FRAC_SMALL = 0.68   # below 2^30 tuples per relation
+
+
+def _fmix64(x):
+    m = (1 << 64) - 1
+    x ^= x >> 33
+    x = (x * 0xff51afd7ed558ccd) & m
+    x ^= x >> 33
+    x = (x * 0xc4ceb9fe1a85ec53) & m
+    x ^= x >> 33
+    return x
+
+
+def mix_triple(key, pr, ps):
+    """hj_digest_triples' per-tuple mix (csrc/hj_kernels.hip: mix_triple), for digest arithmetic on the host."""
+    m = (1 << 64) - 1
+    pair = _fmix64((((key & 0xFFFFFFFF) << 32) | (pr & 0xFFFFFFFF)) & m)
+    return _fmix64(pair ^ (((ps & 0xFFFFFFFF) * 0x9E3779B97F4A7C15) & m))
 
 
 def lib_sha256():
@@ -578,7 +639,7 @@ def main():
         # ... and only if that file was collected from THIS build of libhj.so (its sha256 is stored in the file)
         traffic, src = None, None
         try:
-            src = "profiles/r3_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
+            src = "profiles/r4_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
             pmf = json.load(open(os.path.join(ROOT, src)))
             key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
             if key and pmf.get("lib_sha256") == lib_sha256():
