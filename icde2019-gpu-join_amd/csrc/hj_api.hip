@@ -257,31 +257,18 @@ void invalidate(hj_ctx *c, int rel) {
 
 // Geometry of the histogram-free passes for a relation of n tuples (see hj_kernels.hip): spans of pass 1, slot
 // capacities of both passes.  false when the slotted layout would not fit 32-bit positions.
-// Workgroup geometry of a histogram-free pass of fan-out P (FastArgs.wg_threads): 1024 threads with 512 LDS lines serve any
-// fan-out; up to 256 / 128 digits fit 512- / 256-thread workgroups with 256 / 128 lines, two / four per CU.
-uint32_t fast_wg_threads(const hj_ctx *c, int pass, uint32_t P) {
-    uint32_t nt = pass == 0 ? c->wg0 : pass == 1 ? c->wg1 : c->wg2; // pass 0 = the multi-GPU shard split
-    if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
-    while (nt < 1024 && P > nt / 2) nt *= 2; // the geometry must hold one line per digit
-    return nt;
-}
-
 bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f) {
     if (n == 0) return false;
-    f.wg1 = fast_wg_threads(c, 1, P1);
-    f.wg2 = fast_wg_threads(c, 2, P2);
     // one workgroup per CU up to 2^28 tuples (fewer, longer spans: the per-span prologue and partial-line epilogue weigh
-    // less: pass 1 -4..-12 % at 2^26-2^27), two per CU beyond (no difference measured at 2^30); the smaller geometries
-    // run two / four workgroups per CU: as many spans as fill the chip once
-    uint32_t target = c->target_spans ? c->target_spans : (n >= ((uint64_t)1 << 29) ? 512 : 256);
-    if (!c->target_spans && f.wg1 < 1024) target = 256 * (1024 / f.wg1);
+    // less: pass 1 -4..-12 % at 2^26-2^27), two per CU beyond (no difference measured at 2^30)
+    const uint32_t target = c->target_spans ? c->target_spans : (n >= ((uint64_t)1 << 29) ? 512 : 256);
     uint64_t span = (n + target - 1) / target;
     span = ((span + TILE - 1) / TILE) * TILE;
     uint64_t nspans = (n + span - 1) / span;
     while (nspans > 1024) { span += TILE; nspans = (n + span - 1) / span; } // one LDS table entry per span in pass 2
     f.span = (uint32_t)span; f.nspans = (uint32_t)nspans;
-    f.cap1 = fast_slot_cap((span + P1 - 1) / P1, P1, f.wg1);
-    f.cap2 = fast_slot_cap((n + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2, f.wg2);
+    f.cap1 = fast_slot_cap((span + P1 - 1) / P1, P1);
+    f.cap2 = fast_slot_cap((n + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
     f.sizeA = (uint64_t)P1 * nspans * f.cap1;
     f.sizeB = (uint64_t)P1 * P2 * f.cap2;
     const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
@@ -579,14 +566,14 @@ int partition_rel(hj_ctx *c, int r) {
             uint32_t *ovf = flag;
             FastArgs fa{};
             fa.keys = R.in_k; fa.pays = R.in_p; fa.n = R.n; fa.span = f.span; fa.nspans = f.nspans;
-            fa.shift = b2; fa.P = P1; fa.cap = f.cap1; fa.wg_threads = f.wg1;
+            fa.shift = b2; fa.P = P1; fa.cap = f.cap1;
             fa.out_keys = (int32_t *)R.a_k.p; fa.out_pays = (int32_t *)R.a_p.p;
             fa.obeg = (uint64_t *)R.s1beg.p; fa.oend = (uint64_t *)R.s1end.p; fa.ovf = ovf;
             { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(st, fa)); }
             FastArgs fb{};
             fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
             fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = f.nspans;
-            fb.shift = 0; fb.P = P2; fb.cap = f.cap2; fb.wg_threads = f.wg2;
+            fb.shift = 0; fb.P = P2; fb.cap = f.cap2;
             fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
             fb.obeg = beg; fb.oend = end; fb.ovf = ovf;
             { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(st, fb)); }
@@ -838,9 +825,6 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
-    if (const char *w = getenv("HJ_WG0")) c->wg0 = (uint32_t)atoi(w);
-    if (const char *w = getenv("HJ_WG1")) c->wg1 = (uint32_t)atoi(w);
-    if (const char *w = getenv("HJ_WG2")) c->wg2 = (uint32_t)atoi(w);
     if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
     if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
     if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);

@@ -92,7 +92,6 @@ struct hj_ctx {
     uint32_t max_items = 0;
     uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
-    uint32_t wg0 = 0, wg1 = 0, wg2 = 0; // workgroup threads of the multi-GPU shard split / histogram-free pass 1 / pass 2 (HJ_WG0/1/2: 256, 512, 1024; 0 = default)
     uint32_t fork_log2 = 40;        // inputs up to 2^fork_log2 tuples (= always): S's partition passes on a second stream beside R's (HJ_FORK_LOG2)
     int ncu = 256;                  // CUs of the device
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
@@ -140,8 +139,7 @@ void release(Buf &b);
 void choose_bits(hj_ctx *c);
 void invalidate(hj_ctx *c, int rel = -1);
 // Geometry of the histogram-free passes for a relation of n tuples
-struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; uint32_t wg1, wg2; };
-uint32_t fast_wg_threads(const hj_ctx *c, int pass, uint32_t P);
+struct FastPlan { uint32_t span, nspans, cap1, cap2; uint64_t sizeA, sizeB; };
 bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f);
 int fetch_scalars(hj_ctx *c);
 int kid_of(hj_ctx *c, const char *name);

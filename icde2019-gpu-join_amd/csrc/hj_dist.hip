@@ -351,10 +351,10 @@ int coll_end(hj_dist_rank *r) {
 // Geometry of the sliced exchange of one relation: a function of (n_max over the ranks, G, K) and the radix bits only —
 // identical on every rank, which is what makes the message sizes known without asking anybody.
 struct SliceGeom {
-    uint32_t K = 0, nsp = 0, span = 0, cap0 = 0, cap1 = 0, cap2 = 0, NS = 0, wg0 = 0, wg2 = 0;
+    uint32_t K = 0, nsp = 0, span = 0, cap0 = 0, cap1 = 0, cap2 = 0, NS = 0;
     uint64_t L = 0, region = 0, sizeA = 0, sizeB = 0;
 };
-bool plan_slices(const hj_ctx *c, uint64_t nmax, uint32_t G, uint32_t Kwant, uint32_t P1, uint32_t P2, SliceGeom &g) {
+bool plan_slices(uint64_t nmax, uint32_t G, uint32_t Kwant, uint32_t P1, uint32_t P2, SliceGeom &g) {
     if (nmax == 0) nmax = 1;
     // Pass 2 reads at most 1024 segments per parent = local pass-1 spans over all slices: K slices of <= 1024/K spans.  The
     // default K = 4 keeps every split / pass-1 launch 256 workgroups wide (one per CU); K = 8 halves the exposed first split and
@@ -364,20 +364,19 @@ bool plan_slices(const hj_ctx *c, uint64_t nmax, uint32_t G, uint32_t Kwant, uin
     uint64_t L = (nmax + K - 1) / K;
     L = ((L + TILE - 1) / TILE) * TILE;
     K = (uint32_t)((nmax + L - 1) / L);
-    g.wg0 = fast_wg_threads(c, 0, G); g.wg2 = fast_wg_threads(c, 2, P2);
-    const uint32_t want = std::min<uint32_t>(256u * (1024u / g.wg0), 1024u / K);
+    const uint32_t want = std::min<uint32_t>(256u, 1024u / K);
     uint64_t span = (L + want - 1) / want;
     span = ((span + TILE - 1) / TILE) * TILE;
     const uint32_t nsp = (uint32_t)((L + span - 1) / span);
     if ((uint64_t)K * nsp > 1024) return false;
     g.K = K; g.L = L; g.span = (uint32_t)span; g.nsp = nsp; g.NS = K * nsp;
-    g.cap0 = fast_slot_cap((span + G - 1) / G, G, g.wg0);
+    g.cap0 = fast_slot_cap((span + G - 1) / G, G);
     g.region = (uint64_t)nsp * g.cap0;
     // the local pass-1 workgroup reads the G slots (*, s): span tuples in expectation
     uint64_t sd = 1;
     while (sd * sd < span) sd++;
     g.cap1 = fast_slot_cap((span + 8 * sd + P1 - 1) / P1, P1);
-    g.cap2 = fast_slot_cap((nmax + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2, g.wg2);
+    g.cap2 = fast_slot_cap((nmax + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
     g.sizeA = (uint64_t)P1 * g.NS * g.cap1;
     g.sizeB = (uint64_t)P1 * P2 * g.cap2;
     const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
@@ -401,7 +400,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     const uint32_t P1 = 1u << b1, P2 = 1u << b2;
     SliceGeom g[2];
     for (int x = 0; x < 2; x++)
-        if (!plan_slices(c, nmax[x], G, r->cfg.slices, P1, P2, g[x])) return 0;
+        if (!plan_slices(nmax[x], G, r->cfg.slices, P1, P2, g[x])) return 0;
     *applicable = true;
     hipStream_t cs = c->stream, ms = r->comm;
     uint64_t *sc = (uint64_t *)c->scalars.p;
@@ -426,7 +425,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             Grp gr{};
             gr.s0 = cu.first; gr.s1 = cu.second; gr.NS = (gr.s1 - gr.s0) * q.nsp;
             const uint64_t share = (nmax[x] * (gr.s1 - gr.s0) + q.K - 1) / q.K;
-            gr.cap2 = fast_slot_cap((share + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2, q.wg2);
+            gr.cap2 = fast_slot_cap((share + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
             gr.sizeA = (uint64_t)P1 * gr.NS * q.cap1; gr.sizeB = (uint64_t)P1 * P2 * gr.cap2;
             gr.offA = offA; gr.offB = offB; gr.s1off = s1off; gr.boff = boff;
             offA += gr.sizeA + PAD; offB += gr.sizeB + PAD; s1off += (size_t)P1 * gr.NS; boff += (size_t)P1 * P2;
@@ -480,7 +479,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         const uint64_t lo = std::min<uint64_t>((uint64_t)i * q.L, n[x]), hi = std::min<uint64_t>(lo + q.L, n[x]);
         FastArgs fa{};
         fa.keys = cols[2 * x] + lo; fa.pays = cols[2 * x + 1] + lo; fa.n = hi - lo; fa.span = q.span; fa.nspans = q.nsp;
-        fa.shift = 0; fa.P = G; fa.cap = q.cap0; fa.mode = 1; fa.wg_threads = q.wg0;
+        fa.shift = 0; fa.P = G; fa.cap = q.cap0; fa.mode = 1;
         const uint64_t base = (uint64_t)i * G * q.region; // slice i's G regions; positions inside the kernel are relative to it
         fa.out_keys = (int32_t *)r->send_k[x].p + base; fa.out_pays = (int32_t *)r->send_p[x].p + base;
         fa.obeg = (uint64_t *)r->s_beg[x].p + (size_t)i * G * q.nsp; fa.oend = (uint64_t *)r->s_end[x].p + (size_t)i * G * q.nsp;
@@ -552,7 +551,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         FastArgs fb{};
         fb.keys = (const int32_t *)R.a_k.p + gr.offA; fb.pays = (const int32_t *)R.a_p.p + gr.offA;
         fb.sbeg = (const uint64_t *)R.s1beg.p + gr.s1off; fb.send = (const uint64_t *)R.s1end.p + gr.s1off; fb.nparents = P1; fb.spp = gr.NS;
-        fb.shift = 0; fb.P = P2; fb.cap = gr.cap2; fb.wg_threads = q.wg2;
+        fb.shift = 0; fb.P = P2; fb.cap = gr.cap2;
         fb.out_keys = (int32_t *)R.b_k.p + gr.offB; fb.out_pays = (int32_t *)R.b_p.p + gr.offB;
         fb.obeg = (uint64_t *)R.beg.p + gr.boff; fb.oend = (uint64_t *)R.end.p + gr.boff;
         fb.ovf = reinterpret_cast<uint32_t *>(sc + 8 + x);

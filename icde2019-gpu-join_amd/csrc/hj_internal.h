@@ -61,7 +61,6 @@ struct FastArgs {
     uint32_t *ovf;               // overflow flag (also read: a set flag makes the kernel return at once)
     uint32_t mode;               // pass 1: 0 = radix digit, 1 = multi-GPU shard of the key (hash; P = number of GPUs)
     uint32_t seg_pass1, span0;   // launch_part2_fast as a pass 1 over received segments: workgroup b is span span0 + b of nspans
-    uint32_t wg_threads;         // workgroup geometry: 0 / 1024 threads = 512 LDS lines (any fan-out), 512 = 256 lines (P <= 256), 256 = 128 lines (P <= 128)
 };
 
 // one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
@@ -111,8 +110,7 @@ hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64
 hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
-uint32_t fast_slot_cap(uint64_t expected, uint32_t P, uint32_t wg_threads = 0);
-uint32_t fast_wg_lines(uint32_t wg_threads);
+uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 // the sampled path of skewed relations (hj_kernels.hip: k_part1_var, k_part2_var)
 struct VarArgs {
     const uint32_t *vbase, *vcap; // pass 1: per digit [P]; pass 2: per (parent, child) [nparents*P]

@@ -374,6 +374,7 @@ constexpr int WC_HSTRIDE = MAX_PARTS + 64; // arrival counters per parity + 64 p
 // The per-round machinery (rank by one LDS atomic, per-digit write-combining lines, full lines leave as aligned
 // 128-byte stores) is that of k_scatter_wc; all lines are aligned here, so there is no first-line masking.
 constexpr int WF_TRASH_LINES = WC_THREADS / WC_LINE;   // one trash slot per thread (branch-free placement)
+constexpr int WF_LINES = MAX_PARTS + WF_TRASH_LINES;
 constexpr int WF_MAXSEG = 1024;                        // segments of one parent (= pass-1 workgroups)
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu;
 
@@ -417,21 +418,20 @@ __device__ __forceinline__ uint32_t slot_cap(const FastGeom &g, uint32_t d) { re
 // says each will receive per round (L_.lt[d] = lines << 16 | first line, L_.own[line] = digit), instead of K each.
 // MODE 1 (exact pass only): the digit is the multi-GPU shard of the key (digit_of<1>: hash, optional position table), P
 // need not be a power of two (K = the largest power of two <= 512/P lines per digit).
-template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0, int NT = WC_THREADS>
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
                                         int32_t *__restrict__ out_pays, uint64_t *__restrict__ obeg,
                                         uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf,
                                         const uint32_t *__restrict__ remap = nullptr) {
-    constexpr int NL = NT / 2, HS = NL + 64; // LDS lines of the geometry (one per digit at the largest fan-out); counters per parity
     int2 *buf = L_.buf;
     uint32_t *hh = L_.hh, *line = L_.line;
-    const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)NL / P);
+    const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)MAX_PARTS / P);
     const uint32_t K = 1u << kshift, capS = K * WC_LINE; // lines / slots per digit in LDS
     const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
     const uint32_t mask = P - 1;
-    constexpr uint32_t ROUND = NT * 4 * U;
+    constexpr uint32_t ROUND = WC_THREADS * 4 * U;
     // ---- input feeder ----
     // SRC 0: the contiguous tuples [lo64, hi64): thread t of round r loads the 16 bytes at a0 + r*ROUND + (u*1024+t)*4.
     // SRC 1: the parent's segments as one stream of 4-tuple units (segments are 16-byte aligned and padded to whole
@@ -446,7 +446,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         nrounds = (rhi + ROUND - 1) / ROUND;
     } else {
         const uint32_t T4 = L_.pc4[nseg];
-        const uint32_t R = ((T4 + (NT / 64) * 64 - 1) / ((NT / 64) * 64)) * 64; // units per wave, multiple of 64
+        const uint32_t R = ((T4 + (WC_THREADS / 64) * 64 - 1) / ((WC_THREADS / 64) * 64)) * 64; // units per wave, multiple of 64
         nrounds = (R + 64 * U - 1) / (64 * U);
         wbeg = wv * R;
         wend = wbeg + R < T4 ? wbeg + R : T4;
@@ -460,7 +460,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     auto fetch = [&](uint32_t round, int u, int4 &kv, int4 &pv, uint32_t &vm) {
         kv = make_int4(0, 0, 0, 0); pv = make_int4(0, 0, 0, 0); vm = 0;
         if (SRC == 0) {
-            const uint32_t r = round * ROUND + (u * NT + tid) * 4;
+            const uint32_t r = round * ROUND + (u * WC_THREADS + tid) * 4;
             if (round < nrounds && r < rhi) {
                 kv = load4(kin, r, navail);
                 pv = load4(pin, r, navail);
@@ -491,10 +491,10 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     // the digit this thread owns (tid < P): slot geometry
     const uint32_t my_base = tid < P ? slot_base(g, tid) : 0u, my_lim = my_base + (tid < P ? slot_cap(g, tid) : 0u);
     const uint32_t my_gran = (VAR && tid < P) ? (L_.lt[tid] >> 16) * WC_LINE : capS; // a slot counts as full one granule (the digit's LDS lines) early
-    const uint32_t trash = NL * WC_LINE + tid;
+    const uint32_t trash = MAX_PARTS * WC_LINE + tid;
     uint32_t par = 0;
     for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
-        uint32_t *h = hh + par * HS, *hprev = hh + (par ^ 1) * HS;
+        uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
         // ---- A ----
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -505,7 +505,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             }
         // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
         // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
-        if (!EXACT && tid == 0 && (round & 3u) == 0) L_.wlist[(NT / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!EXACT && tid == 0 && (round & 3u) == 0) L_.wlist[(WC_THREADS / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < P) { // the lines flushed last round move this digit's output position
             const uint32_t w = hprev[tid];
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
@@ -533,12 +533,12 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const bool valid = (vmc[u] >> e) & 1u;
                 const uint32_t d = MODE == 0 ? (((uint32_t)elem(kk[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kk[u], e), 0, P, remap);
                 const uint32_t old = HEAVY ? rank_in_digit(h, d, valid, P <= 2)
-                                           : atomicAdd(&h[valid ? d : (uint32_t)NL + ln], 1u); // invalid: a trash counter
+                                           : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
         __syncthreads();
         // ---- B ----
-        const uint32_t stop = EXACT ? 0u : L_.wlist[(NT / 64) * 32];
+        const uint32_t stop = EXACT ? 0u : L_.wlist[(WC_THREADS / 64) * 32];
         uint32_t hw[U * 4];
 #pragma unroll
         for (int j = 0; j < U * 4; j++) hw[j] = h[code[j] != WF_NONE ? code[j] >> 16 : 0u]; // all LDS reads first
@@ -626,7 +626,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         if (stop) return; // workgroup-uniform: every thread read the same LDS word between the same barriers
     }
     // ---- epilogue: phase A of the last round, the partially filled last line of every digit, the slot ranges ----
-    uint32_t *hlast = hh + (par ^ 1) * HS;
+    uint32_t *hlast = hh + (par ^ 1) * WC_HSTRIDE;
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
@@ -643,7 +643,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         }
     }
     __syncthreads();
-    for (uint32_t d = wv; d < P; d += NT / 64) {
+    for (uint32_t d = wv; d < P; d += WC_THREADS / 64) {
         const uint32_t s = ln & (WC_LINE - 1);
         const uint32_t w = hlast[d];
         const uint32_t cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
@@ -661,37 +661,21 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     }
 }
 
-// LDS layout of one write-combining workgroup of NT threads: NL = NT/2 lines (+ one trash slot per thread), the per-digit
-// counters, the flush work lists, and — pass 2 only — the parent's segment table (maxseg entries).  The 1024-thread geometry
-// (512 lines: one per digit at 9 bits, 155 KiB, one workgroup per CU) always carries room for 1024 segments and the tables of
-// the lines-dealt-by-need modes (VAR), as before; the 512- and 256-thread geometries (low fan-out: 75 KiB = two workgroups per
-// CU, 38 KiB = four) carry a segment table of the size the launch needs and no VAR tables.
-template <int NT>
-__device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem, uint32_t maxseg = WF_MAXSEG) {
-    constexpr int NL = NT / 2;
+__device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.buf = reinterpret_cast<int2 *>(smem);
-    L_.hh = reinterpret_cast<uint32_t *>(L_.buf + (NL + NT / WC_LINE) * WC_LINE);
-    L_.line = L_.hh + 2 * (NL + 64);
-    L_.wlist = L_.line + NL;
-    L_.pc4 = L_.wlist + (NT / 64) * 32 + 4; // + the "stop" word
-    L_.sb = L_.pc4 + maxseg + 4;
+    L_.hh = reinterpret_cast<uint32_t *>(L_.buf + WF_LINES * WC_LINE);
+    L_.line = L_.hh + 2 * WC_HSTRIDE;
+    L_.wlist = L_.line + MAX_PARTS;
+    L_.pc4 = L_.wlist + (WC_THREADS / 64) * 32 + 4; // + the "stop" word
+    L_.sb = L_.pc4 + WF_MAXSEG + 4;
     L_.lo = L_.pc4;
-    if (NT == WC_THREADS) {
-        L_.lt = L_.sb + maxseg;      // lines dealt by need: an area of their own (the segment tables of pass 2 are in use then)
-        L_.own = L_.lt + MAX_PARTS;
-    } else {
-        L_.lt = nullptr; L_.own = nullptr;
-    }
+    L_.lt = L_.sb + WF_MAXSEG;       // lines dealt by need: an area of their own (the segment tables of pass 2 are in use then)
+    L_.own = L_.lt + MAX_PARTS;
 }
-// maxseg: segments of one pass-2 parent (0: pass 1, no segment table)
-size_t fast_lds_bytes_nt(int nt, uint32_t maxseg) {
-    const size_t nl = (size_t)nt / 2;
-    size_t b = (nl + (size_t)nt / WC_LINE) * WC_LINE * 8 + (nl + 64) * 4 * 2 + nl * 4 + (((size_t)nt / 64) * 32 + 4) * 4;
-    if (nt == WC_THREADS) return b + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2;
-    if (maxseg) b += ((size_t)maxseg + 4) * 4 + (size_t)maxseg * 4;
-    return (b + 15) & ~(size_t)15;
+size_t fast_lds_bytes_impl() {
+    return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
+           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2;
 }
-size_t fast_lds_bytes_impl() { return fast_lds_bytes_nt(WC_THREADS, WF_MAXSEG); }
 
 // The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
 // digit d starts at g0 (any alignment); the LDS lines of d mirror the 128-byte output lines being filled.
@@ -708,7 +692,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
                                                            uint64_t n_out, const uint32_t *__restrict__ remap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
-    wf_carve<WC_THREADS>(L_, smem);
+    wf_carve(L_, smem);
     SpanInfo si;
     if (!decode_span(sbeg, send, nseg, spp, span_start, span, si)) return;
     const uint32_t tid = threadIdx.x;
@@ -776,26 +760,22 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
 // fan-out 1..512) — the histogram-free level-0 split of the sliced exchange (hj_dist.hip): shard g's slots (g, *) form one
 // contiguous region of fixed size, which is what travels to GPU g.  FEW: at most 4 digits — ranks are taken with the
 // wave-aggregated atomic (nearly every lane would otherwise queue on one of a few LDS words).
-// NT: threads of the workgroup = 2 x its LDS lines.  1024 (512 lines, one workgroup per CU) serves every fan-out up to 512;
-// a pass of at most 256 / 128 digits can run as 512- / 256-thread workgroups with 256 / 128 lines (two / four per CU: the LDS
-// phases of one workgroup overlap the loads and stores of its neighbours) — launch_part1_fast picks by FastArgs.wg_threads.
-template <int U, int MODE, bool FEW, int NT>
-__global__ __launch_bounds__(NT) void k_part1_fast(FastArgs a) {
+template <int U, int MODE, bool FEW>
+__global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NL = NT / 2;
     WfLds L_;
-    wf_carve<NT>(L_, smem, NT == WC_THREADS ? (uint32_t)WF_MAXSEG : 0u);
+    wf_carve(L_, smem);
     if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // an earlier workgroup gave up already
     const uint32_t tid = threadIdx.x, s = blockIdx.x;
     const uint64_t lo = (uint64_t)s * a.span < a.n ? (uint64_t)s * a.span : a.n; // a span past the end (short slice of a multi-GPU split): empty
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
     FastGeom g{s, a.nspans, a.cap};
-    for (uint32_t d = tid; d < 2 * (NL + 64); d += NT) L_.hh[d] = 0;
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     if (tid < a.P) L_.line[tid] = slot_base(g, tid);
-    if (tid == 0) L_.wlist[(NT / 64) * 32] = 0;
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    if (MODE == 0 && a.P == (uint32_t)NL) wc_fast<U, 1, 0, false, false, false, 0, NT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 0, false, FEW, false, MODE, NT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (MODE == 0 && a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, false, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 0, false, FEW, false, MODE>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
 // ---- the sampled path of skewed relations: histogram-free passes with per-digit slot capacities and LDS lines dealt by
@@ -848,7 +828,7 @@ template <int U, bool HEAVY>
 __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
-    wf_carve<WC_THREADS>(L_, smem);
+    wf_carve(L_, smem);
     if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t tid = threadIdx.x, s = blockIdx.x;
     const uint64_t lo = (uint64_t)s * a.span < a.n ? (uint64_t)s * a.span : a.n;
@@ -869,7 +849,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
     if (*a.ovf) return;
     const uint4 w = v.wg[blockIdx.x]; // {parent, first span, spans, output position}
     WfLds L_;
-    wf_carve<WC_THREADS>(L_, smem);
+    wf_carve(L_, smem);
     const uint32_t tid = threadIdx.x, d = w.x;
     FastGeom g{blockIdx.x * a.P, 1u, 0};
     g.vbase = v.vbase + (uint64_t)d * a.P; g.vcap = v.vcap + (uint64_t)d * a.P; g.voff = w.w; g.vs = 0;
@@ -936,42 +916,36 @@ hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n,
 }
 
 // pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
-template <int U, int NT>
-__global__ __launch_bounds__(NT) void k_part2_fast(FastArgs a) {
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (*a.ovf) return; // pass 1 gave up: the exact passes take over
-    constexpr int NL = NT / 2;
     WfLds L_;
-    wf_carve<NT>(L_, smem, NT == WC_THREADS ? (uint32_t)WF_MAXSEG : a.spp);
+    wf_carve(L_, smem);
     const uint32_t tid = threadIdx.x, parent = blockIdx.x;
     // pass 2: child c of parent d -> slot d*P + c.  seg_pass1 (multi-GPU, hj_dist.hip): the workgroup is span span0 + parent of
     // a pass 1 whose input arrives as segments (the slots received from every peer): digit d -> slot (d, span0 + parent)
     const FastGeom g = a.seg_pass1 ? FastGeom{a.span0 + parent, a.nspans, a.cap} : FastGeom{parent * a.P, 1u, a.cap};
     uint32_t *scratch = L_.hh; // 17 words, before hh is zeroed
-    // segment table of this parent: 4-tuple units per segment, scanned (chunks of NT segments with a running carry)
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < a.spp; base += NT) {
-        const uint32_t i = base + tid;
-        uint32_t units = 0;
-        if (i < a.spp) {
-            const uint64_t b = a.sbeg[(uint64_t)parent * a.spp + i], e = a.send[(uint64_t)parent * a.spp + i];
-            const uint32_t cnt = (uint32_t)(e - b);
-            units = (cnt + 3) >> 2;
-            L_.sb[i] = (uint32_t)b | (units * 4 - cnt); // segment start (multiple of 4) | padding of its last unit
-        }
-        uint32_t total;
-        const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
-        if (i < a.spp) L_.pc4[i] = carry + ex;
-        carry += total;
+    // segment table of this parent: 4-tuple units per segment, scanned
+    uint32_t units = 0;
+    if (tid < a.spp) {
+        const uint64_t b = a.sbeg[(uint64_t)parent * a.spp + tid], e = a.send[(uint64_t)parent * a.spp + tid];
+        const uint32_t cnt = (uint32_t)(e - b);
+        units = (cnt + 3) >> 2;
+        L_.sb[tid] = (uint32_t)b | (units * 4 - cnt); // segment start (multiple of 4) | padding of its last unit
     }
-    if (tid == 0) L_.pc4[a.spp] = carry;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
+    if (tid < a.spp) L_.pc4[tid] = ex;
+    if (tid == 0) L_.pc4[a.spp] = total;
     __syncthreads();
-    for (uint32_t d = tid; d < 2 * (NL + 64); d += NT) L_.hh[d] = 0;
+    for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     if (tid < a.P) L_.line[tid] = slot_base(g, tid);
-    if (tid == 0) L_.wlist[(NT / 64) * 32] = 0;
+    if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    if (a.P == (uint32_t)NL) wc_fast<U, 1, 1, false, false, false, 0, NT>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 1, false, false, false, 0, NT>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
 // tuples per shard (MODE 1 digit, no remap): per-workgroup LDS histogram, one global atomic per shard per workgroup
@@ -1687,7 +1661,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
         uint32_t par = 0;
         for (uint32_t rr = 0; rr < nr; rr++) { // list items: whole ranges, one after the other, against the same table
         uint64_t q0, q1;
-        if (LISTS) { item_range(a, it, rr, q0, q1); q0 = uniform64(q0); q1 = uniform64(q1); } // the range cursor is wave-uniform: SGPRs, as in k_join
+        if (LISTS) { item_range(a, it, rr, q0, q1); q0 = uniform64(q0); q1 = uniform64(q1); } // the range cursor is wave-uniform: SGPRs, as in k_join (28 B/lane of scratch otherwise)
         else { q0 = it.q0; q1 = it.q1; }
         for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)MR_SUB) {
             // the sub-chunk's probe tuples: issued first, so that they fly while the table is built
@@ -2336,8 +2310,8 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
 
 // slot capacity of the histogram-free passes: expected count + 8 standard deviations (Poisson), rounded to the
 // digit's LDS lines (K = 512/P lines of 32 tuples), plus one such granule (a slot counts as full one granule early)
-uint32_t fast_slot_cap(uint64_t expected, uint32_t P, uint32_t wg_threads) {
-    const uint64_t gran = (uint64_t)(fast_wg_lines(wg_threads) / P) * WC_LINE;
+uint32_t fast_slot_cap(uint64_t expected, uint32_t P) {
+    const uint64_t gran = (uint64_t)(MAX_PARTS / P) * WC_LINE;
     uint64_t sd = 1;
     while (sd * sd < expected) sd++;
     uint64_t c = expected + 8 * sd + 32;
@@ -2345,51 +2319,37 @@ uint32_t fast_slot_cap(uint64_t expected, uint32_t P, uint32_t wg_threads) {
     return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
 }
 
-// LDS lines of a write-combining workgroup of wg_threads threads (0 = the default 1024-thread geometry)
-uint32_t fast_wg_lines(uint32_t wg_threads) { return (wg_threads ? wg_threads : (uint32_t)WC_THREADS) / 2; }
-
 template <typename F>
-static hipError_t fast_attr(F fn, bool *flags, size_t bytes = 0) {
+static hipError_t fast_attr(F fn, bool *flags) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (dev < 0 || dev >= 64 || !flags[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes ? bytes : fast_lds_bytes()));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds_bytes());
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) flags[dev] = true;
     }
     return hipSuccess;
 }
 
-// the geometry of a histogram-free launch: FastArgs.wg_threads = 0 / 1024 (512 LDS lines, any fan-out), 512 (256 lines: fan-out
-// <= 256, two workgroups per CU) or 256 (128 lines: fan-out <= 128, four per CU)
-static bool fast_wg_ok(const FastArgs &fa) {
-    const uint32_t nt = fa.wg_threads ? fa.wg_threads : (uint32_t)WC_THREADS;
-    return (nt == 1024 || nt == 512 || nt == 256) && fa.P <= nt / 2;
-}
-
-template <int MODE, bool FEW, int NT>
-static hipError_t launch_part1_fast_t(hipStream_t st, const FastArgs &fa, bool *set) {
-    auto fn = k_part1_fast<2, MODE, FEW, NT>;
-    const size_t lds = fast_lds_bytes_nt(NT, 0);
-    hipError_t e = fast_attr(fn, set, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(NT), lds, st, fa);
-    return hipGetLastError();
-}
-
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
-    static bool set[3][3][64] = {};
-    if (!fast_wg_ok(fa)) return hipErrorInvalidValue;
-    const uint32_t nt = fa.wg_threads ? fa.wg_threads : (uint32_t)WC_THREADS;
-    const int g = nt == 1024 ? 0 : nt == 512 ? 1 : 2;
+    static bool set[3][64] = {};
+    hipError_t e;
     // mode 1 = the multi-GPU level-0 split (shard digit); few digits take the wave-aggregated rank
-#define HJ_P1(MODE_, FEW_, V_) (g == 0 ? launch_part1_fast_t<MODE_, FEW_, 1024>(st, fa, set[V_][0]) : g == 1 ? launch_part1_fast_t<MODE_, FEW_, 512>(st, fa, set[V_][1]) \
-                                                                                                 : launch_part1_fast_t<MODE_, FEW_, 256>(st, fa, set[V_][2]))
-    if (fa.mode == 0) return HJ_P1(0, false, 0);
-    if (fa.P <= 4) return HJ_P1(1, true, 1);
-    return HJ_P1(1, false, 2);
-#undef HJ_P1
+    if (fa.mode == 0) {
+        auto fn = k_part1_fast<2, 0, false>;
+        if ((e = fast_attr(fn, set[0])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    } else if (fa.P <= 4) {
+        auto fn = k_part1_fast<2, 1, true>;
+        if ((e = fast_attr(fn, set[1])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    } else {
+        auto fn = k_part1_fast<2, 1, false>;
+        if ((e = fast_attr(fn, set[2])) != hipSuccess) return e;
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy) {
@@ -2416,22 +2376,13 @@ hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &v
     return hipGetLastError();
 }
 
-template <int NT>
-static hipError_t launch_part2_fast_t(hipStream_t st, const FastArgs &fa, bool *set) {
-    auto fn = k_part2_fast<2, NT>;
-    hipError_t e = fast_attr(fn, set, fast_lds_bytes_nt(NT, WF_MAXSEG));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(fa.nparents), dim3(NT), fast_lds_bytes_nt(NT, fa.spp), st, fa);
-    return hipGetLastError();
-}
-
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa) {
-    static bool set[3][64] = {};
-    if (!fast_wg_ok(fa) || fa.spp > (uint32_t)WF_MAXSEG) return hipErrorInvalidValue;
-    const uint32_t nt = fa.wg_threads ? fa.wg_threads : (uint32_t)WC_THREADS;
-    if (nt == 1024) return launch_part2_fast_t<1024>(st, fa, set[0]);
-    if (nt == 512) return launch_part2_fast_t<512>(st, fa, set[1]);
-    return launch_part2_fast_t<256>(st, fa, set[2]);
+    static bool set[64] = {};
+    auto fn = k_part2_fast<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(fa.nparents), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    return hipGetLastError();
 }
 
 hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end) {

@@ -298,49 +298,6 @@ def test_fast_path_layout_and_fallback(P):
         assert hj.partition_layout(P.REL_R) == "exact"
 
 
-@pytest.mark.parametrize("wg", [(512, 512), (256, 256), (1024, 256), (512, 1024), (256, 512)])
-def test_workgroup_geometries_of_the_histogram_free_passes(P, monkeypatch, wg):
-    """The write-combining passes as 512- / 256-thread workgroups with 256 / 128 LDS lines (two / four per CU) next to the
-    1024-thread / 512-line default: same partitions (offset for offset, digest for digest) and the same join as the oracle at
-    every fan-out a geometry can hold; a fan-out beyond its lines takes the next larger geometry.  HJ_WG1 / HJ_WG2 are read at
-    hj_create."""
-    monkeypatch.setenv("HJ_WG1", str(wg[0]))
-    monkeypatch.setenv("HJ_WG2", str(wg[1]))
-    rng = np.random.default_rng(wg[0] * 7 + wg[1])
-    for n, cfg in ((1 << 20, dict(bits1=8, bits2=7)), (3 * (1 << 18) + 123, dict(bits1=7, bits2=6)), ((1 << 18) + 1, dict(bits1=4, bits2=4)),
-                   ((1 << 21) + 5, dict(bits1=9, bits2=6)), (1 << 19, dict(bits1=2, bits2=1)), (70_001, dict(bits1=6, bits2=7))):
-        keys = rng.permutation(n).astype(np.int32)
-        keys[: n // 8] = rng.integers(-2**31, 2**31 - 1, n // 8)          # mild irregularity, no skew
-        pay = np.arange(n, dtype=np.int32)
-        S = keys[rng.permutation(n)[: n // 2]]
-        Ps = np.arange(len(S), dtype=np.int32)
-        with P.HashJoin(0) as hj:
-            hj.configure(**cfg)
-            hj.load_host(P.REL_R, keys, pay)
-            hj.load_host(P.REL_S, S, Ps)
-            hj.partition(P.REL_R)
-            hj.partition(P.REL_S)
-            assert hj.partition_layout(P.REL_R) == "slotted", (wg, cfg, n)
-            gk, gp, goff = hj.partitions(P.REL_R, n)
-            ok, op, ooff = o.radix_partition(keys, pay, 0, cfg["bits1"] + cfg["bits2"])
-            assert np.array_equal(goff, ooff), (wg, cfg)
-            assert np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff)), (wg, cfg)
-            assert hj.join_count() == o.join_count(keys, pay, S, Ps, checksum=False)[:2], (wg, cfg)
-            k, pr, ps = hj.join_materialize()
-            assert o.triples_checksum(k, pr, ps) == o.join_count(keys, pay, S, Ps)[2], (wg, cfg)
-    # skew still raises the flag in the small geometries and the exact passes answer
-    n = 1 << 18
-    skew = np.where(rng.random(n) < 0.5, 12345, rng.integers(0, n, n)).astype(np.int32)
-    uni = rng.permutation(n).astype(np.int32)
-    pay = np.arange(n, dtype=np.int32)
-    with P.HashJoin(0) as hj:
-        hj.configure(bits1=7, bits2=7)
-        hj.load_host(P.REL_R, uni, pay)
-        hj.load_host(P.REL_S, skew, pay)
-        assert hj.join() == o.join_count(uni, pay, skew, pay, checksum=False)[:2]
-        assert hj.partition_layout(P.REL_S) in ("exact", "sampled")
-
-
 # ---- partition parity --------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [dict(bits1=1), dict(bits1=9), dict(bits1=4, bits2=4), dict(bits1=9, bits2=9), dict(bits1=7, bits2=2)])
 def test_partition_parity(P, cfg):
