@@ -146,6 +146,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     assert hj.join()[0] == expect          # first contact: optimistic attempt -> overflow -> sample -> tables -> sampled passes -> join
     torch.cuda.synchronize()
     first_ms = (time.perf_counter() - t0) * 1e3
+    first_split = hj.last_call_breakdown()   # allocation / failed optimistic attempt / sample + plan / the step that answered
     for _ in range(a.warmup):
         assert hj.join()[0] == expect
     torch.cuda.synchronize()
@@ -602,6 +603,7 @@ def main():
                      "driver": "hj_dist (C++ over RCCL, include/hj_dist.h)" if c_impl else "dist.py (torch.distributed)",
                      "driver_fallback_reason": dist_fallback,
                      "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
+        dist_info["transport"] = "rccl (grouped ncclSend/ncclRecv per slice, hj_dist)" if c_impl else "torch.distributed all_to_all_single (%s)" % dist.get_backend()
         if c_impl:
             st = dj.stats()
             G = a.phantom if (world == 1 and a.phantom > 1) else world
@@ -664,6 +666,25 @@ def main():
                          "line_scatter_ceiling": round(scat, 1), "frac_of_line_scatter": round(achieved / scat, 4),
                          "ceilings": "hj_ubench, same run: 16 B/lane copy of a 2^%d-tuple column pair; same reads with every 128-B "
                                      "line stored at a pseudo-random aligned line position" % a.log2n})
+    if use_dist and c_impl and dist_info and dist_info["rank0"]["path"] == "sliced" and (world > 1 or a.phantom > 1):
+        # N > 1: the step is bound by the links, not by HBM: every ordered pair of GPUs has its own xGMI link, and a
+        # rank's bytes to ONE peer cross ONE link direction.  achieved = those bytes over the device time the exchange was in
+        # flight on the communication stream (HIP events, first slice's exchange start to last slice's end) — on one GPU in the
+        # shape of a G-GPU job (--phantom) nothing crosses a link and achieved is null, the model stands in.
+        st = dist_info["rank0"]
+        G = a.phantom if world == 1 else world
+        per_peer = st["link_bytes"] / (G - 1)
+        LINK_GBS = 76.8
+        achieved = (per_peer / (st["exchange_ms"] * 1e-3) / 1e9) if (world > 1 and st["exchange_ms"] > 0) else None
+        roof = {"bound": "xgmi", "kernel": "exchange (one grouped send/recv per slice, %d slices per relation)" % st["slices"],
+                "achieved": round(achieved, 2) if achieved else None, "peak": LINK_GBS, "unit": "GB/s per link direction",
+                "frac": round(achieved / LINK_GBS, 4) if achieved else None, "traffic": per_peer,
+                "bytes_per_link_direction": per_peer, "payload_bytes_per_link_direction": st["payload_bytes"] / (G - 1),
+                "exchange_ms": round(st["exchange_ms"], 3),
+                "exposed_local_ms": round(st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"], 3),
+                "local_ms_total": round(sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"], 3),
+                "note": "rank 0's view; peak = one xGMI link direction (7 links x 153.6 GB/s bidirectional per GPU); traffic = bytes rank 0 "
+                        "sends to ONE peer per step, padding of the fixed-size regions included"}
     kernels = {k: {"launches_per_step": v["launches"] / isteps, "ms_per_step": round(v["total_ms"] / isteps, 4)}
                for k, v in kt.items() if v["launches"]}
     jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
@@ -754,7 +775,9 @@ def main():
                        if world == 1 else
                        "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform per GPU, %d GPUs" % (a.log2n, a.log2n, world))
                       + (" [PLUMBING RUN over gloo on ONE GPU: not a measurement]" if backend == "gloo" else ""),
-            "is_measurement": backend != "gloo",
+            # not a measurement: the gloo plumbing mode, and any N > 1 line produced by the torch.distributed FALLBACK driver when
+            # hj_dist was asked for (a communicator could not be made): a scaling number from it must not pass for hj_dist's
+            "is_measurement": backend != "gloo" and not (use_dist and a.dist_impl == "c" and not c_impl and backend != "gloo" and a.balance == "hash"),
             "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",

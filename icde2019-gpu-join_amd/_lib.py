@@ -21,7 +21,7 @@ class Config(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
                 ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
                 ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("materialize_two_pass", C.c_uint32),
-                ("lds_stage", C.c_uint32), ("graph", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("reserved0", C.c_uint32), ("graph", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class KernelTime(C.Structure):
@@ -37,7 +37,7 @@ class Args(C.Structure):  # include/hj_reference_abi.h  (src/common-host.h:39-52
 
 class DistConfig(C.Structure):  # include/hj_dist.h
     _fields_ = [("slices", C.c_uint32), ("exact_only", C.c_uint32), ("self_via_link", C.c_uint32), ("phantom_world", C.c_uint32),
-                ("single_group", C.c_uint32), ("balance_size", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("single_group", C.c_uint32), ("balance_size", C.c_uint32), ("timeout_ms", C.c_uint32), ("test_stall_rank", C.c_uint32)]
 
 
 class DistStats(C.Structure):
@@ -45,7 +45,7 @@ class DistStats(C.Structure):
                 ("slices", C.c_uint32), ("spans_per_slice", C.c_uint32), ("slot_capacity", C.c_uint32 * 2),
                 ("split_ms", C.c_float * 2), ("pass1_ms", C.c_float * 2), ("pass2_join_ms", C.c_float),
                 ("first_split_ms", C.c_float), ("last_pass1_ms", C.c_float), ("wall_ms", C.c_float), ("early_pass2_join_ms", C.c_float), ("probe_groups", C.c_uint32),
-                ("balanced", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("balanced", C.c_uint32), ("exchange_ms", C.c_float), ("reserved", C.c_uint32 * 4)]
 
 
 class LastResult(C.Structure):
@@ -70,12 +70,12 @@ SIGNATURES = {
     "hj_shard_count": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, u64p]),
     "hj_shard_split_ordered": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), vp, vp, u64p]),
     "hj_enable_timings": (C.c_int, [vp, C.c_int]),
+    "hj_last_call_breakdown": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hj_join_stream_probe_materialize": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp, C.c_uint64, u64p, u64p]),
     "hj_host_split": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, u64p, C.POINTER(C.c_double)]),
     "hj_coprocess_numa": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hj_host_split_throughput": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "hj_ubench": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
-    "hj_ubench_handoff": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
     "hj_partition_layout": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "hj_join_count": (C.c_int, [vp, u64p, u64p]),
     "hj_join_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
@@ -108,6 +108,7 @@ SIGNATURES = {
     "hj_read_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
     "hj_write_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
     "hj_dist_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]),
+    "hj_dist_create_transport": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_char_p]),
     "hj_dist_destroy": (C.c_int, [vp]),
     "hj_dist_error": (C.c_char_p, [vp]),
     "hj_dist_world": (C.c_int, [vp]),

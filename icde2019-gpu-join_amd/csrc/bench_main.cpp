@@ -64,6 +64,7 @@ struct Input {
     const char *R_file = nullptr, *S_file = nullptr;
     uint64_t seed = 0;
     int gpus = 1, json = 0, cpu_baseline = 0;
+    const char *transport = nullptr; // --gpus N: "rccl" (default on distinct GPUs) or "copy" (peer copies on the copy engines)
 };
 
 [[noreturn]] void usage_exit() { // main.cu:68-73
@@ -81,6 +82,7 @@ void parse(int argc, char **argv, Input *in) {
                                    {"gpus", required_argument, nullptr, 1004},
                                    {"json", no_argument, nullptr, 1005},
                                    {"cpu-baseline", no_argument, nullptr, 1006},
+                                   {"transport", required_argument, nullptr, 1007},
                                    {"benchmark", required_argument, nullptr, 'b'},
                                    {"alg", required_argument, nullptr, 'a'},
                                    {"SelsNum", required_argument, nullptr, 'S'},
@@ -107,6 +109,7 @@ void parse(int argc, char **argv, Input *in) {
         case 1004: in->gpus = atoi(optarg); printf("gpus = %d\t", in->gpus); break;
         case 1005: in->json = 1; printf("json\t"); break;
         case 1006: in->cpu_baseline = 1; printf("cpu-baseline\t"); break;
+        case 1007: in->transport = optarg; printf("transport = %s\t", optarg); break;
         case 'b': in->option = atoi(optarg); printf("option = %d\t", in->option); break;
         case 'a':
             for (const JoinAlg *a = kAlgs; a->name; a++)
@@ -197,11 +200,11 @@ CpuJoin cpu_join(const int32_t *R, uint64_t nR, const int32_t *S, uint64_t nS) {
 // the rest in C++: level-0 split on the GPUs, sliced all-to-all over xGMI (RCCL), local passes + build/probe, all-reduce.
 // Fewer than N visible GPUs: refused (non-zero), nothing is emulated on the host.
 struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = 0; std::string transport, path; hj_dist_stats st{}; };
-MultiResult multi_gpu_join(const args &ja, int gpus) {
+MultiResult multi_gpu_join(const args &ja, int gpus, const char *transport) {
     MultiResult out;
     hj_dist *d = nullptr;
-    out.status = hj_dist_create(&d, gpus, nullptr);
-    if (out.status) { fprintf(stderr, "GPU Error: --gpus %d: hj_dist_create failed (code %d): fewer GPUs visible than ranks, or no GPU\n", gpus, out.status); return out; }
+    out.status = hj_dist_create_transport(&d, gpus, nullptr, transport);
+    if (out.status) { fprintf(stderr, "GPU Error: --gpus %d%s%s: hj_dist_create_transport failed (code %d): fewer GPUs visible than ranks, no GPU, or a transport these devices do not allow\n", gpus, transport ? " --transport " : "", transport ? transport : "", out.status); return out; }
     out.transport = hj_dist_transport(d);
     std::vector<void *> bufs;
     for (int g = 0; g < gpus && !out.status; g++) {
@@ -237,8 +240,9 @@ MultiResult multi_gpu_join(const args &ja, int gpus) {
     return out;
 }
 #else
-struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = HJ_EHIP; std::string transport, path; };
-MultiResult multi_gpu_join(const args &, int) { return MultiResult(); }
+struct MultiStats { float exchange_ms = 0; unsigned long long link_bytes = 0; };
+struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = HJ_EHIP; std::string transport, path; MultiStats st; };
+MultiResult multi_gpu_join(const args &, int, const char *) { return MultiResult(); }
 #endif
 
 int32_t *alloc_col(uint64_t n, bool *pinned) {
@@ -364,11 +368,14 @@ int main(int argc, char **argv) {
     if (in.option == 7 && in.gpus > 1) {
         printf("%s : %d GPUs, level-0 split + all-to-all over xGMI (RCCL)\n", in.alg->name, in.gpus);
         fflush(stdout);
-        multi = multi_gpu_join(ja, in.gpus);
+        multi = multi_gpu_join(ja, in.gpus, in.transport);
         status = multi.status ? 10 : 0;
         if (!multi.status) {
             const double bytes = 2.0 * (double)(ja.R_els + ja.S_els) * sizeof(int);
             printf("Exchange: %s, %s path\n", multi.transport.c_str(), multi.path.c_str());
+            if (multi.st.exchange_ms > 0) // what ONE link direction sustained while the exchange ran, against its 76.8 GB/s
+                printf("Links: %.2f GB to each peer in %.2f ms of exchange = %.1f GB/s per link direction (xGMI: 76.8)\n",
+                       multi.st.link_bytes / (double)(in.gpus - 1) / 1e9, multi.st.exchange_ms, multi.st.link_bytes / (double)(in.gpus - 1) / 1e6 / multi.st.exchange_ms);
             printf("Total Throughput (%d GPUs) %f\n", in.gpus, bytes / multi.seconds / 1000 / 1000);
             printf("%llu results\n", multi.agg);
         }

@@ -40,8 +40,11 @@ int fail(hj_ctx *c, int code, const char *fmt, ...) {
     return code;
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int ensure(hj_ctx *c, Buf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return 0;
+    const double t0 = now_ms();
     if (b.p) {
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
@@ -50,6 +53,9 @@ int ensure(hj_ctx *c, Buf &b, size_t bytes) {
     if (bytes == 0) bytes = 256;
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    if (c) { c->prof.alloc_ms += now_ms() - t0; c->prof.allocs++; }
+    static const bool dbg = getenv("HJ_DEBUG") != nullptr;
+    if (dbg && bytes >= ((size_t)64 << 20)) fprintf(stderr, "[hj] (re)allocated %.2f GiB in %.1f ms\n", bytes / 1073741824.0, now_ms() - t0);
     return 0;
 }
 
@@ -180,7 +186,7 @@ void choose_bits(hj_ctx *c) {
     // fewer than 16 radix bits: the LDS table stores full 4-byte keys (no 16-bit tags), 10 instead of 8 bytes per build
     // tuple.  With the default shape that is 62 KiB = 2 workgroups per CU; 4352 tuples + 2048 heads is 51.5 KiB = 3 per CU
     // (measured at 2^26-2^27: k_join_count 0.476 -> 0.439 ms, -8 %).
-    if (c->bits1 + c->bits2 < 16 - c->tag_extra_max && !g.lds_capacity && !g.lds_heads) { // (with HJ_TAG_EXTRA: 14 / 15 bits keep 16-bit tags)
+    if (c->bits1 + c->bits2 < 16 && !g.lds_capacity && !g.lds_heads) {
         c->cap = 4352;
         if (c->nh > 2048) c->nh = 2048;
     }
@@ -284,7 +290,14 @@ bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &
 // ranges (JoinArgs.rpart).  Once per binding: later partition calls reuse the tables, with no histogram and no host read.
 constexpr uint32_t SAMPLE_STRIDE = 8;
 
+int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2);
 int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
+    const double t0 = now_ms(), a0 = c->prof.alloc_ms;
+    const int rc = plan_sampled_impl(c, R, b1, b2);
+    c->prof.plan_ms += (now_ms() - t0) - (c->prof.alloc_ms - a0); // sampling kernel + read-back + host planning + table upload
+    return rc;
+}
+int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     Rel::Sampled &sp = R.sp;
     const uint32_t P1 = 1u << b1, P2 = 1u << b2, NP = P1 * P2;
     hipStream_t st = c->stream;
@@ -644,14 +657,13 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     if (B.sampled) return fail(c, HJ_EHIP, "internal: the build side must have one range per partition");
     // sampled probe side: several ranges per partition.  Whole ranges are packed into list items (one table build for all of them);
     // the LDS-staging kernel does not take list items: one item list per range there
-    const bool lists = Pb.sampled && Pb.pr0 && !(c->cfg.lds_stage || c->stage_cap);
+    const bool lists = Pb.sampled && Pb.pr0;
     const uint32_t nparts = lists ? Pb.nparts : Pb.nranges; // planning threads: partitions, or probe RANGES (== partitions unless sampled)
     const uint32_t rbits = B.pb1 + B.pb2;
-    // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2).  At 14 and 15 radix bits the 1-2 key bits a 16-bit tag
-    // cannot hold select the upper part of the bucket index instead (k_join: hidx), which keeps the comparison exact and the 8-byte
-    // table entries; below that the table stores full keys.
-    const uint32_t tag_extra = (32 - rbits) > 16 ? (32 - rbits) - 16 : 0;
-    tag16 = tag_extra <= (uint32_t)c->tag_extra_max && c->nh >= 16 && (tag_extra == 0 || c->cap < 8192);
+    // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2): what is left of a key fits the 16 stored bits.  Below that
+    // the table stores full keys.  (Round 3 also built 16-bit tags at 14 / 15 radix bits, the extra key bits folded into the bucket
+    // index: parity-green, measured no faster than full keys, removed — profiles/r3_tag_extra_ab.txt.)
+    tag16 = rbits >= 16 && c->nh >= 16;
     const uint64_t max_items64 = (uint64_t)Pb.nranges + Pb.n / c->chunk + 1;
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
@@ -677,7 +689,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     if (lists) { a.pr0 = Pb.pr0; a.pnr = Pb.pnr; a.rstride = Pb.rstride; }
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
-    a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk; a.tag_extra = tag16 ? tag_extra : 0;
+    a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
@@ -755,6 +767,8 @@ int fetch_scalars(hj_ctx *c) {
 int count_and_fetch(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = nullptr) {
     RET(run_count(c, a, tag16, late));
     RET(fetch_scalars(c));
+    if (c->redo_mask && c->prof.t0 > 0 && c->prof.attempt_ms == 0) // the optimistic attempt of this call came back flagged: what it cost
+        c->prof.attempt_ms = (now_ms() - c->prof.t0) - c->prof.alloc_ms;
     for (int attempt = 0; c->redo_mask; attempt++) { // histogram-free -> sampled capacities -> exact passes: at most two redos
         if (attempt == 2) return fail(c, HJ_EHIP, "exact passes reported an overflow");
         const uint32_t m = c->redo_mask;
@@ -825,11 +839,9 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
-    if (const char *sc = getenv("HJ_STAGE_CAP")) c->stage_cap = (uint32_t)atoi(sc);
     if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
     if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
     (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
-    if (const char *te = getenv("HJ_TAG_EXTRA")) c->tag_extra_max = std::max(0, std::min(2, atoi(te)));
     *out = c;
     return HJ_OK;
 }
@@ -890,7 +902,6 @@ int hj_configure(hj_ctx *c, const hj_config *cfg) {
     if (cfg->bits1 > 9 || cfg->bits2 > 9) return fail(c, HJ_EINVAL, "at most 9 radix bits per pass");
     if (cfg->lds_capacity > 65535) return fail(c, HJ_EINVAL, "lds_capacity must be <= 65535 (16-bit chain links)");
     if (cfg->lds_heads & (cfg->lds_heads - 1)) return fail(c, HJ_EINVAL, "lds_heads must be a power of two");
-    if (cfg->lds_stage && (cfg->lds_stage < 64 || cfg->lds_stage > 16384)) return fail(c, HJ_EINVAL, "lds_stage must be in [64, 16384]");
     c->cfg = *cfg;
     invalidate(c);
     drop_graph(c);
@@ -907,7 +918,6 @@ int hj_get_config(const hj_ctx *c, hj_config *cfg) {
     cfg->lds_capacity = c->cap; cfg->lds_heads = c->nh; cfg->probe_chunk = c->chunk;
     cfg->exact_only = c->cfg.exact_only || !c->fast_path;
     cfg->materialize_two_pass = c->cfg.materialize_two_pass;
-    cfg->lds_stage = c->cfg.lds_stage;
     cfg->graph = c->cfg.graph;
     return HJ_OK;
 }
@@ -981,19 +991,6 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
 
 namespace {
 
-// LDS staging block of the one-probe materialising kernel: what is left of half a CU's LDS (two workgroups per CU) next to
-// the hash table, 6 bytes per staged match
-uint32_t stage_capacity(const hj_ctx *c, bool tag16) {
-    if (c->cfg.lds_stage) return c->cfg.lds_stage;
-    if (c->stage_cap) return c->stage_cap;
-    const size_t table = join_mat_lds_bytes(c->nh, c->cap, tag16, 0);
-    const size_t half = 80 * 1024;
-    uint32_t s = table + 512 * 6 < half ? (uint32_t)((half - table) / 6) : 512;
-    s &= ~63u;
-    if (s > 4608) s = 4608; // 9 records per thread stay in registers across the output reservation (MAT_R)
-    return s;
-}
-
 // the two-probe path: count (unless the counts of these partitions are on the device already), scan, second probe writing
 // at the scanned per-wave positions: deterministic given the partitions, no output atomics (hj_config.materialize_two_pass)
 int materialize_two_pass(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
@@ -1020,13 +1017,12 @@ int materialize_two_pass(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_
     return 0;
 }
 
-// ONE probe: plan the work items, k_join_mat stages + reserves + writes; the cursor comes back with the result block
+// ONE probe: plan the work items, k_join_mat_reg finds, reserves and writes; the cursor comes back with the result block
 int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
     for (int attempt = 0; attempt < 3; attempt++) {
         JoinArgs a;
         bool tag16;
-        const bool staged = c->cfg.lds_stage || c->stage_cap;
-        if (c->join_planned && !(staged && c->last_args.pr0)) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
+        if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
             a = c->last_args; tag16 = c->last_tag16;
             HIPCHK(c, hipMemsetAsync((uint64_t *)c->scalars.p + 10, 0, 8, c->stream));
         } else {
@@ -1036,13 +1032,9 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
         a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
         a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
         a.out_cap = cap;
-        // default: matches held in registers (k_join_mat_reg, 3 workgroups per CU); hj_config.lds_stage / HJ_STAGE_CAP select the
-        // kernel that stages them in an LDS block of that many matches (k_join_mat, 2 per CU)
-        a.stage_cap = staged ? stage_capacity(c, tag16) : 0;
-        const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap) + 96;
-        if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table + staging block of %zu bytes exceed 160 KiB", lds);
-        { Timed t(c, "k_join_materialize");
-          HIPCHK(c, staged ? launch_join_mat(c->stream, a, c->max_items, tag16) : launch_join_mat_reg(c->stream, a, c->max_items, tag16)); }
+        const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16);
+        if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
+        { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join_mat_reg(c->stream, a, c->max_items, tag16)); }
         c->join_planned = false;
         RET(fetch_scalars(c)); // [sync]
         if (!c->redo_mask) break;
@@ -1186,11 +1178,26 @@ int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     bool done = false;
+    c->prof = hj_ctx::CallProf{};
+    c->prof.t0 = now_ms();
     RET(join_graph(c, matches, agg, &done));
-    if (done) return HJ_OK;
-    RET(partition_both(c));
-    RET(hj_join_count(c, matches, agg));
-    if (c->cfg.graph) { set_key(c); c->graph_warm = true; } // the next call on this binding may capture
+    if (!done) {
+        RET(partition_both(c));
+        RET(hj_join_count(c, matches, agg));
+        if (c->cfg.graph) { set_key(c); c->graph_warm = true; } // the next call on this binding may capture
+    }
+    c->prof.total_ms = now_ms() - c->prof.t0;
+    c->prof.t0 = 0;
+    return HJ_OK;
+}
+
+int hj_last_call_breakdown(const hj_ctx *c, double *alloc_ms, uint32_t *allocations, double *failed_attempt_ms, double *sample_plan_ms, double *total_ms) {
+    if (!c) return HJ_EINVAL;
+    if (alloc_ms) *alloc_ms = c->prof.alloc_ms;
+    if (allocations) *allocations = c->prof.allocs;
+    if (failed_attempt_ms) *failed_attempt_ms = c->prof.attempt_ms;
+    if (sample_plan_ms) *sample_plan_ms = c->prof.plan_ms;
+    if (total_ms) *total_ms = c->prof.total_ms;
     return HJ_OK;
 }
 
@@ -1790,29 +1797,6 @@ int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p,
     while (pow2 * 2 <= lines) pow2 *= 2;
     if (avg_ms) *avg_ms = (double)ms / reps;
     if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * 16; // 8 B read + 8 B written per tuple
-    return HJ_OK;
-}
-
-int hj_ubench_handoff(hj_ctx *c, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_ring_k, int32_t *d_ring_p, uint64_t n,
-                      uint64_t window_tuples, uint64_t ring_tuples, uint32_t reps, double *avg_ms, uint64_t *bytes_per_rep) {
-    if (!c || !reps) return HJ_EINVAL;
-    if (!d_in_k || !d_in_p || !d_ring_k || !d_ring_p) return fail(c, HJ_EINVAL, "hj_ubench_handoff needs four columns");
-    if (window_tuples < 4096 || (window_tuples & (window_tuples - 1)) || ring_tuples < window_tuples || ring_tuples % window_tuples || n < window_tuples)
-        return fail(c, HJ_EINVAL, "window: a power of two >= 4096 tuples; ring: a multiple of it; n >= window");
-    HIPCHK(c, hipSetDevice(c->device));
-    hipEvent_t a = get_event(c), b = get_event(c);
-    if (!a || !b) return fail(c, HJ_EHIP, "no HIP events");
-    uint64_t *sink = (uint64_t *)c->scalars.p + 4;
-    HIPCHK(c, launch_ubench_handoff(c->stream, d_in_k, d_in_p, d_ring_k, d_ring_p, n, window_tuples, ring_tuples, sink)); // warm-up
-    HIPCHK(c, hipEventRecord(a, c->stream));
-    for (uint32_t i = 0; i < reps; i++) HIPCHK(c, launch_ubench_handoff(c->stream, d_in_k, d_in_p, d_ring_k, d_ring_p, n, window_tuples, ring_tuples, sink));
-    HIPCHK(c, hipEventRecord(b, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, a, b));
-    c->pool.push_back(a); c->pool.push_back(b);
-    if (avg_ms) *avg_ms = (double)ms / reps;
-    if (bytes_per_rep) *bytes_per_rep = (n / window_tuples) * window_tuples * 24; // 8 B read (input) + 8 B written + 8 B read back per tuple
     return HJ_OK;
 }
 

@@ -95,8 +95,6 @@ struct hj_ctx {
     uint32_t fork_log2 = 40;        // inputs up to 2^fork_log2 tuples (= always): S's partition passes on a second stream beside R's (HJ_FORK_LOG2)
     int ncu = 256;                  // CUs of the device
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
-    int tag_extra_max = 0;          // HJ_TAG_EXTRA=1|2: 16-bit tags also at 15 / 14 radix bits (exact: the extra key bits go into the bucket index); measured no faster than full keys
-    uint32_t stage_cap = 0;         // experiment knob (HJ_STAGE_CAP): staged matches per flush of the one-probe materialising kernel
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
     hipStream_t copy = nullptr;     // H2D of the next probe segment
@@ -123,6 +121,8 @@ struct hj_ctx {
     uint64_t gkey_n[2] = {0, 0};
     bool gkey_pe[2] = {false, false};
     hipStream_t gkey_st = nullptr;
+    // host-side breakdown of the last hj_join call (hj_last_call_breakdown): what a FIRST call on a binding spends where
+    struct CallProf { double t0 = 0, alloc_ms = 0, attempt_ms = 0, plan_ms = 0, total_ms = 0; uint32_t allocs = 0; } prof;
     // timing
     int events = 0;                 // 0 none (default), 1 main kernels (partition passes / join), 2 every launch: hj_enable_timings, HJ_KERNEL_EVENTS
     std::vector<KStat> kstats;

@@ -68,6 +68,8 @@ struct RcclApi {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional: not part of `ok`
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
     bool ok = false;
 };
 const RcclApi &rccl() {
@@ -94,6 +96,8 @@ const RcclApi &rccl() {
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.ok = all;
+        api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
+        api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
     });
     return api;
 }
@@ -110,6 +114,10 @@ struct Msg {          // one peer's share of an exchange
 struct Link {
     virtual ~Link() {}
     virtual const char *name() const = 0;
+    // A rank that fails must not leave its peers waiting inside a collective: abort() makes every later (and, where the transport
+    // allows it, every pending) collective of this rank's group fail instead of block.  failed(): somebody aborted; why says who.
+    virtual void abort(const std::string &why) = 0;
+    virtual bool failed(std::string *why) = 0;
     virtual int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) = 0;
     virtual int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) = 0; // dst[world][bytes]
     virtual int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *scratch /* [world*n] */, hipStream_t st, std::string &err) = 0;
@@ -120,14 +128,36 @@ struct RcclLink : Link {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     bool own = true;
-    ~RcclLink() override { if (comm && own) (void)rccl().CommDestroy(comm); }
+    bool dead = false;
+    std::string dead_why;
+    ~RcclLink() override {
+        if (!comm || !own) return;
+        if (dead && rccl().CommAbort) (void)rccl().CommAbort(comm); // never ncclCommDestroy on a communicator with a stuck collective: it waits for it
+        else if (!dead) (void)rccl().CommDestroy(comm);
+    }
     const char *name() const override { return "rccl"; }
+    // The communicator is unusable afterwards (the next join on it fails at once).  ncclCommAbort itself is left to the
+    // destructor: aborting while this process still has kernels of the communicator queued is what RCCL documents as safe only
+    // from the thread that owns it, which is the one that destroys the rank.
+    void abort(const std::string &why) override { if (!dead) { dead = true; dead_why = why; } }
+    bool failed(std::string *why) override {
+        if (!dead && comm && rccl().CommGetAsyncError) {
+            ncclResult_t ar = ncclSuccess;
+            if (rccl().CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                dead = true; dead_why = std::string("RCCL asynchronous error: ") + rccl().GetErrorString(ar);
+            }
+        }
+        if (dead && why) *why = dead_why;
+        return dead;
+    }
     static int chk(ncclResult_t r, const char *what, std::string &err) {
         if (r == ncclSuccess) return 0;
         err = std::string(what) + ": " + rccl().GetErrorString(r);
         return HJ_EHIP;
     }
+    bool refuse(std::string &err) { if (dead) err = "communicator aborted: " + dead_why; return dead; }
     int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) override {
+        if (refuse(err)) return HJ_EHIP;
         // ONE group = one all-to-all-v: every ordered pair has its own xGMI link, nothing is relayed
         int rc = chk(rccl().GroupStart(), "ncclGroupStart", err);
         for (const Msg &m : msgs) {
@@ -140,29 +170,60 @@ struct RcclLink : Link {
         return rc ? rc : rc2;
     }
     int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) override {
+        if (refuse(err)) return HJ_EHIP;
         return chk(rccl().AllGather(src, dst, bytes, ncclInt8, comm, st), "ncclAllGather", err);
     }
     int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *, hipStream_t st, std::string &err) override {
+        if (refuse(err)) return HJ_EHIP;
         return chk(rccl().AllReduce(inout, inout, n, ncclUint64, ncclSum, comm, st), "ncclAllReduce", err); // wraps mod 2^64
     }
 };
 
-// ---- ranks of one process sharing a device: pull the peers' buffers ----
+// ---- ranks of one process: pull the peers' buffers with device copies (no RCCL kernel, no CU, no LDS: the copy engines) ----
+// Ranks that share a device (one-GPU test boxes: RCCL refuses duplicate GPUs) or sit on distinct devices with peer access enabled
+// (hipMemcpyPeerAsync over xGMI: the A/B partner of the RCCL transport on a multi-GPU node, hj_dist_create_transport).
 struct CopyGroup {
     int world;
     std::mutex mu;
     std::condition_variable cv;
     int waiting = 0;
     uint64_t generation = 0;
+    bool aborted = false;                    // under mu: a rank failed — every barrier returns at once from now on
+    std::string why;
+    double timeout_s = 120.0;
+    std::vector<char> arrived;               // per rank: at the current barrier (diagnostics of a deadline)
+    std::vector<int> dev;                    // per rank: HIP device
     std::vector<std::vector<Msg>> posted;    // per rank: its messages of the current exchange
     std::vector<const void *> gsrc;          // per rank: source of the current all-gather
     std::vector<hipEvent_t> ready;           // per rank: "my buffers of the current collective are written"
-    explicit CopyGroup(int w) : world(w), posted(w), gsrc(w, nullptr), ready(w, nullptr) {}
-    void barrier() {
+    explicit CopyGroup(int w) : world(w), arrived(w, 0), dev(w, 0), posted(w), gsrc(w, nullptr), ready(w, nullptr) {}
+    // false: the group was aborted, or the deadline passed (then this call aborts it and says who was missing)
+    bool barrier(int rank, const char *what, std::string &err) {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) { err = "device-copy transport: " + why; return false; }
         const uint64_t gen = generation;
-        if (++waiting == world) { waiting = 0; generation++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        arrived[rank] = 1;
+        if (++waiting == world) { waiting = 0; generation++; std::fill(arrived.begin(), arrived.end(), 0); cv.notify_all(); return true; }
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || aborted; });
+        if (aborted) { err = "device-copy transport: " + why; return false; }
+        if (ok) return true;
+        std::string missing;
+        for (int q = 0; q < world; q++) if (!arrived[q]) missing += (missing.empty() ? "" : ", ") + std::to_string(q);
+        why = "deadline of " + std::to_string(timeout_s) + " s passed at the " + what + " barrier: rank " + std::to_string(rank) + " waited for rank(s) " + missing;
+        aborted = true;
+        err = "device-copy transport: " + why;
+        cv.notify_all();
+        return false;
+    }
+    void abort(const std::string &w) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!aborted) { aborted = true; why = w; }
+        cv.notify_all();
+    }
+    bool failed(std::string *w) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (aborted && w) *w = why;
+        return aborted;
     }
 };
 
@@ -178,15 +239,23 @@ struct CopyLink : Link {
     CopyGroup *g = nullptr;
     int rank = 0;
     const char *name() const override { return "device-copy"; }
+    void abort(const std::string &why) override { g->abort(why); }
+    bool failed(std::string *why) override { return g->failed(why); }
     static int chk(hipError_t e, const char *what, std::string &err) {
         if (e == hipSuccess) return 0;
         err = std::string(what) + ": " + hipGetErrorString(e);
         return HJ_EHIP;
     }
+    // dst on my device, src on rank q's: a plain device-to-device copy when the ranks share a device, a peer copy otherwise
+    int pull(void *dst, const void *src, size_t bytes, int q, hipStream_t st, std::string &err) {
+        if (!bytes) return 0;
+        if (g->dev[q] == g->dev[rank]) return chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", err);
+        return chk(hipMemcpyPeerAsync(dst, g->dev[rank], src, g->dev[q], bytes, st), "hipMemcpyPeerAsync", err);
+    }
     int exchange(const std::vector<Msg> &msgs, hipStream_t st, std::string &err) override {
         g->posted[rank] = msgs;
         int rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
-        g->barrier(); // every rank has posted and recorded
+        if (!g->barrier(rank, "exchange (post)", err)) return HJ_EHIP; // every rank has posted and recorded
         for (size_t j = 0; j < msgs.size(); j++) {
             if (rc) break;
             const Msg &m = msgs[j];
@@ -204,21 +273,23 @@ struct CopyLink : Link {
                 break;
             }
             rc = chk(hipStreamWaitEvent(st, g->ready[m.peer], 0), "hipStreamWaitEvent", err);
-            if (!rc && m.rbytes) rc = chk(hipMemcpyAsync(m.dst, theirs->src, m.rbytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", err);
+            if (!rc) rc = pull(m.dst, theirs->src, m.rbytes, m.peer, st, err);
         }
-        g->barrier(); // the posted lists may be overwritten
-        return rc;
+        if (rc) { g->abort("rank " + std::to_string(rank) + ": " + err); return rc; } // the peers leave their barrier instead of waiting for me
+        if (!g->barrier(rank, "exchange (done)", err)) return HJ_EHIP; // the posted lists may be overwritten
+        return 0;
     }
     int allgather(const void *src, void *dst, size_t bytes, hipStream_t st, std::string &err) override {
         g->gsrc[rank] = src;
         int rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
-        g->barrier();
+        if (!g->barrier(rank, "all-gather (post)", err)) return HJ_EHIP;
         for (int q = 0; q < g->world && !rc; q++) {
             rc = chk(hipStreamWaitEvent(st, g->ready[q], 0), "hipStreamWaitEvent", err);
-            if (!rc) rc = chk(hipMemcpyAsync((char *)dst + (size_t)q * bytes, g->gsrc[q], bytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", err);
+            if (!rc) rc = pull((char *)dst + (size_t)q * bytes, g->gsrc[q], bytes, q, st, err);
         }
-        g->barrier();
-        return rc;
+        if (rc) { g->abort("rank " + std::to_string(rank) + ": " + err); return rc; }
+        if (!g->barrier(rank, "all-gather (done)", err)) return HJ_EHIP;
+        return 0;
     }
     int allreduce_sum_u64(uint64_t *inout, size_t n, uint64_t *scratch, hipStream_t st, std::string &err) override {
         int rc = allgather(inout, scratch, n * 8, st, err);
@@ -226,10 +297,10 @@ struct CopyLink : Link {
         // every rank has copied every contribution before anybody overwrites its own: the stream order of each rank alone
         // does not give that, so the ranks meet once more behind their copies
         rc = chk(hipEventRecord(g->ready[rank], st), "hipEventRecord", err);
-        g->barrier();
+        if (!g->barrier(rank, "all-reduce (copied)", err)) return HJ_EHIP;
         for (int q = 0; q < g->world && !rc; q++) rc = chk(hipStreamWaitEvent(st, g->ready[q], 0), "hipStreamWaitEvent", err);
-        g->barrier();
-        if (rc) return rc;
+        if (rc) { g->abort("rank " + std::to_string(rank) + ": " + err); return rc; }
+        if (!g->barrier(rank, "all-reduce (waited)", err)) return HJ_EHIP;
         hipLaunchKernelGGL(k_sum_ranks, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, scratch, (uint32_t)g->world, (uint32_t)n, inout);
         return chk(hipGetLastError(), "k_sum_ranks", err);
     }
@@ -250,6 +321,11 @@ struct hj_dist_rank {
     std::string err;
     hipStream_t comm = nullptr;
     hj_dist_stats st{};
+    double timeout_s = 120.0;  // deadline of every wait on a collective (hj_dist_config.timeout_ms, HJ_DIST_TIMEOUT_S)
+    const char *stage = "idle"; // what the host thread last enqueued / waits for (diagnostics of a deadline)
+    int stage_rel = -1, stage_slice = -1;
+    uint32_t cur_maxK = 0, cur_K[2] = {0, 0}; // the slices of the running sliced join (for the event census of a deadline)
+    std::vector<uint8_t> enq;  // [2*maxK] split events, [2*maxK] exchange events recorded by the running join
     bool prefer_exact = false; // the last fast attempt overflowed somewhere: exact path until new columns are bound
     const int32_t *last_cols[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t last_n[2] = {0, 0};
@@ -299,7 +375,61 @@ int dist_ensure(hj_dist_rank *r, hj_ctx::Buf &b, size_t bytes) {
     return rc;
 }
 
+double env_timeout_s() {
+    static double v = [] { const char *e = getenv("HJ_DIST_TIMEOUT_S"); const double x = e ? atof(e) : 0.0; return x > 0 ? x : 120.0; }();
+    return v;
+}
+
+// Which slice the links (or a peer) still owe: an event census of the running sliced join, for the message of a deadline.
+std::string slice_census(hj_dist_rank *r) {
+    std::string s;
+    for (int x = 0; x < 2 && r->cur_maxK; x++)
+        for (uint32_t i = 0; i < r->cur_K[x]; i++) {
+            const size_t e = (size_t)x * r->cur_maxK + i;
+            if (e >= r->ev_xchg.size()) continue;
+            const size_t half = 2 * (size_t)r->cur_maxK;
+            const bool spq = e < r->enq.size() && r->enq[e], xcq = half + e < r->enq.size() && r->enq[half + e];
+            const bool sp = spq && hipEventQuery(r->ev_split[e]) == hipSuccess, xc = xcq && hipEventQuery(r->ev_xchg[e]) == hipSuccess;
+            if (sp && xc) continue;
+            s += std::string(s.empty() ? "" : "; ") + (x ? "S" : "R") + " slice " + std::to_string(i) + ": split " + (sp ? "done" : spq ? "NOT done" : "not enqueued") +
+                 ", exchange " + (xc ? "done" : xcq ? "NOT complete" : "not enqueued");
+        }
+    (void)hipGetLastError(); // hipErrorNotReady from the queries is not an error
+    return s.empty() ? std::string("every slice's exchange has completed") : s;
+}
+
+// Wait for a stream with a deadline: no wait of the multi-GPU path blocks for ever.  On expiry the message names the rank, the
+// stage, the slices whose exchange has not completed and the peers a message is owed by (every other rank: one grouped
+// send/recv per slice), the rank's group is aborted, and the caller returns HJ_EHIP.
+int wait_stream(hj_dist_rank *r, hipStream_t s, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return r->fail(HJ_EHIP, "rank %d of %d: %s: %s", r->rank, r->world, what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if ((spins & 63u) == 63u) {
+            std::string why;
+            if (r->link && r->link->failed(&why)) return r->fail(HJ_EHIP, "rank %d of %d: %s: given up, the group was aborted: %s", r->rank, r->world, what, why.c_str());
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > r->timeout_s) {
+                const std::string census = slice_census(r);
+                r->fail(HJ_EHIP, "rank %d of %d (%s transport): deadline of %.1f s passed waiting for %s [stage: %s, relation %d, slice %d]; %s; "
+                                 "peers owed/owing a message: every rank but %d.  A peer has failed or stalled, or a link is down "
+                                 "(HJ_DIST_TIMEOUT_S / hj_dist_config.timeout_ms set the deadline)",
+                        r->rank, r->world, r->link ? r->link->name() : "?", r->timeout_s, what, r->stage, r->stage_rel, r->stage_slice, census.c_str(), r->rank);
+                fprintf(stderr, "[hj_dist] %s\n", r->err.c_str());
+                if (r->link) r->link->abort(r->err);
+                return HJ_EHIP;
+            }
+        }
+        if (spins < 4096) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
 int rank_init(hj_dist_rank *r) {
+    r->timeout_s = env_timeout_s();
     DCHK(r, hipSetDevice(r->c->device));
     DCHK(r, hipStreamCreateWithFlags(&r->comm, hipStreamNonBlocking));
     LRET(r, dist_ensure(r, r->small, 16384));
@@ -313,7 +443,7 @@ int rank_init(hj_dist_rank *r) {
 void rank_free(hj_dist_rank *r) {
     if (!r) return;
     if (r->c) (void)hipSetDevice(r->c->device);
-    if (r->comm) (void)hipStreamSynchronize(r->comm);
+    if (r->comm && !(r->link && r->link->failed(nullptr))) (void)hipStreamSynchronize(r->comm); // never behind a collective that was given up
     for (int x = 0; x < 2; x++) {
         release(r->send_k[x]); release(r->send_p[x]); release(r->recv_k[x]); release(r->recv_p[x]);
         release(r->s_beg[x]); release(r->s_end[x]); release(r->r_end[x]); release(r->seg_beg[x]); release(r->seg_end[x]);
@@ -345,6 +475,27 @@ int coll_begin(hj_dist_rank *r) {
 int coll_end(hj_dist_rank *r) {
     DCHK(r, hipEventRecord(r->ev_coll[1], r->comm));
     DCHK(r, hipStreamWaitEvent(r->c->stream, r->ev_coll[1], 0));
+    return 0;
+}
+
+// Every rank reports whether it is still good (local_rc == 0) and every rank learns whether all are: a rank that failed while
+// planning or allocating must not leave the others alone inside the exchange.  One 8-byte all-gather on the communication stream,
+// read by the host; the caller returns when anybody failed.  [sync, with the deadline]
+int agree(hj_dist_rank *r, int local_rc, const char *phase) {
+    hj_ctx *c = r->c;
+    uint64_t *small = (uint64_t *)r->small.p; // [1024] mine, [1032 ..] everybody's (world <= 64)
+    r->h_small[1024] = local_rc ? (uint64_t)(uint32_t)(-local_rc) : 0;
+    r->stage = phase; r->stage_rel = -1; r->stage_slice = -1;
+    const std::string mine = r->err;
+    DCHK(r, hipMemcpyAsync(small + 1024, r->h_small + 1024, 8, hipMemcpyHostToDevice, c->stream));
+    LRET(r, coll_begin(r));
+    LRET(r, r->link->allgather(small + 1024, small + 1032, 8, r->comm, r->err));
+    LRET(r, coll_end(r));
+    DCHK(r, hipMemcpyAsync(r->h_small + 1032, small + 1032, (size_t)r->world * 8, hipMemcpyDeviceToHost, c->stream));
+    LRET(r, wait_stream(r, c->stream, phase));
+    if (local_rc) { r->err = mine; return local_rc; }
+    for (int q = 0; q < r->world; q++)
+        if (r->h_small[1032 + q]) return r->fail(HJ_EHIP, "rank %d: rank %d failed %s (code -%llu): every rank leaves the join", r->rank, q, phase, (unsigned long long)r->h_small[1032 + q]);
     return 0;
 }
 
@@ -435,38 +586,54 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             grp[x].push_back(gr);
         }
     }
-    // buffers + events
+    // buffers + events.  The memory budget is checked before anything is (re)allocated — at 2^30 tuples per relation and G = 8
+    // a rank holds 2 x 2 x 9.0 GiB of send/receive regions and 2 x (2 x 9.2 + 2 x 9.2) GiB of partition buffers beside its 16 GiB
+    // of input — and the ranks AGREE on the outcome before the first message leaves: a rank that cannot allocate takes everybody
+    // out of the join with a message, instead of leaving its peers inside a collective.
     uint32_t maxK = std::max(g[0].K, g[1].K);
-    while (r->ev_split.size() < 2 * (size_t)maxK) {
-        hipEvent_t a, b, t0, t1, t2, t3;
-        DCHK(r, hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        DCHK(r, hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        DCHK(r, hipEventCreate(&t0)); DCHK(r, hipEventCreate(&t1)); DCHK(r, hipEventCreate(&t2)); DCHK(r, hipEventCreate(&t3));
-        r->ev_split.push_back(a); r->ev_xchg.push_back(b);
-        r->ev_t.push_back(t0); r->ev_t.push_back(t1); r->ev_t.push_back(t2); r->ev_t.push_back(t3);
-    }
-    while (r->ev_t.size() < 4 * 2 * (size_t)maxK + 8) { hipEvent_t t; DCHK(r, hipEventCreate(&t)); r->ev_t.push_back(t); }
-    for (int x = 0; x < 2; x++) {
-        const SliceGeom &q = g[x];
-        const size_t el = (size_t)q.K * G * q.region + PAD;
-        LRET(r, dist_ensure(r, r->send_k[x], el * 4)); LRET(r, dist_ensure(r, r->send_p[x], el * 4));
-        LRET(r, dist_ensure(r, r->recv_k[x], el * 4)); LRET(r, dist_ensure(r, r->recv_p[x], el * 4));
-        const size_t slots = (size_t)q.K * G * q.nsp;
-        LRET(r, dist_ensure(r, r->s_beg[x], slots * 8)); LRET(r, dist_ensure(r, r->s_end[x], slots * 8));
-        LRET(r, dist_ensure(r, r->r_end[x], slots * 8));
-        LRET(r, dist_ensure(r, r->seg_beg[x], slots * 8)); LRET(r, dist_ensure(r, r->seg_end[x], slots * 8));
-        hj_ctx::Rel &R = c->rel[x];
-        const Grp &lastg = grp[x].back();
-        const uint64_t totA = lastg.offA + lastg.sizeA + PAD, totB = lastg.offB + lastg.sizeB + PAD;
-        RET(ensure(c, R.a_k, (size_t)totA * 4)); RET(ensure(c, R.a_p, (size_t)totA * 4));
-        RET(ensure(c, R.b_k, (size_t)totB * 4)); RET(ensure(c, R.b_p, (size_t)totB * 4));
-        RET(ensure(c, R.s1beg, (size_t)P1 * q.NS * 8)); RET(ensure(c, R.s1end, (size_t)P1 * q.NS * 8));
-        RET(ensure(c, R.beg, (size_t)P1 * P2 * 8 * grp[x].size())); RET(ensure(c, R.end, (size_t)P1 * P2 * 8 * grp[x].size()));
-        RET(ensure(c, R.root, 16));
-    }
+    auto prepare = [&]() -> int {
+        struct Want { hj_ctx::Buf *b; size_t bytes; };
+        std::vector<Want> wants;
+        for (int x = 0; x < 2; x++) {
+            const SliceGeom &q = g[x];
+            const size_t el = (size_t)q.K * G * q.region + PAD, slots = (size_t)q.K * G * q.nsp;
+            hj_ctx::Rel &R = c->rel[x];
+            const Grp &lastg = grp[x].back();
+            const uint64_t totA = lastg.offA + lastg.sizeA + PAD, totB = lastg.offB + lastg.sizeB + PAD;
+            for (hj_ctx::Buf *b : {&r->send_k[x], &r->send_p[x], &r->recv_k[x], &r->recv_p[x]}) wants.push_back({b, el * 4});
+            for (hj_ctx::Buf *b : {&r->s_beg[x], &r->s_end[x], &r->r_end[x], &r->seg_beg[x], &r->seg_end[x]}) wants.push_back({b, slots * 8});
+            wants.push_back({&R.a_k, (size_t)totA * 4}); wants.push_back({&R.a_p, (size_t)totA * 4});
+            wants.push_back({&R.b_k, (size_t)totB * 4}); wants.push_back({&R.b_p, (size_t)totB * 4});
+            wants.push_back({&R.s1beg, (size_t)P1 * q.NS * 8}); wants.push_back({&R.s1end, (size_t)P1 * q.NS * 8});
+            wants.push_back({&R.beg, (size_t)P1 * P2 * 8 * grp[x].size()}); wants.push_back({&R.end, (size_t)P1 * P2 * 8 * grp[x].size()});
+            wants.push_back({&R.root, 16});
+        }
+        size_t grow = 0, give_back = 0, total = 0;
+        for (const Want &w : wants) { total += w.bytes; if (!(w.bytes <= w.b->cap && w.b->p)) { grow += w.bytes; give_back += w.b->cap; } }
+        size_t free_b = 0, total_b = 0;
+        DCHK(r, hipMemGetInfo(&free_b, &total_b));
+        if (grow > free_b + give_back)
+            return r->fail(HJ_ENOMEM, "rank %d of %d: the sliced exchange of 2 x %llu tuples per rank at G = %u needs %.2f GiB of buffers (%.2f GiB still to allocate), "
+                                      "%.2f GiB of %.2f GiB are free on device %d", r->rank, r->world, (unsigned long long)std::max(nmax[0], nmax[1]), G,
+                           total / 1073741824.0, (grow - give_back) / 1073741824.0, free_b / 1073741824.0, total_b / 1073741824.0, c->device);
+        while (r->ev_split.size() < 2 * (size_t)maxK) {
+            hipEvent_t a, b, t0, t1, t2, t3;
+            DCHK(r, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            DCHK(r, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            DCHK(r, hipEventCreate(&t0)); DCHK(r, hipEventCreate(&t1)); DCHK(r, hipEventCreate(&t2)); DCHK(r, hipEventCreate(&t3));
+            r->ev_split.push_back(a); r->ev_xchg.push_back(b);
+            r->ev_t.push_back(t0); r->ev_t.push_back(t1); r->ev_t.push_back(t2); r->ev_t.push_back(t3);
+        }
+        while (r->ev_t.size() < 4 * 2 * (size_t)maxK + 8) { hipEvent_t t; DCHK(r, hipEventCreate(&t)); r->ev_t.push_back(t); }
+        for (const Want &w : wants) LRET(r, dist_ensure(r, *w.b, w.bytes));
+        return 0;
+    };
+    LRET(r, agree(r, prepare(), "preparing the sliced exchange (memory budget, buffers)"));
+    r->cur_maxK = maxK; r->cur_K[0] = g[0].K; r->cur_K[1] = g[1].K;
+    r->enq.assign(4 * (size_t)maxK, 0); // which of this join's split / exchange events have been recorded (an older record reads "done")
     // flags of both relations down, received counters and the per-group results zero
     for (int x = 0; x < 2; x++) { Timed t(c, "k_set_root"); DCHK(r, launch_set_root(cs, (uint64_t *)c->rel[x].root.p, nmax[x], reinterpret_cast<uint32_t *>(sc + 8 + x))); }
-    DCHK(r, hipMemsetAsync(small + 4, 0, 16, cs));
+    DCHK(r, hipMemsetAsync(small + 4, 0, 32, cs)); // [4],[5] tuples received per relation, [6],[7] of which this rank's own
     DCHK(r, hipMemsetAsync(small + 20, 0, 32, cs));
     r->st.link_bytes = 0; r->st.payload_bytes = 0;
 
@@ -474,8 +641,10 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         for (const Grp &gr : grp[x]) if (i >= gr.s0 && i < gr.s1) return gr;
         return grp[x].back();
     };
+    bool xchg_started = false;
     auto split = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
+        r->stage = "split"; r->stage_rel = x; r->stage_slice = (int)i;
         const uint64_t lo = std::min<uint64_t>((uint64_t)i * q.L, n[x]), hi = std::min<uint64_t>(lo + q.L, n[x]);
         FastArgs fa{};
         fa.keys = cols[2 * x] + lo; fa.pays = cols[2 * x + 1] + lo; fa.n = hi - lo; fa.span = q.span; fa.nspans = q.nsp;
@@ -488,11 +657,16 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         { Timed t(c, "k_split_fast"); DCHK(r, launch_part1_fast(cs, fa)); }
         DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 1], cs));
         DCHK(r, hipEventRecord(r->ev_split[x * maxK + i], cs));
+        r->enq[x * maxK + i] = 1;
         return 0;
     };
     auto exchange = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
+        r->stage = "exchange"; r->stage_rel = x; r->stage_slice = (int)i;
+        if (r->cfg.test_stall_rank == (uint32_t)r->rank + 1 && x == second && i == 0) // test hook: this rank stops taking part for longer than the deadline
+            std::this_thread::sleep_for(std::chrono::duration<double>(r->timeout_s * 2.5 + 0.2));
         DCHK(r, hipStreamWaitEvent(ms, r->ev_split[x * maxK + i], 0));
+        if (!xchg_started) { DCHK(r, hipEventRecord(r->ev_t[4 * 2 * maxK + 6], ms)); xchg_started = true; } // the links are busy from here ...
         const uint64_t base = (uint64_t)i * G * q.region;
         const size_t eb = (size_t)i * G * q.nsp;
         std::vector<Msg> mk, mp, me_;
@@ -521,6 +695,8 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             if (rc) return rc;
         }
         DCHK(r, hipEventRecord(r->ev_xchg[x * maxK + i], ms));
+        DCHK(r, hipEventRecord(r->ev_t[4 * 2 * maxK + 7], ms)); // ... to the last record of this event
+        r->enq[2 * (size_t)maxK + x * maxK + i] = 1;
         return 0;
     };
     auto pass1 = [&](int x, uint32_t i) -> int {
@@ -532,7 +708,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         uint64_t *sb = (uint64_t *)r->seg_beg[x].p + eb, *se = (uint64_t *)r->seg_end[x].p + eb;
         DCHK(r, hipEventRecord(r->ev_t[4 * (x * maxK + i) + 2], cs));
         DCHK(r, launch_dist_segments(cs, (const uint64_t *)r->r_end[x].p + eb, G, q.nsp, q.cap0, phantom ? 0xFFFFFFFFu : me, (uint64_t)i * G * q.region, sb, se,
-                                     reinterpret_cast<uint32_t *>(sc + 8 + x), small + 4 + x));
+                                     reinterpret_cast<uint32_t *>(sc + 8 + x), small + 4 + x, small + 6 + x));
         FastArgs fb{};
         fb.keys = (const int32_t *)r->recv_k[x].p; fb.pays = (const int32_t *)r->recv_p[x].p;
         fb.sbeg = sb; fb.send = se; fb.nparents = q.nsp; fb.spp = G;
@@ -604,6 +780,8 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     LRET(r, after_pass1(order.back().x, order.back().i));
     // the per-group results and, with the result block, the flags of this rank's kernels; [sync]
     DCHK(r, hipMemcpyAsync(r->h_small + 16, small + 20, 32, hipMemcpyDeviceToHost, cs));
+    r->stage = "pipeline drained"; r->stage_rel = -1; r->stage_slice = -1;
+    LRET(r, wait_stream(r, cs, "the sliced pipeline (splits, exchanges, local passes, joins)")); // every exchange is behind this: the deadline, not a blocking sync
     if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
     uint64_t m = r->h_small[16] + r->h_small[18], a = r->h_small[17] + r->h_small[19];
     // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
@@ -612,12 +790,17 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     LRET(r, coll_begin(r));
     LRET(r, r->link->allreduce_sum_u64(small, 4, small + 64, ms, r->err));
     LRET(r, coll_end(r));
-    DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 48, hipMemcpyDeviceToHost, cs));
-    DCHK(r, hipStreamSynchronize(cs));
-    DCHK(r, hipStreamSynchronize(ms));
+    DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 64, hipMemcpyDeviceToHost, cs));
+    r->stage = "all-reduce of the result";
+    LRET(r, wait_stream(r, cs, "the all-reduce of the result (matches, aggregate, overflow flags)"));
+    LRET(r, wait_stream(r, ms, "the communication stream after the all-reduce"));
     out[0] = r->h_small[8]; out[1] = r->h_small[9];
     *flagged = (r->h_small[10] | r->h_small[11]) != 0;
     r->st.received[0] = r->h_small[12]; r->st.received[1] = r->h_small[13];
+    // tuple bytes among the link bytes: what this rank sent to others = its local tuples minus the ones it kept (phantom world: the
+    // shards other than shard 0 of what it holds)
+    r->st.payload_bytes = 0;
+    for (int x = 0; x < 2; x++) { const uint64_t all = phantom ? r->h_small[12 + x] : n[x], self = r->h_small[14 + x]; r->st.payload_bytes += 8 * (all > self ? all - self : 0); }
     // stage times
     r->st.path = 0; r->st.slices = maxK; r->st.spans_per_slice = g[0].nsp; r->st.slot_capacity[0] = g[0].cap0; r->st.slot_capacity[1] = g[1].cap0;
     for (int x = 0; x < 2; x++) {
@@ -626,7 +809,6 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
             r->st.split_ms[x] += ev_ms(r->ev_t[4 * (x * maxK + i) + 0], r->ev_t[4 * (x * maxK + i) + 1]);
             r->st.pass1_ms[x] += ev_ms(r->ev_t[4 * (x * maxK + i) + 2], r->ev_t[4 * (x * maxK + i) + 3]);
         }
-        r->st.payload_bytes = 0;
     }
     r->st.first_split_ms = ev_ms(r->ev_t[4 * (first * maxK) + 0], r->ev_t[4 * (first * maxK) + 1]);
     r->st.last_pass1_ms = ev_ms(r->ev_t[4 * (second * maxK + g[second].K - 1) + 2], r->ev_t[4 * (second * maxK + g[second].K - 1) + 3]);
@@ -635,6 +817,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     for (int k = 0; k < 2; k++)
         if (early_mask & (1u << k)) r->st.early_pass2_join_ms += ev_ms(r->ev_t[4 * 2 * maxK + 2 + 2 * k], r->ev_t[4 * 2 * maxK + 3 + 2 * k]);
     r->st.probe_groups = (uint32_t)grp[second].size();
+    r->st.exchange_ms = xchg_started ? ev_ms(r->ev_t[4 * 2 * maxK + 6], r->ev_t[4 * 2 * maxK + 7]) : 0.f;
     return 0;
 }
 
@@ -668,7 +851,8 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         LRET(r, r->link->allreduce_sum_u64(d_cnt, ns, d_cnt + ns, ms, r->err));
         LRET(r, coll_end(r));
         DCHK(r, hipMemcpyAsync(tot.data(), d_cnt, (size_t)ns * 8, hipMemcpyDeviceToHost, cs));
-        DCHK(r, hipStreamSynchronize(cs));
+        r->stage = "all-reduce of the shard sizes";
+        LRET(r, wait_stream(r, cs, "the all-reduce of the virtual-shard sizes"));
         std::vector<uint32_t> by(ns);
         for (uint32_t v = 0; v < ns; v++) by[v] = v;
         std::stable_sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) { return tot[a] > tot[b]; });
@@ -684,7 +868,11 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         for (uint32_t pos = 0; pos < ns; pos++) position[order[pos]] = pos;
     }
     for (int x = 0; x < 2; x++) {
-        LRET(r, dist_ensure(r, r->x_send_k[x], (size_t)(n[x] + PAD) * 4)); LRET(r, dist_ensure(r, r->x_send_p[x], (size_t)(n[x] + PAD) * 4));
+        {
+            int arc = dist_ensure(r, r->x_send_k[x], (size_t)(n[x] + PAD) * 4);
+            if (!arc) arc = dist_ensure(r, r->x_send_p[x], (size_t)(n[x] + PAD) * 4);
+            LRET(r, agree(r, arc, "allocating the send side of the exact exchange"));
+        }
         std::vector<uint64_t> cnt(G, 0);
         // level-0 split, one contiguous run per owner; [sync]: the run lengths come back to the host
         if (!balance) {
@@ -704,11 +892,16 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         LRET(r, coll_end(r));
         std::vector<uint64_t> all((size_t)G * G);
         DCHK(r, hipMemcpyAsync(all.data(), d_all, (size_t)G * G * 8, hipMemcpyDeviceToHost, cs));
-        DCHK(r, hipStreamSynchronize(cs));
+        r->stage = "all-gather of the shard counts"; r->stage_rel = x;
+        LRET(r, wait_stream(r, cs, "the all-gather of the exact shard counts"));
         std::vector<uint64_t> soff(G + 1, 0), roff(G + 1, 0);
         for (uint32_t q = 0; q < G; q++) { soff[q + 1] = soff[q] + cnt[q]; roff[q + 1] = roff[q] + all[(size_t)q * G + me]; }
         recv_tot[x] = roff[G];
-        LRET(r, dist_ensure(r, r->x_recv_k[x], (size_t)(roff[G] + PAD) * 4)); LRET(r, dist_ensure(r, r->x_recv_p[x], (size_t)(roff[G] + PAD) * 4));
+        {   // the receive side is sized from the counts: the ranks agree that everybody could allocate before anything is sent
+            int arc = dist_ensure(r, r->x_recv_k[x], (size_t)(roff[G] + PAD) * 4);
+            if (!arc) arc = dist_ensure(r, r->x_recv_p[x], (size_t)(roff[G] + PAD) * 4);
+            LRET(r, agree(r, arc, "allocating the receive side of the exact exchange"));
+        }
         // the split ran on the compute stream; the exchange goes to the communication stream
         DCHK(r, hipEventRecord(r->ev_misc[x], cs));
         DCHK(r, hipStreamWaitEvent(ms, r->ev_misc[x], 0));
@@ -736,6 +929,9 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     DRET(r, hj_partition(c, HJ_REL_R));
     DCHK(r, hipStreamWaitEvent(cs, r->ev_misc[3], 0));
     DRET(r, hj_partition(c, HJ_REL_S));
+    r->stage = "exact exchange"; r->stage_rel = -1;
+    LRET(r, wait_stream(r, ms, "the exact-size exchange (grouped send/recv of both relations)")); // hj_join_count synchronises: the deadline first
+    LRET(r, wait_stream(r, cs, "the local partition passes behind the exact exchange"));
     uint64_t m = 0, a = 0;
     DRET(r, hj_join_count(c, &m, &a));
     r->h_small[0] = m; r->h_small[1] = a;
@@ -744,19 +940,44 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     LRET(r, r->link->allreduce_sum_u64(small, 2, small + 64, ms, r->err));
     LRET(r, coll_end(r));
     DCHK(r, hipMemcpyAsync(r->h_small + 8, small, 16, hipMemcpyDeviceToHost, cs));
-    DCHK(r, hipStreamSynchronize(cs));
-    DCHK(r, hipStreamSynchronize(ms));
+    r->stage = "all-reduce of the result";
+    LRET(r, wait_stream(r, cs, "the all-reduce of the result"));
+    LRET(r, wait_stream(r, ms, "the communication stream after the all-reduce"));
     out[0] = r->h_small[8]; out[1] = r->h_small[9];
     r->st.received[0] = recv_tot[0]; r->st.received[1] = recv_tot[1];
-    r->st.path = 1; r->st.slices = 1; r->st.balanced = balance ? 1 : 0;
+    r->st.path = 1; r->st.slices = 1; r->st.balanced = balance ? 1 : 0; r->st.exchange_ms = 0;
     r->st.payload_bytes = r->st.link_bytes;
     return 0;
 }
 
+int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
+                    uint64_t *matches, uint64_t *agg);
+
+// A rank that fails for any reason aborts its group on the way out: peers inside (or on their way into) a collective then leave
+// with an error that names this rank, instead of waiting for the deadline — or, in the reference's terms, instead of the
+// print-and-exit of CHK_ERROR (common.h:132-141) taking one process down while the others hang.
 int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
               uint64_t *matches, uint64_t *agg) {
-    hj_ctx *c = r->c;
     r->err.clear();
+    r->cur_maxK = 0;
+    r->timeout_s = r->cfg.timeout_ms ? r->cfg.timeout_ms * 1e-3 : env_timeout_s();
+    {
+        std::string why;
+        if (r->link->failed(&why)) return r->fail(HJ_EHIP, "rank %d: the group was aborted by an earlier failure (%s): create a new one", r->rank, why.c_str());
+    }
+    const int rc = rank_join_inner(r, Rk, Rp, nR, Sk, Sp, nS, matches, agg);
+    if (rc) {
+        if (r->err.empty()) r->err = hj_error(r->c);
+        r->link->abort("rank " + std::to_string(r->rank) + " failed: " + r->err);
+        hj_invalidate_all(r->c);
+    }
+    r->stage = "idle";
+    return rc;
+}
+
+int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
+                    uint64_t *matches, uint64_t *agg) {
+    hj_ctx *c = r->c;
     if ((nR && (!Rk || !Rp)) || (nS && (!Sk || !Sp))) return r->fail(HJ_EINVAL, "null column");
     if ((((uintptr_t)Rk | (uintptr_t)Rp | (uintptr_t)Sk | (uintptr_t)Sp) & 15)) return r->fail(HJ_EINVAL, "device columns must be 16-byte aligned");
     DCHK(r, hipSetDevice(c->device));
@@ -775,7 +996,8 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
     LRET(r, r->link->allgather(small + 16, small + 128, 32, r->comm, r->err));
     LRET(r, coll_end(r));
     DCHK(r, hipMemcpyAsync(r->h_small + 32, small + 128, (size_t)r->world * 32, hipMemcpyDeviceToHost, c->stream));
-    DCHK(r, hipStreamSynchronize(c->stream));
+    r->stage = "all-gather of the sizes";
+    LRET(r, wait_stream(r, c->stream, "the all-gather of the local sizes (first collective of the join)"));
     uint64_t nmax[2] = {0, 0};
     bool exact = false, balance = false;
     for (int q = 0; q < r->world; q++) {
@@ -819,7 +1041,7 @@ struct hj_dist {
 
 extern "C" {
 
-int hj_dist_create(hj_dist **out, int nranks, const int *devices) {
+int hj_dist_create_transport(hj_dist **out, int nranks, const int *devices, const char *transport) {
     if (!out) return HJ_EINVAL;
     *out = nullptr;
     if (nranks < 1 || nranks > 64) return HJ_EINVAL;
@@ -832,34 +1054,61 @@ int hj_dist_create(hj_dist **out, int nranks, const int *devices) {
         if (dev[r] < 0 || dev[r] >= ndev) return HJ_EINVAL; // fewer GPUs visible than ranks asked for
         for (int q = 0; q < r; q++) distinct &= dev[q] != dev[r];
     }
+    std::string want = transport ? transport : "";
+    if (want.empty() || want == "auto") { const char *e = getenv("HJ_DIST_TRANSPORT"); want = e ? e : ""; }
+    if (want == "copy") want = "device-copy";
+    if (!want.empty() && want != "auto" && want != "rccl" && want != "device-copy") return HJ_EINVAL;
+    if (want == "rccl" && !distinct) return HJ_EINVAL; // RCCL refuses duplicate GPUs
+    const bool use_rccl = want == "rccl" || ((want.empty() || want == "auto") && distinct);
     hj_dist *d = new hj_dist();
     d->world = nranks;
     std::vector<ncclComm_t> comms(nranks, nullptr);
-    if (distinct) {
+    if (use_rccl) {
         if (!rccl().ok || rccl().CommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { delete d; return HJ_EHIP; }
         d->transport = "rccl";
     } else {
         d->copy.reset(new CopyGroup(nranks));
+        d->copy->dev = dev;
+        d->copy->timeout_s = env_timeout_s();
         d->transport = "device-copy";
+        // distinct devices: every rank reads its peers' regions directly (xGMI peer access)
+        for (int r = 0; r < nranks && distinct; r++) {
+            if (hipSetDevice(dev[r]) != hipSuccess) { delete d; return HJ_EHIP; }
+            for (int q = 0; q < nranks; q++) {
+                if (q == r) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev[r], dev[q]) != hipSuccess || !can) { delete d; return HJ_EHIP; }
+                const hipError_t e = hipDeviceEnablePeerAccess(dev[q], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { delete d; return HJ_EHIP; }
+                (void)hipGetLastError();
+            }
+        }
     }
     int rc = 0;
+    size_t wrapped = 0; // communicators handed to a rank (its RcclLink owns and destroys them)
     for (int r = 0; r < nranks && !rc; r++) {
         hj_dist_rank *k = new hj_dist_rank();
         d->ranks.push_back(k);
         k->rank = r; k->world = nranks; k->own_ctx = true;
         rc = hj_create(&k->c, dev[r]);
         if (rc) break;
-        if (distinct) { RcclLink *l = new RcclLink(); l->comm = comms[r]; l->rank = r; l->world = nranks; k->link.reset(l); }
+        if (use_rccl) { RcclLink *l = new RcclLink(); l->comm = comms[r]; l->rank = r; l->world = nranks; k->link.reset(l); wrapped = (size_t)r + 1; }
         else {
             CopyLink *l = new CopyLink(); l->g = d->copy.get(); l->rank = r; k->link.reset(l);
             if (hipSetDevice(dev[r]) != hipSuccess || hipEventCreateWithFlags(&d->copy->ready[r], hipEventDisableTiming) != hipSuccess) rc = HJ_EHIP;
         }
         if (!rc) rc = rank_init(k);
     }
-    if (rc) { hj_dist_destroy(d); return rc; }
+    if (rc) {
+        for (size_t r = wrapped; use_rccl && r < comms.size(); r++) if (comms[r]) (void)rccl().CommDestroy(comms[r]); // not owned by any rank yet
+        hj_dist_destroy(d);
+        return rc;
+    }
     *out = d;
     return HJ_OK;
 }
+
+int hj_dist_create(hj_dist **out, int nranks, const int *devices) { return hj_dist_create_transport(out, nranks, devices, nullptr); }
 
 int hj_dist_destroy(hj_dist *d) {
     if (!d) return HJ_EINVAL;
@@ -878,7 +1127,9 @@ int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg) {
     if (!d || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) { d->err = "at most 64 slices"; return HJ_EINVAL; }
     if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && d->world != 1)) { d->err = "phantom_world needs world size 1 and <= 512 shards"; return HJ_EINVAL; }
+    if (cfg->test_stall_rank > (uint32_t)d->world) { d->err = "test_stall_rank names no rank"; return HJ_EINVAL; }
     for (auto *k : d->ranks) k->cfg = *cfg;
+    if (d->copy) { std::lock_guard<std::mutex> lk(d->copy->mu); d->copy->timeout_s = cfg->timeout_ms ? cfg->timeout_ms * 1e-3 : env_timeout_s(); }
     return HJ_OK;
 }
 
@@ -928,13 +1179,36 @@ int hj_dist_unique_id(void *id128) {
 int hj_dist_rank_create(hj_dist_rank **out, hj_ctx *ctx, int rank, int world, const void *id128) {
     if (!out) return HJ_EINVAL;
     *out = nullptr;
-    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return HJ_EINVAL;
+    // the pipeline's fixed-size scratch (sizes, flags, all-reduce staging) and the split's LDS lines are laid out for <= 64 ranks
+    if (!ctx || !id128 || world < 1 || world > 64 || rank < 0 || rank >= world) return HJ_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HJ_EHIP;
+    if (!rccl().ok) return HJ_EHIP;
+    // ncclCommInitRank is collective and blocks until every rank has called it: it runs on a helper thread so that a rank that
+    // never arrives costs a deadline and a message, not a hang.  On expiry the helper is left behind (it cannot be cancelled).
+    struct Init { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto st = std::make_shared<Init>();
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
+    const int device = ctx->device;
+    std::thread([st, id, rank, world, device] {
+        (void)hipSetDevice(device);
+        ncclComm_t comm = nullptr;
+        const ncclResult_t res = rccl().CommInitRank(&comm, world, id, rank);
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->res = res; st->comm = comm; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        if (!st->cv.wait_for(lk, std::chrono::duration<double>(env_timeout_s()), [&] { return st->done; })) {
+            fprintf(stderr, "[hj_dist] rank %d of %d: deadline of %.1f s passed inside ncclCommInitRank: some rank never called hj_dist_rank_create "
+                            "(or the id did not reach it)\n", rank, world, env_timeout_s());
+            return HJ_EHIP;
+        }
+        if (st->res != ncclSuccess) return HJ_EHIP;
+    }
     RcclLink *l = new RcclLink();
-    l->rank = rank; l->world = world;
-    if (!rccl().ok || rccl().CommInitRank(&l->comm, world, id, rank) != ncclSuccess) { delete l; return HJ_EHIP; }
+    l->rank = rank; l->world = world; l->comm = st->comm;
     hj_dist_rank *k = new hj_dist_rank();
     k->c = ctx; k->rank = rank; k->world = world; k->link.reset(l);
     int rc = rank_init(k);
@@ -955,6 +1229,7 @@ int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg) {
     if (!r || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) return r->fail(HJ_EINVAL, "at most 64 slices");
     if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && r->world != 1)) return r->fail(HJ_EINVAL, "phantom_world needs world size 1 and <= 512 shards");
+    if (cfg->test_stall_rank > (uint32_t)r->world) return r->fail(HJ_EINVAL, "test_stall_rank names no rank");
     r->cfg = *cfg;
     return HJ_OK;
 }

@@ -86,13 +86,11 @@ struct JoinArgs {
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
-    uint32_t tag_extra;      // 16-bit tags at 14 / 15 radix bits: 2 / 1 key bits beyond the tag, folded into the bucket index
     uint64_t *wave_counts, *wave_agg;                     // count kernel outputs [items * JOIN_WAVES]
     const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
     int32_t *out_key, *out_bpay, *out_ppay;
     uint64_t out_cap;
     unsigned long long *out_cursor; // one-probe materialisation: next free output position (zeroed by k_join_plan)
-    uint32_t stage_cap;             // ... matches staged in LDS per flush
     // late materialisation: column-major extra columns gathered by row id on every match
     const int32_t *Db, *Dp;  // build side / probe side tables
     uint32_t ncb, ncp;       // columns to gather
@@ -122,7 +120,7 @@ hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, 
 hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy);
 hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, uint32_t nwg, bool any_heavy, bool any_light);
 hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
-                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received);
+                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received, uint64_t *received_self = nullptr);
 hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag);
 hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
@@ -136,9 +134,8 @@ hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(int device, size_t bytes);
 hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise (second probe, scanned positions), 2 late materialisation
-size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16, uint32_t stage_cap);
-hipError_t launch_join_mat(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16); // materialise in one probe, matches staged in LDS
-hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16); // ... matches held in registers (default)
+size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
+hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16); // materialise in ONE probe, matches held in registers
 hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max);
 hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, const int32_t *bp, const int32_t *pk, const int32_t *pp,
                              uint64_t np, int32_t *lookup, uint64_t range, uint64_t *out2);
@@ -153,8 +150,6 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
                                     const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
-hipError_t launch_ubench_handoff(hipStream_t st, const int32_t *ik, const int32_t *ip, int32_t *rk, int32_t *rp, uint64_t n_total,
-                                 uint64_t window, uint64_t ring, uint64_t *sink);
 hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts);
 
 } // namespace hj

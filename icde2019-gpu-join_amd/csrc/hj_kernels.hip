@@ -883,7 +883,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
 // me == 0xFFFFFFFF (phantom world, a one-GPU measurement mode): region q holds this rank's OWN shard q, i.e. sender slot (q, s).
 __global__ void k_dist_segments(const uint64_t *__restrict__ oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
                                 uint64_t *__restrict__ sbeg, uint64_t *__restrict__ send, uint32_t *__restrict__ flag,
-                                unsigned long long *__restrict__ received) {
+                                unsigned long long *__restrict__ received, unsigned long long *__restrict__ received_self) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * nsp) return;
     const uint32_t q = t / nsp, sidx = t % nsp;
@@ -895,12 +895,13 @@ __global__ void k_dist_segments(const uint64_t *__restrict__ oend, uint32_t G, u
     sbeg[(uint64_t)sidx * G + q] = b;
     send[(uint64_t)sidx * G + q] = b + fill;
     if (fill) atomicAdd(received, (unsigned long long)fill);
+    if (fill && received_self && q == (me == 0xFFFFFFFFu ? 0u : me)) atomicAdd(received_self, (unsigned long long)fill); // tuples that never crossed a link
 }
 
 hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
-                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received) {
+                                uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received, uint64_t *received_self) {
     hipLaunchKernelGGL(k_dist_segments, dim3((G * nsp + 255) / 256), dim3(256), 0, st, oend, G, nsp, cap, me, base, sbeg, send, flag,
-                       reinterpret_cast<unsigned long long *>(received));
+                       reinterpret_cast<unsigned long long *>(received), reinterpret_cast<unsigned long long *>(received_self));
     return hipGetLastError();
 }
 
@@ -1031,43 +1032,6 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
     return hipGetLastError();
 }
 
-// ---- hand-off ceiling: does a producer -> consumer hand-off through a window that fits the Infinity Cache (256 MiB) run
-// faster than the same hand-off through HBM?  Producer = k_ubench<1> (streamed input, 128-byte lines scattered inside the
-// window); consumer streams the window back (16 bytes per lane) and folds it into one word per workgroup. ----
-__global__ __launch_bounds__(256) void k_ubench_consume(const int4 *__restrict__ wk, const int4 *__restrict__ wp, uint64_t n16,
-                                                        unsigned long long *__restrict__ sink) {
-    uint32_t acc = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 512; base < n16; base += (uint64_t)gridDim.x * 512) {
-        int4 a[2], b[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
-            if (u < n16) { a[j] = wk[u]; b[j] = wp[u]; } else { a[j] = make_int4(0, 0, 0, 0); b[j] = a[j]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc += (uint32_t)(a[j].x ^ a[j].y ^ a[j].z ^ a[j].w ^ b[j].x ^ b[j].y ^ b[j].z ^ b[j].w);
-    }
-    acc = (uint32_t)wave_sum64(acc);
-    if (lane_id() == 0 && acc == 0x9E3779B9u) atomicAdd(sink, 1ull); // practically never: keeps the loads alive
-}
-
-// one round: producer over [in + r*W, +W) -> window (r mod nwin); consumer over that window
-hipError_t launch_ubench_handoff(hipStream_t st, const int32_t *ik, const int32_t *ip, int32_t *rk, int32_t *rp, uint64_t n_total,
-                                 uint64_t window, uint64_t ring, uint64_t *sink) {
-    const uint64_t w16 = window / 4, lines = w16 / 8; // window: a power of two of tuples
-    const uint64_t mul = 0x9E3779B97F4A7C15ULL | 1;
-    const uint64_t nwin = ring / window;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(16384, (w16 + 511) / 512);
-    for (uint64_t r = 0; r * window + window <= n_total; r++) {
-        const uint64_t wo = (r % nwin) * window;
-        hipLaunchKernelGGL((k_ubench<1, 2>), dim3(blocks), dim3(256), 0, st, (const int4 *)(ik + r * window), (const int4 *)(ip + r * window),
-                           (int4 *)(rk + wo), (int4 *)(rp + wo), w16, lines - 1, mul, 0);
-        hipLaunchKernelGGL(k_ubench_consume, dim3(blocks), dim3(256), 0, st, (const int4 *)(rk + wo), (const int4 *)(rp + wo), w16,
-                           reinterpret_cast<unsigned long long *>(sink));
-    }
-    return hipGetLastError();
-}
-
 // partition ranges from an offsets array (single-pass / unpartitioned layouts): beg[i] = off[i], end[i] = off[i+1]
 __global__ void k_range_from_offsets(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ beg, uint64_t *__restrict__ end) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1092,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, 
 // jp.cu:843-874, threshold = 2*bucket_size at hjcp.cu:904); no item when either side is empty.
 // bflag / pflag: overflow flags of relations whose histogram-free passes were queued (nullptr otherwise).  A raised
 // flag means the ranges are not valid: no items, the join kernels then do nothing and the host redoes the relation.
-// Thread 0 also zeroes the two result accumulators of k_sum2 and the output cursor of k_join_mat.
+// Thread 0 also zeroes the two result accumulators of k_sum2 and the output cursor of k_join_mat_reg.
 // Probe side in RANGES with several ranges per partition (sampled path): the ranges of partition p are r0[p] + j * stride,
 // j < nr[p].  Whole ranges are packed into LIST items of <= chunk probe tuples (the table of the partition is built once for all
 // of them); a range longer than a chunk is cut into chunk items as above.  emit(index, list, q0, q1): list items carry
@@ -1241,11 +1205,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     const uint64_t b0 = it.b0, nb = it.nb;
     const uint32_t nr = item_nranges(it); // probe ranges of the item (list items: several whole ranges share one table build)
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
-    // 16-bit tags with fewer than 16 radix bits (tag_extra = 1 or 2 more key bits than a tag holds): the top tag_extra bits of
-    // the key pick the upper part of the bucket index, so every chain holds keys that agree on them and comparing the 16 stored
-    // bits is exact (the reference's tag shortcut, jp.cu:1029, is exact only at >= 16 radix bits, D2)
-    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1;
-    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
+    // TAG16 only at >= 16 radix bits: what is left of a key then fits the 16 stored bits and the comparison is exact (the
+    // reference's tag shortcut, jp.cu:1029, is taken at any bit count, D2); below that the table stores full keys
+    auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; };
 
     uint64_t my_matches = 0, my_agg = 0;
     uint64_t cur = 0; // MAT: next output slot of this wave
@@ -1418,210 +1380,16 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     }
 }
 
-// ---- materialisation in ONE probe, matches staged in LDS (hj_config.lds_stage; the default is k_join_mat_reg below) ----
-// The reference's lead timed run writes its output in the same probe that finds the matches: matching lanes are ranked
-// by a ballot into a small shared-memory staging block and one reservation on a global counter is taken per flush
-// (join_partitioned_results, jp.cu:1228-1261, 1358-1388: 16 pairs per warp, one atomicAdd per 32 ints).  Same idea sized
-// for gfx950: the whole workgroup stages into ONE block of stage_cap matches in LDS (6 bytes per match: the probe
-// payload and the 16-bit slot of the build tuple in the LDS table — key and build payload are read back from the table at
-// flush time), so an item of the default size (one ~4096-tuple partition) takes ONE reservation of its exact match count
-// on the output cursor (2^30 matches: 2.6e5 returning atomics instead of the reference's 3.4e7) and leaves as three runs
-// of coalesced 4-byte-per-lane stores.  The output is gap-free, in no particular order (as in the reference: atomics decide).
-// Duplicates / probe chunks with more matches than the block holds: a wave that finds the block full keeps its chain
-// positions in registers and waits at the flush barrier; after the flush every wave resumes where it stopped.
-// LDS: head[nh] | ent[cap] | (full keys) next[cap] u16 | stage payload[stage_cap] u32 | stage slot[stage_cap] u16 | ctl[2][4].
-constexpr int MAT_R = 9;  // staged records a thread carries in registers across the reservation: 512 x 9 = 4608 = the default block
-template <bool TAG16>
-__global__ __launch_bounds__(JOIN_THREADS, 4) void k_join_mat(JoinArgs a) { // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t item = blockIdx.x;
-    if (item >= *a.n_items) return;
-    const uint32_t S = a.stage_cap;
-    uint32_t *head = reinterpret_cast<uint32_t *>(smem);
-    uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
-    uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
-    const size_t tbl = ((size_t)a.nh * 4 + (size_t)a.cap * 8 + (TAG16 ? 0 : (size_t)a.cap * 2) + 15) & ~(size_t)15;
-    uint32_t *sp = reinterpret_cast<uint32_t *>(smem + tbl);
-    uint16_t *ss = reinterpret_cast<uint16_t *>(smem + tbl + (size_t)S * 4);
-    uint32_t *ctl2 = reinterpret_cast<uint32_t *>(smem + tbl + (size_t)S * 4 + (((size_t)S * 2 + 15) & ~(size_t)15)); // 2 x {staged, paused, base lo, base hi}
-    uint32_t par = 0;
-
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
-    const JoinItem it = a.items[item];
-    const uint64_t b0 = it.b0, nb = it.nb, q0 = it.q0, q1 = it.q1;
-    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
-    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
-    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
-    const uint32_t smask = tx ? 0x1FFFu : 0xFFFFu; // staged slot word: slot | (top tag_extra key bits << 13) (cap < 8192 then)
-    const uint32_t plow = it.p & ~JOIN_ITEM_LIST; // (list items never reach this kernel) the partition id is the low `bits` key bits: a 16-bit tag + the id give the key back
-    const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
-
-    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
-        const uint64_t gb = b0 + bc;
-        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
-        const uint64_t wfirst = (q0 & ~(uint64_t)3) + (uint64_t)wave * 256;
-        int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
-        if (wfirst + (uint64_t)ln * 4 < q1) {
-            nk = load4(a.pk, wfirst + (uint64_t)ln * 4, a.p_nalloc);
-            np = load4(a.pp, wfirst + (uint64_t)ln * 4, a.p_nalloc);
-        }
-        for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
-        if (tid == 0) { ctl2[par * 4] = 0; ctl2[par * 4 + 1] = 0; }
-        __syncthreads();
-        // ---- build: as k_join ----
-        for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 3) {
-            int4 bkv[3], bpv[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                if (i < gb + nbc) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint64_t idx = i + e;
-                        if (idx >= gb && idx < gb + nbc) {
-                            const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                            const uint32_t old = atomicExch(&head[hidx(key)], slot);
-                            if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
-                            else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- probe, resumable: (w0, kv, pv, pos4) is the wave's position; a wave leaves the loop when it is done or when the
-        //      staging block is full, and comes back after the flush ----
-        uint64_t w0 = wfirst;
-        bool fresh = true;
-        int4 kv = make_int4(0, 0, 0, 0), pv = make_int4(0, 0, 0, 0);
-        uint32_t pos4[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-        for (;; par ^= 1u) {
-            uint32_t *ctl = ctl2 + par * 4; // staged, paused, base lo, base hi — the other parity's words are reset meanwhile
-            bool paused = false;
-            while (w0 < q1) { // wave-uniform
-                if (fresh) {
-                    const uint64_t i = w0 + (uint64_t)ln * 4;
-                    kv = nk; pv = np;
-                    const uint64_t inext = i + (uint64_t)JOIN_THREADS * 4;
-                    nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
-                    if (inext < q1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint64_t idx = i + e;
-                        const bool valid = idx >= q0 && idx < q1;
-                        pos4[e] = (valid ? head[hidx((uint32_t)elem(kv, e))] : 0xFFFFFFFFu) & 0xFFFFu;
-                    }
-                    fresh = false;
-                }
-                for (;;) {
-                    // the lane's four chains advance in lockstep (their LDS reads overlap) until each sits ON its next match
-                    // or has ended; pos4[e] stays on a match until the match has been staged
-                    uint32_t om = 0, nx4[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-                    for (;;) {
-                        bool walking = false;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const uint32_t pos = pos4[e];
-                            if (pos != 0xFFFFu && !((om >> e) & 1u)) {
-                                const uint32_t key = (uint32_t)elem(kv, e);
-                                const uint2 en = ent[pos];
-                                const uint32_t nx = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
-                                const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
-                                if (eq) { om |= 1u << e; nx4[e] = nx; }
-                                else { pos4[e] = nx; walking |= nx != 0xFFFFu; }
-                            }
-                        }
-                        if (!walking) break;
-                    }
-                    // all matches the wave sits on take their staging slots with ONE LDS atomic: chain-0 matches first, ...
-                    uint64_t m4[4];
-                    uint32_t n = 0, before[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { m4[e] = __ballot((om >> e) & 1u); before[e] = n; n += (uint32_t)__popcll(m4[e]); }
-                    if (!n) break; // every chain of every lane has ended: next 256 probe tuples
-                    uint32_t b = 0;
-                    if (ln == 0) b = atomicAdd(&ctl[0], n);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint32_t idx = b + before[e] + (uint32_t)__popcll(m4[e] & lt_mask);
-                        if (((om >> e) & 1u) && idx < S) {
-                            sp[idx] = (uint32_t)elem(pv, e);
-                            ss[idx] = (uint16_t)(pos4[e] | (tx ? (((uint32_t)elem(kv, e) >> bits) >> 16) << 13 : 0u));
-                            pos4[e] = nx4[e]; // staged: move on
-                        }
-                    }
-                    if (b + n > S) { paused = true; break; } // block full: the unstaged chains stay on their matches
-                }
-                if (paused) break;
-                w0 += (uint64_t)JOIN_THREADS * 4;
-                fresh = true;
-            }
-            if (paused && ln == 0) ctl[1] = 1u;
-            __syncthreads();
-            const uint32_t staged = ctl[0], again = ctl[1];
-            const uint32_t T = staged < S ? staged : S;
-            if (tid == 0) {
-                if (T) { // one reservation of the exact number of staged matches
-                    const unsigned long long base = atomicAdd(a.out_cursor, (unsigned long long)T);
-                    ctl[2] = (uint32_t)base; ctl[3] = (uint32_t)(base >> 32);
-                }
-                ctl2[(par ^ 1u) * 4] = 0; ctl2[(par ^ 1u) * 4 + 1] = 0; // the next round's counters
-            }
-            // while the reservation is in flight: the first MAT_R records of every thread leave LDS for registers (key and
-            // build payload from the table entry of the staged slot)
-            uint32_t rk[MAT_R], rb[MAT_R], rp[MAT_R];
-#pragma unroll
-            for (int r = 0; r < MAT_R; r++) {
-                const uint32_t i = tid + (uint32_t)r * JOIN_THREADS;
-                if (i < T) {
-                    const uint32_t sw = ss[i];
-                    const uint2 en = ent[sw & smask];
-                    rk[r] = TAG16 ? (((en.x >> 16) << bits) | plow | (tx ? (sw >> 13) << (bits + 16) : 0u)) : en.x;
-                    rb[r] = en.y;
-                    rp[r] = sp[i];
-                }
-            }
-            __syncthreads();
-            const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
-#pragma unroll
-            for (int r = 0; r < MAT_R; r++) {
-                const uint32_t i = tid + (uint32_t)r * JOIN_THREADS;
-                const uint64_t o = base + i;
-                if (i < T && o < a.out_cap) {
-                    a.out_key[o] = (int32_t)rk[r];
-                    a.out_bpay[o] = (int32_t)rb[r];
-                    a.out_ppay[o] = (int32_t)rp[r];
-                }
-            }
-            if (T > (uint32_t)MAT_R * JOIN_THREADS) { // a larger staging block than the registers cover (hj_config.lds_stage)
-                for (uint32_t i = tid + (uint32_t)MAT_R * JOIN_THREADS; i < T; i += JOIN_THREADS) {
-                    const uint32_t sw = ss[i];
-                    const uint2 en = ent[sw & smask];
-                    const uint64_t o = base + i;
-                    if (o < a.out_cap) {
-                        a.out_key[o] = (int32_t)(TAG16 ? (((en.x >> 16) << bits) | plow | (tx ? (sw >> 13) << (bits + 16) : 0u)) : en.x);
-                        a.out_bpay[o] = (int32_t)en.y;
-                        a.out_ppay[o] = (int32_t)sp[i];
-                    }
-                }
-                __syncthreads(); // workgroup-uniform: the staging block is free again only now
-            }
-            if (!again) break;
-        }
-        __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
-    }
-}
-
-// ---- materialisation in one probe, matches held in REGISTERS (the default) ----
-// k_join_mat above pays for its LDS staging block with occupancy (2 workgroups per CU instead of the count kernel's 3:
-// +0.8 ms at 2^30 x 2^30) and with a resumable probe loop.  Here nothing is staged in LDS: a lane keeps the up to 12 probe
-// tuples of a 6144-tuple sub-chunk (three 16-byte loads per column) in registers and, per ROUND, the slot of the next match of
+// ---- materialisation in ONE probe, matches held in REGISTERS ----
+// The reference's lead timed run writes its output in the same probe that finds the matches: matching lanes are ranked by a ballot
+// into a small shared-memory staging block and one reservation on a global counter is taken per flush (join_partitioned_results,
+// jp.cu:1228-1261, 1358-1388: 16 pairs per warp, one atomicAdd per 32 ints).  Sized for gfx950: ONE exact reservation on the output
+// cursor per round for the whole workgroup (an item of the default shape = one ~4096-tuple partition pair takes one returning atomic
+// of its exact match count: 2^30 matches = 2.6e5 atomics instead of the reference's 3.4e7), output gap-free, in no particular order
+// (as in the reference: atomics decide).  Round 3's first version staged the matches in a 27-KiB LDS block (k_join_mat: two
+// workgroups per CU instead of the count kernel's three, a resumable probe loop; 5.9-6.6 ms against 5.2-5.3 here; removed in round 4,
+// profiles/r3_materialize_breakdown.txt).  Here nothing is staged in LDS: a lane keeps the probe
+// tuples of a sub-chunk in registers and, per ROUND, the slot of the next match of
 // each of them.  A round = every tuple advances to its next match (four chains in lockstep) -> ballots rank the matches inside the
 // wave, the eight wave totals meet in LDS -> ONE exact reservation on the output cursor for the whole workgroup -> every wave
 // writes its matches as runs of coalesced 4-byte-per-lane stores (key and probe payload from registers, build payload from the
@@ -1649,8 +1417,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
     const uint64_t b0 = it.b0, nb = it.nb;
     const uint32_t nr = LISTS ? item_nranges(it) : 1u;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
-    const uint32_t tx = TAG16 ? a.tag_extra : 0u, lowb = (uint32_t)__builtin_ctz(a.nh) - tx, lowm = (1u << lowb) - 1; // see k_join
-    auto hidx = [&](uint32_t key) -> uint32_t { const uint32_t t = key >> bits; return tx ? ((t & lowm) | ((t >> 16) << lowb)) : (t & nhm); };
+    auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; }; // see k_join
     const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
     constexpr uint32_t END = 0xFFFFu;
 
@@ -2088,14 +1855,15 @@ hipError_t join_set_lds_limit(int device, size_t bytes) {
     return hipSuccess;
 }
 
-size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16, uint32_t stage_cap) {
+// LDS of the one-probe materialising kernel: the table + the per-round wave totals and the reserved output base
+size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16) {
     const size_t tbl = ((size_t)nh * 4 + (size_t)cap * 8 + (tag16 ? 0 : (size_t)cap * 2) + 15) & ~(size_t)15;
-    return tbl + (size_t)stage_cap * 4 + (((size_t)stage_cap * 2 + 15) & ~(size_t)15) + 32;
+    return tbl + 128;
 }
 
 hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16) {
     static size_t limit[64] = {};
-    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, 0) + 96;
+    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16);
     int dev = 0;
     (void)hipGetDevice(&dev);
     {
@@ -2118,29 +1886,6 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
         if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true, false>), g, b, lds, st, a);
         else hipLaunchKernelGGL((k_join_mat_reg<false, false>), g, b, lds, st, a);
     }
-    HJ_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t launch_join_mat(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16) {
-    static size_t limit[64] = {};
-    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16, a.stage_cap);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    {
-        std::lock_guard<std::mutex> lock(g_attr_mutex);
-        if (dev < 0 || dev >= 64 || lds > limit[dev]) {
-            const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat<true>), reinterpret_cast<const void *>(&k_join_mat<false>)};
-            for (const void *f : fns) {
-                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            if (dev >= 0 && dev < 64) limit[dev] = lds;
-        }
-    }
-    dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
-    if (tag16) hipLaunchKernelGGL((k_join_mat<true>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_join_mat<false>), g, b, lds, st, a);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

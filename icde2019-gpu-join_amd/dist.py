@@ -233,20 +233,23 @@ def _stats_dict(s):
             "slot_capacity": [int(s.slot_capacity[0]), int(s.slot_capacity[1])],
             "split_ms": [float(s.split_ms[0]), float(s.split_ms[1])], "pass1_ms": [float(s.pass1_ms[0]), float(s.pass1_ms[1])],
             "pass2_join_ms": float(s.pass2_join_ms), "first_split_ms": float(s.first_split_ms), "last_pass1_ms": float(s.last_pass1_ms),
-            "wall_ms": float(s.wall_ms), "early_pass2_join_ms": float(s.early_pass2_join_ms), "probe_groups": int(s.probe_groups), "balanced": bool(s.balanced)}
+            "wall_ms": float(s.wall_ms), "early_pass2_join_ms": float(s.early_pass2_join_ms), "probe_groups": int(s.probe_groups), "balanced": bool(s.balanced),
+            "exchange_ms": float(s.exchange_ms)}
 
 
 class GroupJoin:
     """hj_dist: ONE process drives every rank (one context + one host thread per rank).  devices[r] = HIP device of rank r;
     distinct devices talk over RCCL, ranks sharing a device over the in-process device-copy transport (tests)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, transport=None):
+        """transport: None / "auto" (RCCL for distinct devices, device copies for shared ones; $HJ_DIST_TRANSPORT), "rccl", "copy"."""
         self._L = _hjlib.lib()
         arr = (_C.c_int * len(devices))(*devices)
         h = _C.c_void_p()
-        rc = self._L.hj_dist_create(_C.byref(h), len(devices), arr)
+        rc = self._L.hj_dist_create_transport(_C.byref(h), len(devices), arr, transport.encode() if transport else None)
         if rc:
-            raise _HJError(rc, "hj_dist_create(%r) failed (fewer GPUs visible than ranks, or no GPU)" % (list(devices),))
+            raise _HJError(rc, "hj_dist_create_transport(%r, %r) failed (fewer GPUs visible than ranks, no GPU, or a transport the devices "
+                               "do not allow)" % (list(devices), transport))
         self._h = h
         self.world = len(devices)
         self._keep = {}
@@ -285,9 +288,11 @@ class GroupJoin:
         hj.close = lambda: None   # never destroyed from here
         return hj
 
-    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False):
+    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False,
+                  timeout_ms=0, test_stall_rank=0):
         cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link), phantom_world=phantom_world,
-                                single_group=int(single_group), balance_size=int(balance_size))
+                                single_group=int(single_group), balance_size=int(balance_size), timeout_ms=int(timeout_ms),
+                                test_stall_rank=int(test_stall_rank))
         self._ck(self._L.hj_dist_configure(self._h, _C.byref(cfg)))
 
     def bind(self, rank, rel, keys, pays, n=None):
@@ -340,9 +345,10 @@ class RankJoin:
             self._L.hj_dist_rank_destroy(self._h)
             self._h = None
 
-    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False):
+    def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False,
+                  timeout_ms=0):
         cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link), phantom_world=phantom_world,
-                                single_group=int(single_group), balance_size=int(balance_size))
+                                single_group=int(single_group), balance_size=int(balance_size), timeout_ms=int(timeout_ms))
         self._ck(self._L.hj_dist_rank_configure(self._h, _C.byref(cfg)))
 
     def join(self, Rk, Rp, Sk, Sp, verify=False):

@@ -83,10 +83,10 @@ class HashJoin:
         self._ck(self._L.hj_set_stream(self._h, own if stream is None else C.c_void_p(int(stream))))
 
     def configure(self, bits1=0, bits2=0, force_bits=False, build_side=0, lds_capacity=0, lds_heads=0,
-                  probe_chunk=0, exact_only=False, materialize_two_pass=False, lds_stage=0, graph=False):
+                  probe_chunk=0, exact_only=False, materialize_two_pass=False, graph=False):
         cfg = _lib.Config(bits1=bits1, bits2=bits2, force_bits=int(force_bits), build_side=build_side,
                           lds_capacity=lds_capacity, lds_heads=lds_heads, probe_chunk=probe_chunk,
-                          exact_only=int(exact_only), materialize_two_pass=int(materialize_two_pass), lds_stage=lds_stage, graph=int(graph))
+                          exact_only=int(exact_only), materialize_two_pass=int(materialize_two_pass), graph=int(graph))
         self._ck(self._L.hj_configure(self._h, C.byref(cfg)))
 
     def config(self):
@@ -136,6 +136,15 @@ class HashJoin:
         m, a = C.c_uint64(), C.c_uint64()
         self._ck(self._L.hj_join(self._h, C.byref(m), C.byref(a)))
         return m.value, a.value
+
+    def last_call_breakdown(self):
+        """Host-side breakdown of the last join() call (hj_last_call_breakdown), ms."""
+        a, f, s, tt = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        n = C.c_uint32()
+        self._ck(self._L.hj_last_call_breakdown(self._h, C.byref(a), C.byref(n), C.byref(f), C.byref(s), C.byref(tt)))
+        return {"allocation_ms": round(a.value, 3), "allocations": n.value, "failed_optimistic_attempt_ms": round(f.value, 3),
+                "sample_and_plan_ms": round(s.value, 3), "total_ms": round(tt.value, 3),
+                "rest_ms (the step that answered)": round(tt.value - a.value - f.value - s.value, 3)}
 
     def join_late_materialize(self, d_Dr, ncolR, strideR, d_Ds, ncolS, strideS):
         """Row-id payloads + gather of extra columns on every match (jp.cu:1420-1557)."""
@@ -319,13 +328,6 @@ class HashJoin:
         self._ck(self._L.hj_ubench(self._h, {"copy": 0, "line_scatter": 1}[kind], _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(out_k),
                                    _dev_ptr(out_p), n, reps, C.byref(ms), C.byref(nb)))
         return nb.value / (ms.value * 1e-3) / 1e9
-
-    def ubench_handoff(self, in_k, in_p, ring_k, ring_p, n, window, ring, reps=3):
-        """Producer -> consumer hand-off through a window of a ring (hj_ubench_handoff).  Returns (ms per repetition, GB/s)."""
-        ms, nb = C.c_double(), C.c_uint64()
-        self._ck(self._L.hj_ubench_handoff(self._h, _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(ring_k), _dev_ptr(ring_p), n, window, ring,
-                                           reps, C.byref(ms), C.byref(nb)))
-        return ms.value, nb.value / (ms.value * 1e-3) / 1e9
 
     def digest_pairs(self, d_keys, d_pays, n):
         d = C.c_uint64()

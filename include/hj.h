@@ -56,14 +56,13 @@ typedef struct hj_config {
                             * bump-allocated buckets of jp.cu:138-192 without their atomics) and falls back to the exact
                             * passes when skew overflows a slot (the overflow flag travels with the join's result block; a
                             * flagged relation is re-partitioned and the join re-run inside the same call). */
-    uint32_t materialize_two_pass; /* 0: hj_join_materialize writes the output in ONE probe (matches staged in LDS, one
-                            * reservation on a global output cursor per flush, as join_partitioned_results jp.cu:1228-1261 does
-                            * per warp).  1: count, scan, second probe writing at the scanned positions — no output atomics, the
-                            * order of the output is a function of the partitions alone. */
-    uint32_t lds_stage;    /* one-probe materialisation: 0 = matches are held in registers (10 probe tuples per lane, one output
-                            * reservation per round of a 5120-tuple sub-chunk; LDS holds the table alone: 3 workgroups per CU).
-                            * N in [64, 16384] = the variant that stages matches in an LDS block of N matches (one reservation per
-                            * flush; 2 workgroups per CU; measured 20 % slower at 2^30 x 2^30) */
+    uint32_t materialize_two_pass; /* 0: hj_join_materialize writes the output in ONE probe (matches held in registers — 10 probe tuples
+                            * per lane, one exact reservation on a global output cursor per round of a 5120-tuple sub-chunk — where
+                            * join_partitioned_results jp.cu:1228-1261 reserves per warp; LDS holds the table alone: 3 workgroups per CU).
+                            * 1: count, scan, second probe writing at the scanned positions — no output atomics, the order of the
+                            * output is a function of the partitions alone; also what the streaming materialising path uses per
+                            * segment, whose output columns are sized from the count. */
+    uint32_t reserved0;    /* was lds_stage (round 3's LDS-staged one-probe kernel, measured 20 % slower, removed); must be 0 */
     uint32_t graph;        /* 1: hj_join replays the whole step (both partition passes, plan, build+probe, result copy) from a
                             * captured hipGraph — one host call per step instead of ~14-22 launches; pays below ~2^24 tuples,
                             * where a step is bound by the host's launch rate.  The first call on a binding runs eagerly, the second
@@ -203,6 +202,13 @@ int hj_get_partitions(hj_ctx *ctx, int rel, const int32_t **d_keys, const int32_
  * probe-side relation (histogram-free passes with capacities from a sample; a partition is then a list of ranges), 0 if from
  * the exact passes. [sync] */
 int hj_partition_layout(hj_ctx *ctx, int rel, int *slotted);
+/* Host-side breakdown of the most recent hj_join call, ms of wall time: device (re)allocations (hipFree + hipMalloc inside the
+ * library, and how many), the optimistic histogram-free attempt that came back with an overflow flag (0 if none did), sampling pass +
+ * host planning + table upload of the sampled path (0 unless this call planned one), and the whole call.  What a FIRST call on a
+ * skewed binding spends where (the reference allocates outside its timed region too, hjcp.cu:815-879; a one-join-per-process CLI
+ * user still waits for it). */
+int hj_last_call_breakdown(const hj_ctx *ctx, double *alloc_ms, uint32_t *allocations, double *failed_attempt_ms,
+                           double *sample_plan_ms, double *total_ms);
 int hj_enable_timings(hj_ctx *ctx, int level); /* 0 off, 1 data-moving kernels, 2 every launch.  [sync] */
 int hj_timings_reset(hj_ctx *ctx);
 /* [sync] fills up to cap entries, returns the number of kernels known in *n. */
@@ -249,13 +255,6 @@ int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_
  *      flush).  avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
 int hj_ubench(hj_ctx *ctx, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p,
               uint64_t n, uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch);
-
-/* Hand-off ceiling: per round, a producer streams window_tuples of the input and stores them as scattered 128-byte lines into a
- * window of a ring of ring_tuples (ring == window: the same window every round, small enough to stay in the 256 MiB Infinity
- * Cache; ring >> cache: every round a window that has long left it), then a dependent consumer kernel streams that window back.
- * n / window rounds per repetition; avg_ms per repetition, bytes = 24 per tuple (input read, window write, window read).  [sync] */
-int hj_ubench_handoff(hj_ctx *ctx, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_ring_k, int32_t *d_ring_p, uint64_t n,
-                      uint64_t window_tuples, uint64_t ring_tuples, uint32_t reps, double *avg_ms, uint64_t *bytes_per_rep);
 
 /* ---- generator_ETHZ drop-in (host side; src/generator_ETHZ.cuh:11-23) ----
  * Same generators, same raw-int32 .bin cache format; the time(NULL)/rand() global state of the

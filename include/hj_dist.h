@@ -50,7 +50,11 @@ typedef struct hj_dist_config {
     uint32_t balance_size;  /* 1: size-aware shard assignment on the exact path even when no skew has been seen (8 virtual shards per
                              * GPU, dealt longest-first by |R|+|S|).  It is switched on by itself once a join on the same columns
                              * overflowed a slot somewhere. */
-    uint32_t reserved[2];
+    uint32_t timeout_ms;    /* deadline of every wait on a collective (all-gather of the sizes, the drained exchange pipeline, the
+                             * all-reduce of the result, ncclCommInitRank); 0 = $HJ_DIST_TIMEOUT_S seconds, or 120 s.  On expiry the call
+                             * returns HJ_EHIP and hj_dist(_rank)_error names the rank, the stage, the slices whose exchange has not
+                             * completed and the peers a message is owed by; the group is unusable afterwards (create a new one). */
+    uint32_t test_stall_rank; /* tests: rank test_stall_rank - 1 stops taking part in the exchange for 2.5 deadlines (a stalled peer) */
 } hj_dist_config;
 
 typedef struct hj_dist_stats {
@@ -69,7 +73,10 @@ typedef struct hj_dist_stats {
     float early_pass2_join_ms; /* pass 2 of the build side + pass 2 and build/probe of the probe side's earlier slices (under the exchange) */
     uint32_t probe_groups;
     uint32_t balanced;         /* exact path: 1 if the shards were assigned to GPUs by size */
-    uint32_t reserved[5];
+    float exchange_ms;         /* sliced path: device time on the communication stream from the start of the first slice's exchange to
+                                * the end of the last one's (HIP events): link_bytes / (world - 1) / exchange_ms = the rate ONE link
+                                * direction sustained, to be held against its 76.8 GB/s */
+    uint32_t reserved[4];
 } hj_dist_stats;
 
 /* ---- one process, G ranks ---- */
@@ -77,6 +84,11 @@ typedef struct hj_dist_stats {
  * refuses duplicate GPUs; test mode on a one-GPU box): the same pipeline over an in-process device-copy transport.
  * HJ_EINVAL if nranks < 1 or a device is not visible (`bench --gpus N` on a box with fewer than N GPUs fails here). */
 int hj_dist_create(hj_dist **out, int nranks, const int *devices);
+/* The same with the transport chosen by the caller: "rccl" (distinct devices only), "device-copy" = "copy" (ranks pull each other's
+ * regions with hipMemcpyAsync / hipMemcpyPeerAsync: the copy engines instead of RCCL's kernels — no CU, no LDS taken from the
+ * 155-KiB-LDS pass workgroups that run beside the exchange; peer access is enabled between distinct devices), or NULL / "" / "auto"
+ * = $HJ_DIST_TRANSPORT, else rccl for distinct devices and device-copy for shared ones (what hj_dist_create does). */
+int hj_dist_create_transport(hj_dist **out, int nranks, const int *devices, const char *transport);
 int hj_dist_destroy(hj_dist *d);
 const char *hj_dist_error(const hj_dist *d);
 int hj_dist_world(const hj_dist *d);

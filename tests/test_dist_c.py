@@ -153,6 +153,108 @@ def test_default_geometry_at_2p24():
     assert all(s["path"] == "sliced" for s in st) and sum(s["received"][0] for s in st) == 2 * n, st
 
 
+def _bind_group(g, P, world, R, S, misalign_rank=None):
+    """Even cuts of R and S over the ranks of a group on cuda:0; misalign_rank: that rank's S key column starts 4 bytes off a
+    16-byte boundary (hj_dist_rank_join refuses it before its first collective)."""
+    import torch
+    keep = []
+    for r in range(world):
+        cols = []
+        for X in (R, S):
+            a, b = len(X) * r // world, len(X) * (r + 1) // world
+            k = torch.from_numpy(np.ascontiguousarray(X[a:b])).cuda()
+            cols += [k, torch.ones_like(k)]
+        if r == misalign_rank:
+            pad = torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda"), cols[2]])
+            cols[2] = pad[1:]
+        keep.append(cols)
+        g.bind(r, P.REL_R, cols[0], cols[1], n=int(cols[0].numel()))
+        g.bind(r, P.REL_S, cols[2], cols[3], n=int(cols[2].numel()))
+    return keep
+
+
+@pytest.mark.parametrize("world,stall", [(2, 1), (3, 0)])
+def test_a_stalled_peer_hits_the_deadline_instead_of_hanging(world, stall):
+    """no wait of the multi-GPU path blocks for ever.  One rank stops taking part in the exchange of S's
+    first slice for 2.5 deadlines (hj_dist_config.test_stall_rank); the others give up at the deadline with a message that says
+    who waited for whom and where, the stalled rank finds the group aborted when it comes back, hj_dist_join returns an error —
+    and the group refuses further joins (a communicator with a collective that was given up is not reused)."""
+    import time
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(200_000, 400_000, 21, "unique")
+    with D.GroupJoin([0] * world) as g:
+        for r in range(world):
+            g.context(r).configure(bits1=5, bits2=4)
+        keep = _bind_group(g, P, world, R, S)
+        g.configure(slices=3, timeout_ms=1000)
+        assert g.join()[0] == len(S)                       # healthy first: the deadline does not fire on a working group
+        g.configure(slices=3, timeout_ms=1000, test_stall_rank=stall + 1)
+        t0 = time.time()
+        with pytest.raises(P.HJError) as ei:
+            g.join()
+        dt = time.time() - t0
+        msg = str(ei.value)
+        assert "deadline" in msg and "rank" in msg and ("waited for rank(s) %d" % stall) in msg, msg
+        assert 0.9 < dt < 8.0, dt                          # the deadline (1 s) and the stalled rank's return (2.7 s), not minutes
+        g.configure(slices=3, timeout_ms=1000)
+        with pytest.raises(P.HJError) as ei2:
+            g.join()
+        assert "aborted" in str(ei2.value)
+        del keep
+    with D.GroupJoin([0] * world) as g:                    # a fresh group on the same device works
+        for r in range(world):
+            g.context(r).configure(bits1=5, bits2=4)
+        keep = _bind_group(g, P, world, R, S)
+        assert g.join()[0] == len(S)
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_join():
+    """a rank that fails locally must not leave its peers inside a collective.  Rank 1's S keys are not 16-byte aligned:
+    it fails before its first collective; ranks 0 and 2 are waiting in the all-gather of the sizes and leave at once — long before
+    the 60-s deadline — with an error that names rank 1."""
+    import time
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(100_000, 300_000, 22, "unique")
+    with D.GroupJoin([0, 0, 0]) as g:
+        keep = _bind_group(g, P, 3, R, S, misalign_rank=1)
+        g.configure(timeout_ms=60_000)
+        t0 = time.time()
+        with pytest.raises(P.HJError) as ei:
+            g.join()
+        assert time.time() - t0 < 20.0
+        assert "rank 1" in str(ei.value) and "aligned" in str(ei.value), str(ei.value)
+        del keep
+
+
+def test_transport_is_selectable():
+    """hj_dist_create_transport: device copies on request (what a multi-GPU node A/Bs against RCCL's kernels), RCCL refused for
+    ranks that share a device, unknown names refused; world 1 runs over either."""
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(150_000, 350_000, 23, "unique")
+    for transport, devices, expect in (("copy", [0], "device-copy"), ("rccl", [0], "rccl"), ("device-copy", [0, 0], "device-copy"), (None, [0, 0], "device-copy")):
+        with D.GroupJoin(devices, transport=transport) as g:
+            assert g.transport == expect
+            for r in range(len(devices)):
+                g.context(r).configure(bits1=5, bits2=4)
+            keep = _bind_group(g, P, len(devices), R, S)
+            g.configure(slices=2, self_via_link=True)
+            assert g.join()[0] == len(S)
+            st = g.stats(0)
+            assert st["path"] == "sliced" and st["exchange_ms"] > 0
+            # tuples among the link bytes: what the rank sent to others (nothing at world 1)
+            if len(devices) == 1:
+                assert st["payload_bytes"] == 0
+            else:
+                assert 0 < st["payload_bytes"] <= st["link_bytes"], st
+            del keep
+    for bad in (("rccl", [0, 0]), ("smoke-signals", [0])):
+        with pytest.raises(P.HJError):
+            D.GroupJoin(bad[1], transport=bad[0])
+
+
 def test_more_ranks_than_gpus_is_refused():
     P = pkg()
     D = import_module(P.__name__ + ".dist")

@@ -54,13 +54,6 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
             # ... on fresh partitions with no count before it (the timed shape: partition both, materialise) ...
             hj.partition_both()
             check(*hj.join_materialize(cap=em), "one probe, no count")
-            # ... with the LDS-staged variant of the kernel: a block of the default size, and one so small that every wave stops
-            # and resumes many times ...
-            for stage in (4608, 64):
-                hj.configure(**dict(cfg or {}, lds_stage=stage))
-                hj.partition(P.REL_R)
-                hj.partition(P.REL_S)
-                check(*hj.join_materialize(cap=em), "one probe, %d-match LDS staging block" % stage)
             # ... and the two-probe path (count, scan, second probe at scanned positions)
             hj.configure(**dict(cfg or {}, materialize_two_pass=True))
             assert hj.join() == (em, eagg)
@@ -236,21 +229,16 @@ def test_skew_heavy_hitters(P):
         _check_join(P, R, np.arange(n, dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
 
 
-@pytest.mark.parametrize("tag_extra", [None, "2"])
-def test_tag16_vs_full_key_paths(P, monkeypatch, tag_extra):
-    # 16+ radix bits → 16-bit tags (the reference's compression, jp.cu:1029); fewer → full keys — or, with HJ_TAG_EXTRA (an
-    # experiment knob read at hj_create; measured no faster, profiles/r3_tag_extra_ab.txt), 16-bit tags also at 15 / 14 radix
-    # bits with the one / two key bits a tag cannot hold folded into the bucket index.
-    if tag_extra:
-        monkeypatch.setenv("HJ_TAG_EXTRA", tag_extra)
+def test_tag16_vs_full_key_paths(P):
+    # 16+ radix bits → 16-bit tags (the reference's compression, jp.cu:1029, exact only then: D2); fewer → full keys
     rng = np.random.default_rng(11)
     R = rng.integers(-2**31, 2**31 - 1, 1 << 16).astype(np.int32)
     S = np.concatenate([R[: 1 << 15], rng.integers(-2**31, 2**31 - 1, 1 << 15).astype(np.int32)])
     # keys that agree in the low bits and in the hash slot bits but differ above must not match
     R[:4] = [0x00010000, 0x10010000, 0x20010000, 0x30010000]
     S[:2] = [0x40010000, 0x10010000]
-    # keys that differ ONLY in the one or two top bits a 16-bit tag cannot hold at 15 / 14 radix bits (folded into the bucket
-    # index there): same partition, same tag, same low bucket bits — must not match
+    # keys that differ ONLY in the one or two top bits a 16-bit tag could not hold at 15 / 14 radix bits: same partition, same
+    # low 16 remaining bits — must not match (full keys are compared there)
     R[4:8] = [0x00012345, -0x7FFEDCBB, 0x40012345, -0x3FFEDCBB]       # 0x00012345 | top bits 00, 10, 01, 11
     S[2:5] = [-0x7FFEDCBB, 0x40012345, 0x00012345 | 0x20000000]
     R[8:10] = [-2**31, 2**31 - 1]

@@ -173,11 +173,6 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
         assert hj.join() == (em, eagg)
         k, pr, ps = hj.join_materialize()
         assert o.triples_checksum(k, pr, ps) == echk
-        # the LDS-staging kernel takes no list items: the plan falls back to one item list per range
-        hj.configure(**dict(cfg or {}, lds_stage=4608))
-        assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
-        k, pr, ps = hj.join_materialize()
-        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
         # small probe chunks: runs of whole ranges are closed when the next range would not fit, long ranges are cut
         hj.configure(**dict(cfg or {}, probe_chunk=3000))
         assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
