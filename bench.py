@@ -127,10 +127,10 @@ def bench_zipf(a, pkg, torch, dev, local):
     """BASELINE configs[3]: PK-FK 2^27 x 2^31, Zipf(1.0) foreign keys, one GPU.  Reported in DESIGN.md; not the headline line.
     The first join on a fresh binding is timed on its own: it finds S's slots overflowing, samples the key distribution and
     builds the capacity tables; the steady-state steps (what `value` is) reuse them."""
-    nR, nS = 1 << 27, 1 << 31
+    nR, nS = 1 << a.zipf_sizes[0], 1 << a.zipf_sizes[1]
     hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
-    if a.probe_chunk or a.exact_only:
-        hj.configure(probe_chunk=a.probe_chunk, exact_only=a.exact_only)
+    if a.probe_chunk or a.exact_only or a.build_side:
+        hj.configure(probe_chunk=a.probe_chunk, exact_only=a.exact_only, build_side=a.build_side)
     Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
     Sk, Sp = (torch.empty(nS, dtype=torch.int32, device=dev) for _ in range(2))
     hj.gen_unique(Rk, nR, 0, nR, 3)
@@ -235,14 +235,15 @@ def bench_zipf(a, pkg, torch, dev, local):
                         "algorithmic_bytes_per_launch": 8.0 * (nR + nS) + 12.0 * nout})
         del ok, opr, ops
     cpu = None if a.no_cpu_baseline else zipf_cpu_baseline(hj, torch, dev)
-    print(json.dumps({"metric": "billion tuples/sec (build+probe), PK-FK 2^27 x 2^31 Zipf theta=1.0, 1 GPU",
+    print(json.dumps({"metric": "billion tuples/sec (build+probe), PK-FK 2^%d x 2^%d Zipf theta=1.0, 1 GPU%s" % (a.zipf_sizes[0], a.zipf_sizes[1], ", the Zipf side BUILDS" if a.build_side == 2 else ""),
                       "value": round((nR + nS) * a.steps / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                       "dtype": "int32", "data": "synthetic", "vs_baseline": None,
                       "first_call_ms": round(first_ms, 3), "first_call_split_ms": first_split,
                       "first_call": "optimistic histogram-free attempt on S (overflows) + sampling pass + host-side capacity tables + the step itself; "
                                     "later steps on the same binding reuse the tables",
-                      "config": {"workload": "PK-FK 2^27 x 2^31, Zipf(1.0) foreign keys (device generator), payload=1, count-only",
+                      "config": {"workload": "PK-FK 2^%d x 2^%d, Zipf(1.0) foreign keys (device generator), payload=1, count-only" % tuple(a.zipf_sizes),
+                                 "build_side": hj.config()["build_side"],
                                  "matches": int(got), "radix_bits": [hj.config()["bits1"], hj.config()["bits2"]],
                                  "partition_layout_R_S": layout},
                       "roofline": roof, "probe_phase": probe, "kernels": kernels, "materialize": mat, "cpu_baseline": cpu, "lib_sha256": lib_sha256()}))
@@ -438,6 +439,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=30, help="tuples per relation per GPU = 2^log2n")
     ap.add_argument("--workload", choices=["uniform", "zipf", "stream", "coprocess", "baselines"], default="uniform",
                     help="uniform = BASELINE configs[2] (the headline); zipf = configs[3]: 2^27 x 2^31 PK-FK, Zipf theta 1.0 (N=1 only)")
+    ap.add_argument("--zipf-sizes", type=int, nargs=2, default=[27, 31], help="--workload zipf: log2 of |R| (unique keys) and |S| (Zipf foreign keys); default = BASELINE configs[3]")
+    ap.add_argument("--build-side", type=int, default=0, help="hj_config.build_side: 0 = the smaller relation, 1 = R, 2 = S (--workload zipf: the skewed side builds)")
     ap.add_argument("--probe-chunk", type=int, default=0, help="experiment knob: hj_config.probe_chunk")
     ap.add_argument("--bits", type=int, nargs=2, default=None, help="experiment knob: radix bits of pass 1 and 2")
     ap.add_argument("--lds", type=int, nargs=2, default=None, help="experiment knob: LDS table capacity and heads of the join kernel")

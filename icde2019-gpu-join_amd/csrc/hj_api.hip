@@ -165,7 +165,10 @@ void choose_bits(hj_ctx *c) {
         if (!c->bits1) { c->bits1 = c->bits2; c->bits2 = 0; }
         return;
     }
-    uint64_t nb = c->rel[c->build].n;
+    // The partition count follows the SMALLER relation — which is the build relation unless hj_config.build_side names the larger one:
+    // then the table side is chosen per partition (general items, plan_join), which makes the smaller partition build after all.
+    // (The streaming probe path partitions R once for segments of any size: its bits follow |R|.)
+    uint64_t nb = c->force_build_r ? c->rel[c->build].n : std::min(nR, nS);
     uint32_t total = nb > TARGET_PART ? ceil_log2((nb + TARGET_PART - 1) / TARGET_PART) : 0;
     if (total > 18) total = 18;
     if (total <= 9) {
@@ -537,8 +540,9 @@ int partition_rel(hj_ctx *c, int r) {
     R.flag_known_good = false;
     R.part_off = nullptr;
     R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
-    // known to be skewed, and on the probe side (the build side needs one range per partition): the sampled path
-    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 15 && c->fast_path && !c->cfg.exact_only && r != c->build &&
+    // known to be skewed: the sampled path — on either side of the join since round 4 (a build partition that is a list of ranges
+    // is built into the LDS table piece by piece: general items, plan_join)
+    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 15 && c->fast_path && !c->cfg.exact_only &&
         R.n >= ((uint64_t)1 << 20)) {
         bool done = false;
         RET(partition_sampled(c, r, b1, b2, flag, &done));
@@ -646,25 +650,38 @@ int exact_for_introspection(hj_ctx *c, Rel &R) {
 }
 
 // work-item list of the current partitions: k_join_plan + scan + k_join_expand (decompose_chains, jp.cu:843-874)
-int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
+// gen_ok: the kernel that follows takes general items (the count kernel and the one-probe materialiser do; the second probe of the
+// two-probe path and the late-materialising kernel do not: a sampled build side is redone with the exact passes for them)
+int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok = true) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
+    if (B.sampled && !gen_ok) {
+        B.force_exact = true;
+        const int rc = partition_rel(c, c->build);
+        B.force_exact = false;
+        RET(rc);
+    }
     if (B.nparts != Pb.nparts || B.pb1 + B.pb2 != Pb.pb1 + Pb.pb2)
         return fail(c, HJ_EINVAL, "relations were partitioned with different radix bits (%u+%u vs %u+%u): partition both after loading both",
                     B.pb1, B.pb2, Pb.pb1, Pb.pb2);
     hipStream_t st = c->stream;
-    if (B.sampled) return fail(c, HJ_EHIP, "internal: the build side must have one range per partition");
-    // sampled probe side: several ranges per partition.  Whole ranges are packed into list items (one table build for all of them);
-    // the LDS-staging kernel does not take list items: one item list per range there
+    // A build relation known to be skewed (its slots overflowed once): GENERAL items.  Its partitions may be lists of ranges (sampled
+    // path) that are built into the LDS table piece by piece, and a build partition that does not fit the table while the other
+    // side's is smaller is joined with the roles flipped (jp.cu:929-1003) — one item per chunk of the big side instead of one
+    // workgroup looping over hundreds of table chunks.
+    // The same items serve a designated build relation that is the LARGER one (hj_config.build_side): the radix bits follow the smaller
+    // relation (choose_bits), so its partitions would not fit the table either.
+    const bool general = gen_ok && (B.sampled || B.prefer_exact || B.n > Pb.n);
+    // sampled probe side: several ranges per partition.  Whole ranges are packed into list items (one table build for all of them)
     const bool lists = Pb.sampled && Pb.pr0;
-    const uint32_t nparts = lists ? Pb.nparts : Pb.nranges; // planning threads: partitions, or probe RANGES (== partitions unless sampled)
+    const uint32_t nparts = (lists || general) ? Pb.nparts : Pb.nranges; // planning threads: partitions, or probe RANGES (== partitions unless sampled)
     const uint32_t rbits = B.pb1 + B.pb2;
     // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2): what is left of a key fits the 16 stored bits.  Below that
     // the table stores full keys.  (Round 3 also built 16-bit tags at 14 / 15 radix bits, the extra key bits folded into the bucket
     // index: parity-green, measured no faster than full keys, removed — profiles/r3_tag_extra_ab.txt.)
     tag16 = rbits >= 16 && c->nh >= 16;
-    const uint64_t max_items64 = (uint64_t)Pb.nranges + Pb.n / c->chunk + 1;
+    const uint64_t max_items64 = (uint64_t)Pb.nranges + Pb.n / c->chunk + 1 + (general ? (uint64_t)B.nranges + B.n / c->chunk + 1 : 0); // flipped partitions are cut on the build relation
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
     RET(ensure(c, c->items_cnt, (size_t)nparts * 4));
@@ -687,13 +704,15 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
     a.pk = Pb.part_k; a.pp = Pb.part_p; a.pbeg = Pb.part_beg; a.pend = Pb.part_end; a.p_nalloc = Pb.n_alloc;
     a.rpart = Pb.sampled && !lists ? Pb.rpart : nullptr;
     if (lists) { a.pr0 = Pb.pr0; a.pnr = Pb.pnr; a.rstride = Pb.rstride; }
+    if (B.sampled) { a.br0 = B.pr0; a.bnr = B.pnr; a.bstride = B.rstride; }
+    a.general = general ? 1u : 0u;
     a.items = (const JoinItem *)c->items.p;
     a.n_items = sc + 0;
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
-    if (nparts <= 16384 && !Pb.sampled) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
+    if (nparts <= 16384 && !Pb.sampled && !general) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
         Timed t(c, "k_join_plan");
         HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, sc + 10, sc + 0));
     } else {
@@ -710,7 +729,9 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16) {
 
 // work-item list + per-wave counts (the scan of the counts is only run when the two-probe materialising path follows)
 int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nullptr) {
-    RET(plan_join(c, a_out, tag16));
+    // general items are for the count kernel and the one-probe materialiser; the late-materialising kernel and a count whose wave
+    // counts feed the second probe of the two-probe path want plain items
+    RET(plan_join(c, a_out, tag16, !late && !c->cfg.materialize_two_pass && !c->plain_items));
     JoinArgs &a = a_out;
     hipStream_t st = c->stream;
     uint64_t *sc = (uint64_t *)c->scalars.p;
@@ -1332,6 +1353,8 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
     c->rel[HJ_REL_S].sampled_failed = false; c->rel[HJ_REL_S].sp.valid = false;
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
+    const bool saved_plain = c->plain_items;
+    c->plain_items = h_out != nullptr; // the per-segment second probe reads plain items
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
     c->rel[HJ_REL_S].in_k = (const int32_t *)c->seg_k[0].p;
     c->rel[HJ_REL_S].in_p = (const int32_t *)c->seg_p[0].p;
@@ -1451,6 +1474,7 @@ done:
     (void)hipStreamSynchronize(c->copy);
     if (c->d2h) (void)hipStreamSynchronize(c->d2h);
     c->force_build_r = saved_force;
+    c->plain_items = saved_plain;
     c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation: S is unbound afterwards (hj.h)
     c->rel[HJ_REL_S].n = 0;
     invalidate(c, HJ_REL_S);

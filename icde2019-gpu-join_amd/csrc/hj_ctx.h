@@ -96,6 +96,7 @@ struct hj_ctx {
     int ncu = 256;                  // CUs of the device
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
+    bool plain_items = false;       // ... and its per-segment second probe wants plain work items (no general items)
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)

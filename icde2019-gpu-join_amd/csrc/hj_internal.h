@@ -71,6 +71,11 @@ struct JoinItem {
     uint32_t nb, p;
 };
 constexpr uint32_t JOIN_ITEM_LIST = 0x80000000u;
+// general items (JoinArgs.general: the build relation is skewed):
+//   JOIN_ITEM_BLIST  the TABLE side of the item is a list of ranges: b0 = first range, nb = number of ranges (stride of that relation)
+//   JOIN_ITEM_SWAP   roles flipped for this item: the table is built from the relation the host calls probe side, the designated
+//                    build side is streamed (b0/nb and q0/q1 then index that relation's arrays)
+constexpr uint32_t JOIN_ITEM_BLIST = 0x40000000u, JOIN_ITEM_SWAP = 0x20000000u;
 
 struct JoinArgs {
     const int32_t *bk, *bp;  // build side, partitioned
@@ -83,6 +88,9 @@ struct JoinArgs {
     const uint32_t *rpart;   // probe side given as RANGES (sampled path): partition id of range i; nullptr: range i = partition i
     const uint32_t *pr0, *pnr; // ... or PARTITIONS with a list of ranges each: first range, number of ranges (stride rstride)
     uint32_t rstride;
+    const uint32_t *br0, *bnr; // build side in PARTITIONS with a list of ranges each (sampled build relation), stride bstride
+    uint32_t bstride;
+    uint32_t general;        // 1: general items (table side may be a list, roles may be flipped per partition): k_join_plan_gen / GEN kernels
     const JoinItem *items;   // (build partition, probe chunk) descriptors
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;

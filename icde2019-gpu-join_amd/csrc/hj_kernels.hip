@@ -1140,6 +1140,65 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
     }
 }
 
+// ---- general items (a skewed build relation: JoinArgs.general) ----
+// A side of the join as the planner sees it: partition i is range i (r0 == nullptr) or the list of ranges r0[i] + j * stride, j < nr[i].
+struct SideRef { const uint64_t *beg, *end; const uint32_t *r0, *nr; uint32_t stride; };
+__device__ inline uint64_t side_size(const SideRef &s, uint32_t i) {
+    if (!s.r0) return s.end[i] - s.beg[i];
+    uint64_t tot = 0;
+    for (uint32_t j = 0; j < s.nr[i]; j++) { const uint32_t r = s.r0[i] + j * s.stride; tot += s.end[r] - s.beg[r]; }
+    return tot;
+}
+// The items of partition i.  With a skewed build relation the table side is chosen PER PARTITION: the smaller of the two partitions
+// builds (the reference flips the roles for build partitions that do not fit its table, jp.cu:929-1003).  That turns ONE workgroup
+// looping over hundreds of table chunks of a heavy hitter into one item per chunk of the streamed side, and it keeps a key with
+// thousands of duplicates out of the table, where it would be one chain that every probe of that key walks link by link (count) or
+// one output round per duplicate (materialisation): measured at 2^24 x 2^27 Zipf with the Zipf side designated to build, 1.5 s
+// per step without flipping, 6.8 ms flipping only oversize partitions, 1.5 ms with this rule (profiles/r4_skewed_build.txt).
+// The streamed side is cut into items exactly as the probe side always was (walk_ranges / chunks).  emit(index, item).
+template <class F>
+__device__ inline uint32_t general_items(const JoinArgs &a, uint32_t i, F emit) {
+    const SideRef B{a.bbeg, a.bend, a.br0, a.bnr, a.bstride}, P{a.pbeg, a.pend, a.pr0, a.pnr, a.rstride};
+    const uint64_t nb = side_size(B, i), np = side_size(P, i);
+    if (!nb || !np) return 0;
+    const bool swap = np < nb;
+    const SideRef &T = swap ? P : B, &S = swap ? B : P;
+    JoinItem base;
+    base.p = i | (swap ? JOIN_ITEM_SWAP : 0u) | (T.r0 ? JOIN_ITEM_BLIST : 0u);
+    if (T.r0) { base.b0 = T.r0[i]; base.nb = T.nr[i]; }
+    else { base.b0 = T.beg[i]; base.nb = (uint32_t)(T.end[i] - T.beg[i]); }
+    base.q0 = 0; base.q1 = 0;
+    if (S.r0)
+        return walk_ranges(S.beg, S.end, S.r0[i], S.nr[i], S.stride, a.chunk, [&](uint32_t idx, bool list, uint64_t q0, uint64_t q1) {
+            JoinItem it = base;
+            it.q0 = q0; it.q1 = q1; if (list) it.p |= JOIN_ITEM_LIST;
+            emit(idx, it);
+        });
+    uint32_t n = 0;
+    for (uint64_t q = S.beg[i]; q < S.end[i]; q += a.chunk, n++) {
+        JoinItem it = base;
+        it.q0 = q; it.q1 = q + a.chunk < S.end[i] ? q + a.chunk : S.end[i];
+        emit(n, it);
+    }
+    return n;
+}
+
+__global__ void k_join_plan_gen(JoinArgs a, uint32_t nparts, uint32_t *__restrict__ items_cnt, uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
+    if (i >= nparts) return;
+    if ((a.bflag && *a.bflag) || (a.pflag && *a.pflag)) { items_cnt[i] = 0; return; }
+    items_cnt[i] = general_items(a, i, [](uint32_t, const JoinItem &) {});
+}
+__global__ void k_join_expand_gen(JoinArgs a, uint32_t nparts, const uint32_t *__restrict__ items_scanned, const uint64_t *__restrict__ chunk_prefix,
+                                  JoinItem *__restrict__ items) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparts) return;
+    if ((a.bflag && *a.bflag) || (a.pflag && *a.pflag)) return;
+    const uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
+    general_items(a, i, [&](uint32_t idx, const JoinItem &it) { items[at + idx] = it; });
+}
+
 // the probe ranges of an item: one chunk [q0, q1), or (list items) range rr of it.q1 whole ranges starting at range it.q0
 __device__ inline uint32_t item_nranges(const JoinItem &it) { return (it.p & JOIN_ITEM_LIST) ? (uint32_t)it.q1 : 1u; }
 __device__ inline void item_range(const JoinArgs &a, const JoinItem &it, uint32_t rr, uint64_t &q0, uint64_t &q1) {
@@ -1188,9 +1247,15 @@ hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t np
 // LDS layout (dynamic): head[nh] u32 | entries[cap] 8 bytes ({tag16 << 16 | next16, payload} or {key, payload}) | with full
 // keys: next[cap] u16.  The reference's table: elem int16 tag, payload int32, next int16, head int32[1024] (jp.cu:899-902):
 // the same 8 bytes per tuple, here laid out so that one 8-byte LDS load per chain hop fetches tag, link and payload.
-template <bool TAG16, int JM>
+// GEN (general items: the build relation is skewed — host: hj_api.hip plan_join): the TABLE side of an item may be a LIST of ranges
+// (a sampled build relation: JOIN_ITEM_BLIST, b0 = first range, nb = number of ranges) that is built into the LDS table piece by
+// piece, the table taking the next cap tuples of the concatenated ranges per chunk; and the roles may be FLIPPED for the item
+// (JOIN_ITEM_SWAP): the table is built from the relation the host calls probe side and the designated build side is streamed —
+// what the reference does for build partitions that do not fit its table (jp.cu:929-1003).  Count and aggregate are symmetric.
+template <bool TAG16, int JM, bool GEN = false>
 __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     constexpr bool MAT = JM == 1;
+    static_assert(!GEN || JM == 0, "general items: count kernel and k_join_mat_reg only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t item = blockIdx.x;
     if (item >= *a.n_items) return;
@@ -1202,9 +1267,28 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
 
     const uint32_t tid = threadIdx.x, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // scalar: the probe stream state stays in SGPRs
     const JoinItem it = a.items[item];
-    const uint64_t b0 = it.b0, nb = it.nb;
     const uint32_t nr = item_nranges(it); // probe ranges of the item (list items: several whole ranges share one table build)
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    // the two sides of the item (wave-uniform; without GEN: the build relation is the table, the probe relation the stream)
+    const bool swap = GEN && (it.p & JOIN_ITEM_SWAP), blist = GEN && (it.p & JOIN_ITEM_BLIST);
+    const int32_t *const tk = swap ? a.pk : a.bk, *const tp = swap ? a.pp : a.bp, *const sk = swap ? a.bk : a.pk, *const sp = swap ? a.bp : a.pp;
+    const uint64_t t_nalloc = swap ? a.p_nalloc : a.b_nalloc, s_nalloc = swap ? a.b_nalloc : a.p_nalloc;
+    const uint64_t *const tbeg = swap ? a.pbeg : a.bbeg, *const tend = swap ? a.pend : a.bend, *const sbeg = swap ? a.bbeg : a.pbeg, *const send = swap ? a.bend : a.pend;
+    const uint32_t tstride = swap ? a.rstride : a.bstride, sstride = swap ? a.bstride : a.rstride;
+    auto stream_range = [&](uint32_t rr_, uint64_t &q0_, uint64_t &q1_) {
+        if (it.p & JOIN_ITEM_LIST) { const uint32_t r = (uint32_t)it.q0 + rr_ * sstride; q0_ = sbeg[r]; q1_ = send[r]; }
+        else { q0_ = it.q0; q1_ = it.q1; }
+    };
+    // table cursor: range tr of ntr, [tb, te) = what is left of it
+    const uint32_t ntr = blist ? it.nb : 1u;
+    uint32_t tr = 0;
+    uint64_t tb, te;
+    auto table_range = [&](uint32_t j) {
+        if (blist) { const uint32_t r = (uint32_t)it.b0 + j * tstride; tb = tbeg[r]; te = tend[r]; }
+        else { tb = it.b0; te = it.b0 + it.nb; }
+    };
+    table_range(0);
+    if (GEN) while (tb == te && tr + 1 < ntr) table_range(++tr);
     // TAG16 only at >= 16 radix bits: what is left of a key then fits the 16 stored bits and the comparison is exact (the
     // reference's tag shortcut, jp.cu:1029, is taken at any bit count, D2); below that the table stores full keys
     auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; };
@@ -1217,9 +1301,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     }
     const uint64_t lt_mask = ((uint64_t)1 << lane_id()) - 1;
 
-    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
-        const uint64_t gb = b0 + bc;
-        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+    while (tb < te) { // one table chunk per iteration: the next cap tuples of the table side
+        uint64_t gb = tb;
+        uint32_t nbc = (uint32_t)(te - tb < a.cap ? te - tb : a.cap), filled = 0;
         // ---- build: tuple j of the chunk lives in slot j; LIFO chain insert by atomic exchange on
         // the bucket head (jp.cu:1021-1048).  Loads of three iterations (6144 tuples: a whole default-size table) are
         // in flight at a time; the first three are issued BEFORE the heads are initialised (they need no LDS) ----
@@ -1229,7 +1313,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
+                if (i < gb + nbc) { bkv[r] = load4(tk, i, t_nalloc); bpv[r] = load4(tp, i, t_nalloc); }
             }
         };
         bload();
@@ -1237,38 +1321,48 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
         // (rr, nq0, nq1, w0) is wave-uniform.  The loads of the NEXT position are always in flight while the current one is probed.
         uint32_t rr = 0;
         uint64_t nq0, nq1;
-        item_range(a, it, 0, nq0, nq1);
+        stream_range(0, nq0, nq1);
         uint64_t w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256;
         auto skip_empty = [&]() { // this wave has nothing (left) in range rr: on to the next one
-            while (w0 >= nq1 && rr + 1 < nr) { rr++; item_range(a, it, rr, nq0, nq1); w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256; }
+            while (w0 >= nq1 && rr + 1 < nr) { rr++; stream_range(rr, nq0, nq1); w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256; }
         };
         skip_empty();
         int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
         if (w0 + (uint64_t)lane_id() * 4 < nq1) {
-            nk = load4(a.pk, w0 + (uint64_t)lane_id() * 4, a.p_nalloc);
-            np = load4(a.pp, w0 + (uint64_t)lane_id() * 4, a.p_nalloc);
+            nk = load4(sk, w0 + (uint64_t)lane_id() * 4, s_nalloc);
+            np = load4(sp, w0 + (uint64_t)lane_id() * 4, s_nalloc);
         }
         for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
         __syncthreads();
-        while (i0 < gb + nbc) {
+        for (;;) { // the pieces of this chunk: [gb, gb + nbc) goes to slots filled ... (one piece unless the table side is a list)
+            while (i0 < gb + nbc) {
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                if (i < gb + nbc) {
+                for (int r = 0; r < 3; r++) {
+                    const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                    if (i < gb + nbc) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        uint64_t idx = i + e;
-                        if (idx >= gb && idx < gb + nbc) {
-                            const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                            const uint32_t old = atomicExch(&head[hidx(key)], slot);
-                            if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
-                            else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                        for (int e = 0; e < 4; e++) {
+                            uint64_t idx = i + e;
+                            if (idx >= gb && idx < gb + nbc) {
+                                const uint32_t slot = filled + (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                                const uint32_t old = atomicExch(&head[hidx(key)], slot);
+                                if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                                else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                            }
                         }
                     }
                 }
+                i0 += (uint64_t)JOIN_THREADS * 4 * 3;
+                if (i0 < gb + nbc) bload();
             }
-            i0 += (uint64_t)JOIN_THREADS * 4 * 3;
-            if (i0 < gb + nbc) bload();
+            filled += nbc; tb += nbc;
+            if (!GEN) break;
+            while (tb == te && tr + 1 < ntr) table_range(++tr); // the next range that holds something
+            if (tb == te || filled == a.cap) break;              // table side exhausted, or the table is full
+            gb = tb;
+            nbc = (uint32_t)(te - tb < a.cap - filled ? te - tb : a.cap - filled);
+            i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4;
+            bload();
         }
         __syncthreads();
         // ---- probe ----
@@ -1283,7 +1377,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 skip_empty();
                 const uint64_t inext = w0 + (uint64_t)lane_id() * 4;
                 nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
-                if (inext < nq1) { nk = load4(a.pk, inext, a.p_nalloc); np = load4(a.pp, inext, a.p_nalloc); }
+                if (inext < nq1) { nk = load4(sk, inext, s_nalloc); np = load4(sp, inext, s_nalloc); }
             }
             if (JM == 0) {
                 // count-only: the four bucket heads of this lane's four tuples are fetched first and the four
@@ -1401,11 +1495,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
 constexpr int MR_IT = 3;
 #define MR_NE(t) ((t) == 2 ? 2 : 4)
 constexpr uint32_t MR_SUB = 2 * JOIN_THREADS * 4 + JOIN_THREADS * 2;
-template <bool TAG16, bool LISTS> // LISTS: the items may be list items (sampled probe side)
-__global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { // 6 waves per SIMD = three workgroups per CU: <= 85 VGPRs
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t item = blockIdx.x;
-    if (item >= *a.n_items) return;
+// The body is a function of its own so that flipped roles (SWAP) are a template parameter: either way every column pointer is a
+// kernel argument the compiler can fetch where it is used, instead of twenty selected pointers held in registers for the whole
+// item (40-56 bytes per lane of scratch that way).
+template <bool TAG16, bool LISTS, bool GEN, bool SWAP>
+__device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinItem &it, unsigned char *smem) {
     uint32_t *head = reinterpret_cast<uint32_t *>(smem);
     uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)a.nh * 4);
     uint16_t *lnext = reinterpret_cast<uint16_t *>(smem + (size_t)a.nh * 4 + (size_t)a.cap * 8);
@@ -1413,23 +1507,42 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + tbl); // [2][JOIN_WAVES] wave totals (round parity) | [16],[17] base lo/hi
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
-    const JoinItem it = a.items[item];
-    const uint64_t b0 = it.b0, nb = it.nb;
-    const uint32_t nr = LISTS ? item_nranges(it) : 1u;
+    const uint32_t nr = (LISTS || GEN) ? item_nranges(it) : 1u;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
     auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; }; // see k_join
     const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
     constexpr uint32_t END = 0xFFFFu;
+    // the two sides of the item, as in k_join; flipped roles also flip the two payload columns of the output
+    constexpr bool swap = SWAP;
+    const bool blist = GEN && (it.p & JOIN_ITEM_BLIST);
+    const int32_t *const tk = swap ? a.pk : a.bk, *const tp = swap ? a.pp : a.bp, *const sk = swap ? a.bk : a.pk, *const sp = swap ? a.bp : a.pp;
+    const uint64_t t_nalloc = swap ? a.p_nalloc : a.b_nalloc, s_nalloc = swap ? a.b_nalloc : a.p_nalloc;
+    const uint64_t *const tbeg = swap ? a.pbeg : a.bbeg, *const tend = swap ? a.pend : a.bend, *const sbeg = swap ? a.bbeg : a.pbeg, *const send = swap ? a.bend : a.pend;
+    const uint32_t tstride = swap ? a.rstride : a.bstride, sstride = swap ? a.bstride : a.rstride;
+    int32_t *const out_tpay = swap ? a.out_ppay : a.out_bpay, *const out_spay = swap ? a.out_bpay : a.out_ppay;
+    const uint32_t ntr = blist ? it.nb : 1u;
+    uint32_t tr = 0;
+    uint64_t tb, te;
+    auto table_range = [&](uint32_t j) {
+        if (blist) { const uint32_t r = (uint32_t)it.b0 + j * tstride; tb = uniform64(tbeg[r]); te = uniform64(tend[r]); }
+        else { tb = it.b0; te = it.b0 + it.nb; }
+    };
+    table_range(0);
+    if (GEN) while (tb == te && tr + 1 < ntr) table_range(++tr);
 
-    for (uint64_t bc = 0; bc < nb; bc += a.cap) {
-        const uint64_t gb = b0 + bc;
-        const uint32_t nbc = (uint32_t)(nb - bc < a.cap ? nb - bc : a.cap);
+    const uint64_t b0_ = it.b0, nb_ = it.nb;
+    for (uint64_t bc = 0; GEN ? tb < te : bc < nb_; bc += a.cap) { // one table chunk per iteration: the next cap tuples of the table side
         bool built = false;
         uint32_t par = 0;
+        const uint64_t gb0 = GEN ? tb : b0_ + bc;
+        const uint32_t nbc0 = GEN ? 0u : (uint32_t)(nb_ - bc < a.cap ? nb_ - bc : a.cap);
         for (uint32_t rr = 0; rr < nr; rr++) { // list items: whole ranges, one after the other, against the same table
         uint64_t q0, q1;
-        if (LISTS) { item_range(a, it, rr, q0, q1); q0 = uniform64(q0); q1 = uniform64(q1); } // the range cursor is wave-uniform: SGPRs, as in k_join (28 B/lane of scratch otherwise)
-        else { q0 = it.q0; q1 = it.q1; }
+        if (LISTS || GEN) { // the range cursor is wave-uniform: SGPRs, as in k_join (28 B/lane of scratch otherwise)
+            if (it.p & JOIN_ITEM_LIST) { const uint32_t r = (uint32_t)it.q0 + rr * sstride; q0 = sbeg[r]; q1 = send[r]; }
+            else { q0 = it.q0; q1 = it.q1; }
+            q0 = uniform64(q0); q1 = uniform64(q1);
+        } else { q0 = it.q0; q1 = it.q1; }
         for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)MR_SUB) {
             // the sub-chunk's probe tuples: issued first, so that they fly while the table is built
             // the first 2048 tuples are requested before the table is built (they fly during the build); the rest behind it — the
@@ -1442,10 +1555,10 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
                 const uint64_t i = tuple_index(t, 0);
                 kk[t] = make_int4(0, 0, 0, 0); pp[t] = make_int4(0, 0, 0, 0);
                 if (i >= q1) return;
-                if (t < 2) { kk[t] = load4(a.pk, i, a.p_nalloc); pp[t] = load4(a.pp, i, a.p_nalloc); }
+                if (t < 2) { kk[t] = load4(sk, i, s_nalloc); pp[t] = load4(sp, i, s_nalloc); }
                 else { // 8-byte group (i is even; the second element may lie beyond the allocation)
-                    kk[t].x = a.pk[i]; pp[t].x = a.pp[i];
-                    if (i + 1 < a.p_nalloc) { kk[t].y = a.pk[i + 1]; pp[t].y = a.pp[i + 1]; }
+                    kk[t].x = sk[i]; pp[t].x = sp[i];
+                    if (i + 1 < s_nalloc) { kk[t].y = sk[i + 1]; pp[t].y = sp[i + 1]; }
                 }
             };
             fetch(0);
@@ -1456,29 +1569,39 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
             if (!built) {
                 for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
                 __syncthreads();
-                for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 2) {
-                    int4 bkv[2], bpv[2]; // two loads per column in flight (the probe tuples are live in registers already)
+                uint32_t filled = 0;
+                for (;;) { // the pieces of this table chunk (one piece unless the table side is a list)
+                    const uint64_t gb = GEN ? tb : gb0;
+                    const uint32_t nbc = GEN ? (uint32_t)(te - tb < a.cap - filled ? te - tb : a.cap - filled) : nbc0;
+                    for (uint64_t i0 = (gb & ~(uint64_t)3) + (uint64_t)tid * 4; i0 < gb + nbc; i0 += (uint64_t)JOIN_THREADS * 4 * 2) {
+                        int4 bkv[2], bpv[2]; // two loads per column in flight (the probe tuples are live in registers already)
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                        if (i < gb + nbc) { bkv[r] = load4(a.bk, i, a.b_nalloc); bpv[r] = load4(a.bp, i, a.b_nalloc); }
-                    }
+                        for (int r = 0; r < 2; r++) {
+                            const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                            if (i < gb + nbc) { bkv[r] = load4(tk, i, t_nalloc); bpv[r] = load4(tp, i, t_nalloc); }
+                        }
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
-                        if (i < gb + nbc) {
+                        for (int r = 0; r < 2; r++) {
+                            const uint64_t i = i0 + (uint64_t)r * JOIN_THREADS * 4;
+                            if (i < gb + nbc) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const uint64_t idx = i + e;
-                                if (idx >= gb && idx < gb + nbc) {
-                                    const uint32_t slot = (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
-                                    const uint32_t old = atomicExch(&head[hidx(key)], slot);
-                                    if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
-                                    else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                                for (int e = 0; e < 4; e++) {
+                                    const uint64_t idx = i + e;
+                                    if (idx >= gb && idx < gb + nbc) {
+                                        const uint32_t slot = (GEN ? filled : 0u) + (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
+                                        const uint32_t old = atomicExch(&head[hidx(key)], slot);
+                                        if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                                        else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
+                                    }
                                 }
                             }
                         }
                     }
+                    if (!GEN) break;
+                    // the table cursor is wave-uniform, but it moves inside nested loops: pinned to SGPRs by hand
+                    filled = (uint32_t)__builtin_amdgcn_readfirstlane((int)(filled + nbc)); tb = uniform64(tb + nbc);
+                    while (tb == te && tr + 1 < ntr) { tr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tr + 1)); table_range(tr); }
+                    if (tb == te || filled == a.cap) break;
                 }
                 __syncthreads();
                 built = true;
@@ -1552,8 +1675,8 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
                             const uint64_t at = o + (uint64_t)__popcll(mask & lt_mask);
                             if (at < a.out_cap) {
                                 a.out_key[at] = elem(kk[t], e);
-                                a.out_bpay[at] = (int32_t)en.y;
-                                a.out_ppay[at] = elem(pp[t], e);
+                                out_tpay[at] = (int32_t)en.y;
+                                out_spay[at] = elem(pp[t], e);
                             }
                             setp(j, TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[slot]); // the next round starts behind the match
                         }
@@ -1565,8 +1688,19 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
             par ^= 1u;
         }
         }
+        if (GEN && !built) break; // nothing to probe in any range of the item: no table was built, the cursor did not move
         __syncthreads(); // the table is rebuilt (next build chunk): every wave must be through with it
     }
+}
+
+template <bool TAG16, bool LISTS, bool GEN = false> // LISTS: the items may be list items (sampled probe side); GEN: general items (see k_join)
+__global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { // 6 waves per SIMD = three workgroups per CU: <= 85 VGPRs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t item = blockIdx.x;
+    if (item >= *a.n_items) return;
+    const JoinItem it = a.items[item];
+    if (GEN && (it.p & JOIN_ITEM_SWAP)) join_mat_reg_item<TAG16, LISTS, GEN, GEN>(a, it, smem); // (GEN as SWAP: no flipped instance without GEN)
+    else join_mat_reg_item<TAG16, LISTS, GEN, false>(a, it, smem);
 }
 
 // count-only result: sums of the per-wave match counts and aggregates into out[0], out[1] (zeroed by k_join_plan)
@@ -1821,6 +1955,11 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa) {
 }
 
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor) {
+    if (a.general) {
+        hipLaunchKernelGGL(k_join_plan_gen, dim3((nparts + 255) / 256), dim3(256), 0, st, a, nparts, items_cnt, zero2, zero_cursor);
+        HJ_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(k_join_plan, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items_cnt,
                        a.bflag, a.pflag, zero2, zero_cursor, a.rpart, a.pr0, a.pnr, a.rstride);
     HJ_LAUNCH_CHECK();
@@ -1829,6 +1968,11 @@ hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, 
 
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items) {
+    if (a.general) {
+        hipLaunchKernelGGL(k_join_expand_gen, dim3((nparts + 255) / 256), dim3(256), 0, st, a, nparts, items_scanned, chunk_prefix, items);
+        HJ_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(k_join_expand, dim3((nparts + 255) / 256), dim3(256), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk,
                        items_scanned, chunk_prefix, items, a.bflag, a.pflag, a.rpart, a.pr0, a.pnr, a.rstride);
     HJ_LAUNCH_CHECK();
@@ -1846,7 +1990,8 @@ hipError_t join_set_lds_limit(int device, size_t bytes) {
     if (device >= 0 && device < 64 && bytes <= limit[device]) return hipSuccess;
     const void *fns[] = {reinterpret_cast<const void *>(&k_join<true, 0>), reinterpret_cast<const void *>(&k_join<true, 1>),
                          reinterpret_cast<const void *>(&k_join<true, 2>), reinterpret_cast<const void *>(&k_join<false, 0>),
-                         reinterpret_cast<const void *>(&k_join<false, 1>), reinterpret_cast<const void *>(&k_join<false, 2>)};
+                         reinterpret_cast<const void *>(&k_join<false, 1>), reinterpret_cast<const void *>(&k_join<false, 2>),
+                         reinterpret_cast<const void *>(&k_join<true, 0, true>), reinterpret_cast<const void *>(&k_join<false, 0, true>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
@@ -1870,7 +2015,8 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
         std::lock_guard<std::mutex> lock(g_attr_mutex);
         if (dev < 0 || dev >= 64 || lds > limit[dev]) {
             const void *fns[] = {reinterpret_cast<const void *>(&k_join_mat_reg<true, false>), reinterpret_cast<const void *>(&k_join_mat_reg<false, false>),
-                                 reinterpret_cast<const void *>(&k_join_mat_reg<true, true>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true>)};
+                                 reinterpret_cast<const void *>(&k_join_mat_reg<true, true>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true>),
+                                 reinterpret_cast<const void *>(&k_join_mat_reg<true, true, true>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true, true>)};
             for (const void *f : fns) {
                 hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
@@ -1879,7 +2025,10 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
         }
     }
     dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
-    if (a.pr0) {
+    if (a.general) {
+        if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true, true, true>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join_mat_reg<false, true, true>), g, b, lds, st, a);
+    } else if (a.pr0) {
         if (tag16) hipLaunchKernelGGL((k_join_mat_reg<true, true>), g, b, lds, st, a);
         else hipLaunchKernelGGL((k_join_mat_reg<false, true>), g, b, lds, st, a);
     } else {
@@ -1893,6 +2042,13 @@ hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_i
 hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm) {
     size_t lds = join_lds_bytes(a.nh, a.cap, tag16);
     dim3 g(max_items ? max_items : 1), b(JOIN_THREADS);
+    if (a.general) {
+        if (jm != 0) return hipErrorInvalidValue; // general items: count and one-probe materialisation only (the host sees to it)
+        if (tag16) hipLaunchKernelGGL((k_join<true, 0, true>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_join<false, 0, true>), g, b, lds, st, a);
+        HJ_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     if (tag16) {
         if (jm == 0) hipLaunchKernelGGL((k_join<true, 0>), g, b, lds, st, a);
         else if (jm == 1) hipLaunchKernelGGL((k_join<true, 1>), g, b, lds, st, a);

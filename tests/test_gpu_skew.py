@@ -196,6 +196,102 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
             assert hj.partition_layout(P.REL_S) == "exact"
 
 
+@pytest.mark.parametrize("cfg,nR,nS,both", [(dict(bits1=5, bits2=4, build_side=2), 1 << 16, 1 << 20, False),
+                                            (dict(bits1=8, bits2=7, build_side=2), 1 << 18, 3 << 20, False),
+                                            (dict(build_side=2), 1 << 22, 1 << 24, False),
+                                            (dict(bits1=6, bits2=5, build_side=2, lds_capacity=512, lds_heads=128), 1 << 20, 1 << 21, True),
+                                            (dict(bits1=8, bits2=8, build_side=2), 1 << 18, 1 << 21, False)])
+def test_skewed_build_side_one_launch_passes_and_flipped_roles(P, cfg, nR, nS, both):
+    """the SKEWED relation builds (build_side=2: S).  After first contact S is partitioned by the histogram-free
+    passes at sampled capacities like a skewed probe side — no k_hist — and its partitions, lists of ranges, are built into the
+    LDS table piece by piece (general work items); a build partition that does not fit the table while the other side's is
+    smaller is joined with the roles flipped (the reference's jp.cu:929-1003): the heavy hitter becomes many items instead of
+    one workgroup looping over hundreds of table chunks.  Count, aggregate and the materialised (key, payR, payS) multiset —
+    payloads in the right columns whichever side built — against the oracle; `both`: R is skewed too (lists on both sides);
+    8+8 bits: no sampled path at 16 radix bits (exact layout), flipped roles alone."""
+    import torch
+    rng = np.random.default_rng(94)
+    R = rng.permutation(nR).astype(np.int32)
+    u = rng.random(nS)
+    S = np.where(u < 0.40, R[3], np.where(u < 0.55, R[11], np.where(u < 0.60, R[12], R[rng.integers(0, nR, nS)]))).astype(np.int32)
+    if both:
+        R[rng.random(nR) < 0.30] = -5                    # a heavy hitter on the other side as well (a key S does not hold: no quadratic output)
+        R[100:400] = R[11]                               # and duplicates of one of S's heavy keys: 300 x 15 % of S more matches
+    Pr = np.arange(nR, dtype=np.int32)
+    Ps = (np.arange(nS, dtype=np.int64) * 7 % 1000003 + (1 << 24)).astype(np.int32)      # disjoint from payR: a swapped column shows
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    dR, dPr, dS, dPs = (torch.from_numpy(x).cuda() for x in (R, Pr, S, Ps))
+    with P.HashJoin(0) as hj:
+        hj.configure(**cfg)
+        hj.bind_device(P.REL_R, dR, dPr)
+        hj.bind_device(P.REL_S, dS, dPs)
+        c0 = hj.config()
+        assert c0["build_side"] == 2
+        sampled_ok = c0["bits2"] > 0 and c0["bits1"] + c0["bits2"] <= 15     # default bits follow the SMALLER relation (2^22: 9+1)
+        for i in range(3):     # overflow -> sample -> sampled passes + general items; then twice from the remembered tables
+            assert hj.join() == (em, eagg), i
+            assert hj.partition_layout(P.REL_S) == ("sampled" if sampled_ok else "exact"), i
+        hj.enable_timings(2)
+        hj.timings_reset()
+        assert hj.join() == (em, eagg)
+        kt = hj.timings()
+        hj.enable_timings(0)
+        if sampled_ok:
+            assert "k_hist" not in kt or kt["k_hist"]["launches"] == 0, kt   # no histogram after first contact, on either side
+            assert hj.partition_layout(P.REL_R) == ("sampled" if both else "slotted")
+        k, pr, ps = hj.join_materialize()
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        if em <= 3_000_000:
+            for a, b in zip(sorted_triples(k, pr, ps), sorted_triples(*o.join_materialize(R, Pr, S, Ps))):
+                assert np.array_equal(a, b)
+        assert np.array_equal(R[pr], k) and int(ps.min()) >= (1 << 24)  # payR / payS in their own columns whichever side built
+        hj.partition_both()
+        k, pr, ps = hj.join_materialize(cap=em)                       # one probe on fresh partitions, no count before it
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        # the two-probe path and the late-materialising kernel take plain items: the sampled build side is redone exact for them
+        hj.configure(**dict(cfg, materialize_two_pass=True))
+        assert hj.join() == (em, eagg)
+        k, pr, ps = hj.join_materialize()
+        assert o.triples_checksum(k, pr, ps) == echk
+        hj.configure(**dict(cfg, probe_chunk=3000))
+        assert hj.join() == (em, eagg)
+        k, pr, ps = hj.join_materialize(cap=em)
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        hj.configure(**cfg)
+        assert hj.join() == (em, eagg)
+        # introspection still hands out oracle-identical gap-free partitions of the build relation
+        c = hj.config()
+        gk, gp, goff = hj.partitions(P.REL_S, nS)
+        ok, op, ooff = o.radix_partition(S, Ps, 0, c["bits1"] + c["bits2"])
+        assert np.array_equal(goff, ooff) and np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+        assert hj.join() == (em, eagg)
+
+
+def test_late_materialize_with_a_skewed_build_side(P):
+    """join_partitioned_varpayload semantics with the skewed relation building: the late-materialising kernel takes plain work items,
+    so a sampled build side is redone with the exact passes for it."""
+    import torch
+    rng = np.random.default_rng(95)
+    nR, nS = 1 << 16, 1 << 20
+    R = rng.permutation(nR).astype(np.int32)
+    S = np.where(rng.random(nS) < 0.5, R[5], R[rng.integers(0, nR, nS)]).astype(np.int32)
+    Dr = rng.integers(-1000, 1000, (2, nR)).astype(np.int32)
+    Ds = rng.integers(-1000, 1000, (3, nS)).astype(np.int32)
+    idx = {int(k): i for i, k in enumerate(R)}
+    rows = np.array([idx[int(k)] for k in S], dtype=np.int64)
+    expect = (int(Dr[:, rows].astype(np.int64).sum()) + int(Ds.astype(np.int64).sum())) % (1 << 64)
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=5, bits2=4, build_side=2)
+        hj.load_host(P.REL_R, R, payload="rowid")
+        hj.load_host(P.REL_S, S, payload="rowid")
+        assert hj.join()[0] == nS and hj.join()[0] == nS
+        assert hj.partition_layout(P.REL_S) == "sampled"
+        dDr, dDs = torch.from_numpy(Dr).cuda(), torch.from_numpy(Ds).cuda()
+        hj.partition_both()
+        m, s = hj.join_late_materialize(dDr, 2, nR, dDs, 3, nS)
+        assert m == nS and s == expect
+
+
 def test_stream_probe_segments_that_overflow_are_redone(P):
     """The count-only streaming loop never blocks the host: every segment's result and overflow flag are parked on the device
     and read once at the end; segments whose histogram-free slots overflowed (half of every segment is one key here)
