@@ -200,7 +200,7 @@ int pass_prep(hj_ctx *c, int wsid, const int32_t *in_k, const int32_t *in_p, uin
               uint32_t nparents, uint32_t shift, uint32_t P, uint32_t mask_or_n, int32_t *out_k, int32_t *out_p,
               PassArgs &pa) {
     if (nparents > (uint32_t)MAX_SEGS || P > (uint32_t)MAX_PARTS || P == 0) return fail(c, HJ_EINVAL, "pass fan-out out of range");
-    if (n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU pass (n < 2^32 required)");
+    if (n > ((uint64_t)1 << 34)) return fail(c, HJ_EINVAL, "relation too large for one GPU pass (n <= 2^34 tuples)");
     const uint32_t target_spans = c->target_spans ? c->target_spans : TARGET_SPANS;
     uint64_t span64 = (n + target_spans - 1) / target_spans;
     span64 = ((span64 + TILE - 1) / TILE) * TILE;
@@ -280,8 +280,8 @@ bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &
     f.cap2 = fast_slot_cap((n + (uint64_t)P1 * P2 - 1) / ((uint64_t)P1 * P2), P2);
     f.sizeA = (uint64_t)P1 * nspans * f.cap1;
     f.sizeB = (uint64_t)P1 * P2 * f.cap2;
-    const uint64_t lim = ((uint64_t)1 << 32) - ((uint64_t)1 << 20);
-    return f.sizeA < lim && f.sizeB < lim;
+    const uint64_t lim = (uint64_t)1 << 36; // 32-bit line numbers inside the kernels: 2^37 tuples; half of that here
+    return f.sizeA < lim && f.sizeB < lim && f.cap1 < ((uint32_t)1 << 31) && f.cap2 < ((uint32_t)1 << 31);
 }
 
 // ---- the sampled path: a relation known to be skewed, on the probe side ----
@@ -474,6 +474,8 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     return 0;
 }
 
+int ensure_part(hj_ctx *c, Buf &b, size_t bytes);
+
 // the two launches; *done = false when the relation cannot take this path (the caller goes on to the exact passes)
 int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag, bool *done) {
     Rel &R = c->rel[r];
@@ -487,8 +489,8 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     }
     const uint32_t P1 = 1u << b1, P2 = 1u << b2;
     hipStream_t st = c->stream;
-    RET(ensure(c, R.a_k, (size_t)(sp.sizeA + PAD) * 4)); RET(ensure(c, R.a_p, (size_t)(sp.sizeA + PAD) * 4));
-    RET(ensure(c, R.b_k, (size_t)(sp.sizeB + PAD) * 4)); RET(ensure(c, R.b_p, (size_t)(sp.sizeB + PAD) * 4));
+    RET(ensure_part(c, R.a_k, (size_t)(sp.sizeA + PAD) * 4)); RET(ensure_part(c, R.a_p, (size_t)(sp.sizeA + PAD) * 4));
+    RET(ensure_part(c, R.b_k, (size_t)(sp.sizeB + PAD) * 4)); RET(ensure_part(c, R.b_p, (size_t)(sp.sizeB + PAD) * 4));
     RET(ensure(c, R.s1beg, (size_t)P1 * sp.nspans * 8)); RET(ensure(c, R.s1end, (size_t)P1 * sp.nspans * 8));
     RET(ensure(c, sp.rbeg, (size_t)sp.nranges * 8)); RET(ensure(c, sp.rend, (size_t)sp.nranges * 8));
     FastArgs fa{};
@@ -521,12 +523,37 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     return 0;
 }
 
+// Partition buffers are allocated with 10 % of headroom: a relation whose slots overflow (skew) moves to the sampled geometry, whose
+// buffers are 5-7 % larger than the uniform ones; without the headroom that switch frees and re-allocates every buffer of the
+// relation — and device allocation is what a cold first call spends its time on when the driver has pages to scrub (19 ms ... 2.7 s
+// for the 70 GiB of config 4, profiles/r4_first_call.txt).
+int ensure_part(hj_ctx *c, Buf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    return ensure(c, b, bytes + bytes / 10);
+}
+
 int partition_rel(hj_ctx *c, int r) {
     Rel &R = c->rel[r];
     if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
-    // positions inside the partition kernels are 32-bit: checked before anything is allocated
-    if (R.n >= ((uint64_t)1 << 32) - 2 * TILE) return fail(c, HJ_EINVAL, "relation too large for one GPU (n < 2^32 - 16384 tuples required)");
+    // Positions inside the partition kernels are 32-bit LINE numbers (2^37 tuples): what bounds a relation is the card's memory,
+    // checked here before anything is (re)allocated — pass-1 and final buffers of both columns, ~1.14 x 16 bytes per tuple on top
+    // of the input (the reference's CLI accepts up to ULONG_MAX/4 tuples, main.cu:491-514).
+    if (R.n > ((uint64_t)1 << 34)) return fail(c, HJ_EINVAL, "relation too large (n <= 2^34 tuples: pass-2 parents are addressed in 32-bit units)");
     choose_bits(c);
+    {
+        const uint32_t P1g = 1u << c->bits1, P2g = 1u << c->bits2;
+        FastPlan fg{};
+        const bool fastg = c->bits2 && c->fast_path && !c->cfg.exact_only && !R.prefer_exact && plan_fast(c, R.n, P1g, P2g, fg);
+        const uint64_t wantA = c->bits2 ? (std::max<uint64_t>(R.n, fastg ? fg.sizeA : 0) + PAD) * 4 : 0, wantB = (std::max<uint64_t>(R.n, fastg ? fg.sizeB : 0) + PAD) * 4;
+        uint64_t grow = 0, give_back = 0;
+        for (const Buf *b : {&R.a_k, &R.a_p}) if (wantA > b->cap) { grow += wantA + wantA / 10; give_back += b->cap; }
+        for (const Buf *b : {&R.b_k, &R.b_p}) if (wantB > b->cap) { grow += wantB + wantB / 10; give_back += b->cap; }
+        size_t free_b = 0, total_b = 0;
+        if (grow && hipMemGetInfo(&free_b, &total_b) == hipSuccess && grow > (uint64_t)free_b + give_back)
+            return fail(c, HJ_ENOMEM, "partitioning %llu tuples needs %.1f GiB of partition buffers (%.1f GiB still to allocate), %.1f of %.1f GiB are free on device %d",
+                        (unsigned long long)R.n, (2.0 * wantA + 2.0 * wantB) / 1073741824.0, (grow - give_back) / 1073741824.0, free_b / 1073741824.0,
+                        total_b / 1073741824.0, c->device);
+    }
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));
     uint32_t *const flag = reinterpret_cast<uint32_t *>((uint64_t *)c->scalars.p + 8 + r); // travels with the result block
@@ -562,8 +589,8 @@ int partition_rel(hj_ctx *c, int r) {
     FastPlan f{};
     const bool fast = b2 && c->fast_path && !c->cfg.exact_only && !R.prefer_exact && plan_fast(c, R.n, P1, P2, f);
     const uint64_t elemsA = std::max<uint64_t>(R.n, fast ? f.sizeA : 0), elemsB = std::max<uint64_t>(R.n, fast ? f.sizeB : 0);
-    RET(ensure(c, R.b_k, (size_t)(elemsB + PAD) * 4));
-    RET(ensure(c, R.b_p, (size_t)(elemsB + PAD) * 4));
+    RET(ensure_part(c, R.b_k, (size_t)(elemsB + PAD) * 4));
+    RET(ensure_part(c, R.b_p, (size_t)(elemsB + PAD) * 4));
     RET(ensure(c, R.beg, (size_t)nparts * 8));
     RET(ensure(c, R.end, (size_t)nparts * 8));
     uint64_t *beg = (uint64_t *)R.beg.p, *end = (uint64_t *)R.end.p;
@@ -572,8 +599,8 @@ int partition_rel(hj_ctx *c, int r) {
         RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, 0, P1, P1 - 1, (int32_t *)R.b_k.p,
                      (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, beg, end));
     } else {
-        RET(ensure(c, R.a_k, (size_t)(elemsA + PAD) * 4));
-        RET(ensure(c, R.a_p, (size_t)(elemsA + PAD) * 4));
+        RET(ensure_part(c, R.a_k, (size_t)(elemsA + PAD) * 4));
+        RET(ensure_part(c, R.a_p, (size_t)(elemsA + PAD) * 4));
         if (fast) {
             // ---- histogram-free passes.  Optimistic: if a slot overflows, the kernels raise the relation's flag, the
             //      join's planning kernel then produces no work, and the host — which reads the flag with the next result

@@ -390,15 +390,19 @@ struct WfLds {
 // digit d's output slot has index slotA + d*slotB (that is where its range [beg, end) is written) and, with uniform capacities,
 // lies at index*cap.  Variable capacities (the sampled path of skewed relations): the slot of digit d starts at
 // voff + vbase[d] + vs*vcap[d] and holds vcap[d] tuples.
+// Output positions inside the kernels are kept in LINES (32 tuples = 128 bytes per column): every slot starts on a line and holds
+// whole lines, so 32-bit line numbers address 2^37 tuples — a relation of 2^32 tuples and more (288 GB of HBM, not 32-bit
+// positions, is the size limit of one GPU; the reference's CLI accepts up to ULONG_MAX/4 tuples, main.cu:491-514) — and byte
+// addresses are formed in 64 bits where a line is stored.
 struct FastGeom {
     uint32_t slotA, slotB, cap;
     const uint32_t *vbase = nullptr, *vcap = nullptr;
     uint32_t voff = 0, vs = 0;
 };
-__device__ __forceinline__ uint32_t slot_base(const FastGeom &g, uint32_t d) {
-    return g.vbase ? g.voff + g.vbase[d] + g.vs * g.vcap[d] : (g.slotA + d * g.slotB) * g.cap;
+__device__ __forceinline__ uint32_t slot_line(const FastGeom &g, uint32_t d) { // first line of the slot
+    return g.vbase ? (g.voff + g.vbase[d] + g.vs * g.vcap[d]) / WC_LINE : (g.slotA + d * g.slotB) * (g.cap / WC_LINE);
 }
-__device__ __forceinline__ uint32_t slot_cap(const FastGeom &g, uint32_t d) { return g.vbase ? g.vcap[d] : g.cap; }
+__device__ __forceinline__ uint32_t slot_lines(const FastGeom &g, uint32_t d) { return (g.vbase ? g.vcap[d] : g.cap) / WC_LINE; }
 
 // One workgroup, one input stream, P digits with K = 512/P LDS lines each.  Per round of 8192 tuples:
 //   A  kept tuples of the previous round open their digit's next line; digit owners advance the output position by
@@ -471,7 +475,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             const uint32_t unit = wbeg + (round * U + u) * 64 + ln;
             if (round < nrounds && unit < wend) {
                 while (unit >= chi) { ci++; clo = chi; chi = L_.pc4[ci + 1]; csb = L_.sb[ci]; }
-                const uint32_t addr = (csb & ~3u) + (unit - clo) * 4;
+                const uint64_t addr = (uint64_t)(csb >> 2) * WC_LINE + (uint64_t)(unit - clo) * 4; // segments start on a line
                 kv = *reinterpret_cast<const int4 *>(keys + addr);
                 pv = *reinterpret_cast<const int4 *>(pays + addr);
                 vm = (unit + 1 == chi) ? (0xFu >> (csb & 3u)) : 0xFu; // the segment's last unit may be padded
@@ -489,8 +493,9 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
     for (int u = 0; u < U; u++) { kk[u] = make_int4(0, 0, 0, 0); pp[u] = make_int4(0, 0, 0, 0); }
     // the digit this thread owns (tid < P): slot geometry
-    const uint32_t my_base = tid < P ? slot_base(g, tid) : 0u, my_lim = my_base + (tid < P ? slot_cap(g, tid) : 0u);
-    const uint32_t my_gran = (VAR && tid < P) ? (L_.lt[tid] >> 16) * WC_LINE : capS; // a slot counts as full one granule (the digit's LDS lines) early
+    // (in lines) the slot of the digit this thread owns; a slot counts as full one granule (the digit's LDS lines) early
+    const uint32_t my_base = tid < P ? slot_line(g, tid) : 0u, my_lim = my_base + (tid < P ? slot_lines(g, tid) : 0u);
+    const uint32_t my_gran = (VAR && tid < P) ? (L_.lt[tid] >> 16) : K;
     const uint32_t trash = MAX_PARTS * WC_LINE + tid;
     uint32_t par = 0;
     for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
@@ -510,7 +515,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             const uint32_t w = hprev[tid];
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
             if (full) {
-                uint32_t nl = line[tid] + full;
+                uint32_t nl = line[tid] + full / WC_LINE;
                 if (!EXACT && nl + my_gran > my_lim) { *ovf = 1u | (tid << 8) | (round << 20); nl = my_base; } // slot full: give up (the exact passes redo it)
                 line[tid] = nl;
                 if (EXACT) L_.lo[tid] = 0; // only the run's first line starts mid-line
@@ -575,8 +580,8 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         const uint32_t d = c >> 16, q = c & 0xFFFFu;
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
                         if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
-                            const uint32_t o = line[d] + q;
-                            if (EXACT || o < slot_base(g, d) + slot_cap(g, d)) { out_keys[o] = elem(kk[u], e); out_pays[o] = elem(pp[u], e); }
+                            const uint64_t o = (uint64_t)line[d] * WC_LINE + q;
+                            if (EXACT || o < (uint64_t)(slot_line(g, d) + slot_lines(g, d)) * WC_LINE) { out_keys[o] = elem(kk[u], e); out_pays[o] = elem(pp[u], e); }
                             else *ovf = 2u;
                         }
                     }
@@ -606,7 +611,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     const uint32_t ls = wlist[idx];
                     const uint32_t df = VAR ? L_.own[ls] : ls >> kshift;
                     const uint32_t jf = VAR ? ls - (L_.lt[df] & 0xFFFFu) : (ls & (K - 1));
-                    const uint32_t gpos = line[df] + jf * WC_LINE + c4;
+                    const uint64_t gpos = ((uint64_t)line[df] + jf) * WC_LINE + c4;
                     const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
                     const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
                     const int4 kq = make_int4(x.x, x.z, y.x, y.z), pq = make_int4(x.y, x.w, y.y, y.w);
@@ -636,7 +641,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t w = hlast[tid];
         const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
         if (full) {
-            uint32_t nl = line[tid] + full;
+            uint32_t nl = line[tid] + full / WC_LINE;
             if (!EXACT && nl + my_gran > my_lim) { *ovf = 3u | (tid << 8) | (blockIdx.x << 16); nl = my_base; }
             line[tid] = nl;
             if (EXACT) L_.lo[tid] = 0;
@@ -649,15 +654,15 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         const uint32_t cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
         if (s < cur && (!EXACT || s >= L_.lo[d])) {
             const int2 v = buf[(VAR ? (L_.lt[d] & 0xFFFFu) * WC_LINE : d * capS) + s];
-            if (ln < (uint32_t)WC_LINE) out_keys[line[d] + s] = v.x;
-            else out_pays[line[d] + s] = v.y;
+            if (ln < (uint32_t)WC_LINE) out_keys[(uint64_t)line[d] * WC_LINE + s] = v.x;
+            else out_pays[(uint64_t)line[d] * WC_LINE + s] = v.y;
         }
     }
     if (!EXACT && tid < P) {
         const uint32_t slot = g.slotA + tid * g.slotB;
         const uint32_t w = hlast[tid];
-        obeg[slot] = my_base;
-        oend[slot] = (uint64_t)line[tid] + (((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1));
+        obeg[slot] = (uint64_t)my_base * WC_LINE;
+        oend[slot] = (uint64_t)line[tid] * WC_LINE + (((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1));
     }
 }
 
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
         const uint64_t g0 = (uint64_t)hist[idx] + chunk_prefix[idx >> SCAN_CHUNK_LOG];
         const uint64_t g1 = idx + 1 < L ? (uint64_t)hist[idx + 1] + chunk_prefix[(idx + 1) >> SCAN_CHUNK_LOG] : n_out;
         cnt = (uint32_t)(g1 - g0);
-        L_.line[tid] = (uint32_t)g0 & ~(uint32_t)(WC_LINE - 1);
+        L_.line[tid] = (uint32_t)(g0 / WC_LINE); // in lines (wc_fast); the run's first line starts at slot lo0 of it
         lo0 = (uint32_t)g0 & (WC_LINE - 1);
         L_.lo[tid] = lo0;
     }
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
     FastGeom g{s, a.nspans, a.cap};
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) L_.line[tid] = slot_base(g, tid);
+    if (tid < a.P) L_.line[tid] = slot_line(g, tid);
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     if (MODE == 0 && a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, false, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     FastGeom g{s, a.nspans, 0};
     g.vbase = v.vbase; g.vcap = v.vcap; g.voff = 0; g.vs = s;
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) { L_.line[tid] = slot_base(g, tid); L_.lt[tid] = v.lt[tid]; }
+    if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[tid]; }
     if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
         const uint64_t b = a.sbeg[(uint64_t)d * a.spp + w.y + tid], e = a.send[(uint64_t)d * a.spp + w.y + tid];
         const uint32_t cnt = (uint32_t)(e - b);
         units = (cnt + 3) >> 2;
-        L_.sb[tid] = (uint32_t)b | (units * 4 - cnt);
+        L_.sb[tid] = ((uint32_t)(b / WC_LINE) << 2) | (units * 4 - cnt);
     }
     uint32_t total;
     const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
     if (tid == 0) L_.pc4[w.z] = total;
     __syncthreads();
     for (uint32_t i = tid; i < 2 * WC_HSTRIDE; i += WC_THREADS) L_.hh[i] = 0;
-    if (tid < a.P) { L_.line[tid] = slot_base(g, tid); L_.lt[tid] = v.lt[(uint64_t)d * a.P + tid]; }
+    if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[(uint64_t)d * a.P + tid]; }
     if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[(uint64_t)d * MAX_PARTS + tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
@@ -934,7 +939,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
         const uint64_t b = a.sbeg[(uint64_t)parent * a.spp + tid], e = a.send[(uint64_t)parent * a.spp + tid];
         const uint32_t cnt = (uint32_t)(e - b);
         units = (cnt + 3) >> 2;
-        L_.sb[tid] = (uint32_t)b | (units * 4 - cnt); // segment start (multiple of 4) | padding of its last unit
+        L_.sb[tid] = ((uint32_t)(b / WC_LINE) << 2) | (units * 4 - cnt); // segment start in lines (slots start on a line) | padding of its last unit
     }
     uint32_t total;
     const uint32_t ex = block_excl_scan<uint32_t>(units, scratch, &total);
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     if (tid == 0) L_.pc4[a.spp] = total;
     __syncthreads();
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    if (tid < a.P) L_.line[tid] = slot_base(g, tid);
+    if (tid < a.P) L_.line[tid] = slot_line(g, tid);
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);

@@ -479,8 +479,8 @@ def test_large_unique_properties(P, logn):
 
 
 def test_largest_two_pass_size(P):
-    """2^31 x 2^31 unique keys: the largest power-of-two relations one GPU takes (32-bit positions), 18 radix bits =
-    8192-tuple partitions (two LDS-table chunks per partition).  Count, multiset-preserving partitioning, placement."""
+    """2^31 x 2^31 unique keys: 18 radix bits = 8192-tuple partitions (two LDS-table chunks per partition).  Count,
+    multiset-preserving partitioning, placement."""
     import torch
     n = 1 << 31
     dev = torch.device("cuda:0")
@@ -502,6 +502,50 @@ def test_largest_two_pass_size(P):
         assert bad == 0
         k, p, off, nparts = hj.partition_pointers(P.REL_R)
         assert nparts == 1 << 18 and hj.digest_pairs(k, p, n) == before
+
+
+def test_beyond_2p32_tuples(P):
+    """288 GB of HBM, not 32-bit positions, is what bounds a relation.  PK-FK 2^32 x 2^31: R holds every int32
+    value exactly once (a pseudo-random permutation of the whole key domain), S 2^31 distinct keys — positions inside the
+    partition kernels are 32-bit LINE numbers, byte addresses 64-bit.  Size-independent properties: count = |S| (64-bit, beyond
+    INT32_MAX), multiset-preserving partitioning of the 2^32-tuple relation (order-independent digest), every tuple in its
+    partition; a relation that cannot fit the card is refused with a memory message before anything is allocated."""
+    import torch
+    nR, nS = 1 << 32, 1 << 31
+    dev = torch.device("cuda:0")
+    Rk, Rp = (torch.empty(nR, dtype=torch.int32, device=dev) for _ in range(2))
+    Sk, Sp = (torch.empty(nS, dtype=torch.int32, device=dev) for _ in range(2))
+    with P.HashJoin(0, stream=torch.cuda.current_stream().cuda_stream) as hj:
+        hj.gen_unique(Rk, nR, 0, nR, 21)
+        hj.gen_unique(Sk, nS, 0, nR, 22)
+        hj.fill_payload(Rp, nR, "ones")
+        hj.fill_payload(Sp, nS, "ones")
+        hj.sync()
+        hj.bind_device(P.REL_R, Rk, Rp)
+        hj.bind_device(P.REL_S, Sk, Sp)
+        before = hj.digest_pairs(Rk, Rp, nR)
+        m, agg = hj.join()
+        assert m == agg == nS and m > 2**31 - 1
+        assert hj.config()["bits1"] + hj.config()["bits2"] == 18 and hj.config()["build_side"] == 2
+        assert hj.partition_layout(P.REL_R) == "slotted" and hj.partition_layout(P.REL_S) == "slotted"
+        bad, _ = hj.verify_partitions(P.REL_R)
+        assert bad == 0
+        del Sk, Sp                                   # room for the gap-free copy of R's partitions
+        hj.bind_device(P.REL_S, Rk[:16], Rp[:16])
+        k, p, off, nparts = hj.partition_pointers(P.REL_R)
+        assert nparts == 1 << 18 and hj.digest_pairs(k, p, nR) == before
+        # the exact passes address the same sizes (histogram + scan + scatter, 64-bit offsets)
+        hj.configure(exact_only=True)
+        hj.partition(P.REL_R)
+        bad, _ = hj.verify_partitions(P.REL_R)
+        assert bad == 0
+        k, p, off, nparts = hj.partition_pointers(P.REL_R)
+        assert hj.digest_pairs(k, p, nR) == before
+        # 2^34 tuples of buffers cannot fit 288 GB: refused by the memory check, nothing allocated, the context stays usable
+        with pytest.raises(P.HJError) as ei:
+            hj.bind_device(P.REL_R, Rk, Rp, n=1 << 34)
+            hj.partition(P.REL_R)
+        assert "GiB" in str(ei.value)
 
 
 # ---- streaming probe side (SURVEY §8(f) rank 1: outOfGPU_Join3_payload, hjcp.cu:1684-1984) ----------------
@@ -601,11 +645,11 @@ def test_api_errors_and_config(P):
         hj.configure(bits1=4)   # invalidates both
         with pytest.raises(P.HJError):
             hj.join_count()
-        # maximum size: positions are 32-bit inside the partition kernels; one tuple too many is refused before any
+        # maximum size: what the card's memory holds (positions inside the partition kernels are 32-bit line numbers; the memory check
+        # is exercised with real columns in test_beyond_2p32_tuples); beyond 2^34 tuples the structural limit answers before any
         # buffer is allocated or any byte of the (here fictitious) columns is read
         hj.configure()
-        big = (1 << 32) - 16384
-        rc = hj._L.hj_bind_device(hj._h, P.REL_R, C.c_void_p(1 << 20), C.c_void_p(1 << 21), big)
+        rc = hj._L.hj_bind_device(hj._h, P.REL_R, C.c_void_p(1 << 20), C.c_void_p(1 << 21), (1 << 34) + 16)
         assert rc == 0
         assert hj._L.hj_partition(hj._h, P.REL_R) == -1 and b"too large" in hj._L.hj_error(hj._h)
         hj.load_host(P.REL_R, R, R)
