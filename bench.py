@@ -233,6 +233,7 @@ def bench_zipf(a, pkg, torch, dev, local):
             mat.update({"k_join_materialize_ms": round(avg, 4), "k_join_materialize_GBs": round(gbs, 1),
                         "k_join_materialize_frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": 8.0 * (nR + nS) + 12.0 * nout})
+            mat.update(mix_ceiling(hj, Sk, Sp, ok, opr, min(nS, nout), 8.0 * (nR + nS), 12.0 * nout, gbs))
         del ok, opr, ops
     cpu = None if a.no_cpu_baseline else zipf_cpu_baseline(hj, torch, dev)
     print(json.dumps({"metric": "billion tuples/sec (build+probe), PK-FK 2^%d x 2^%d Zipf theta=1.0, 1 GPU%s" % (a.zipf_sizes[0], a.zipf_sizes[1], ", the Zipf side BUILDS" if a.build_side == 2 else ""),
@@ -371,6 +372,17 @@ def launch_ranks(n):
 # amortise its ramp-up and drain (2^27: measured 0.60-0.63, target 0.68 NOT met).
 PROBE_TARGET_FRAC = 0.70
 PROBE_TARGET_FRAC_SMALL = 0.68   # below 2^30 tuples per relation
+
+
+def mix_ceiling(hj, in_k, in_p, out_k, out_p, n, read_bytes, write_bytes, achieved_gbs):
+    """Same-run ceiling of a kernel that reads read_bytes and writes write_bytes: hj_ubench streams two columns in only and out only
+    (what this box's HBM gives pure reads / pure writes of 16 B per lane); no kernel with that mix can beat
+    (R + W) / (R / read_rate + W / write_rate)."""
+    rd = hj.ubench("read", in_k, in_p, out_k, out_p, n)
+    wr = hj.ubench("write", in_k, in_p, out_k, out_p, n)
+    ceil = (read_bytes + write_bytes) / (read_bytes / rd + write_bytes / wr)
+    return {"read_only_ceiling_GBs": round(rd, 1), "write_only_ceiling_GBs": round(wr, 1), "write_share_of_bytes": round(write_bytes / (read_bytes + write_bytes), 3),
+            "mix_ceiling_GBs": round(ceil, 1), "frac_of_mix_ceiling": round(achieved_gbs / ceil, 4)}
 
 
 def _fmix64(x):
@@ -596,6 +608,7 @@ def main():
     kt = hj.timings()
     hj.enable_timings(0)
     layout = [hj.partition_layout(pkg.REL_R), hj.partition_layout(pkg.REL_S)]
+    hj_cfg_bits = [hj.config()["bits1"], hj.config()["bits2"]]
 
     dist_info = None
     if use_dist:
@@ -763,7 +776,27 @@ def main():
             mat["k_join_materialize_ms"] = round(avg, 4)
             mat["k_join_materialize_GBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9, 1)
             mat["k_join_materialize_frac_of_8TBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if not a.no_extras:
+                mat.update(mix_ceiling(hj, Rk, Rp, ok, opr, n, 8.0 * 2 * n, 12.0 * nout, mat["k_join_materialize_GBs"]))
         del ok, opr, ops
+
+    # BASELINE configs[1] as stated — 2^27 x 2^27 with a SINGLE radix pass of 9 bits (2^18-tuple partitions, the LDS table rebuilt
+    # ~60 times per partition) — timed beside the default two-pass split of the same size, so that the choice of 9+6 bits is visible
+    # where the config is quoted
+    as_stated = None
+    if a.log2n == 27 and not use_dist and not a.no_extras and not a.bits:
+        hj.configure(bits1=9, force_bits=True)
+        assert step() == expect
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            assert step() == expect
+        torch.cuda.synchronize()
+        ms1 = (time.perf_counter() - t0) / 2 * 1e3
+        as_stated = {"radix_bits": [9, 0], "ms_per_step": round(ms1, 3), "value": round(2.0 * n / (ms1 * 1e-3) / 1e9, 3), "unit": "billion tuples/s",
+                     "note": "configs[1] as stated: single-pass radix (9 bits); the default for this size is two passes (%d+%d bits): %.3f ms"
+                             % (hj_cfg_bits[0], hj_cfg_bits[1], ms_per_step)}
+        hj.configure()
 
     cpu = None
     if rank == 0 and not use_dist and not a.no_cpu_baseline:
@@ -773,6 +806,7 @@ def main():
 
     if rank == 0:
         cfg = hj.config()
+        cfg["bits1"], cfg["bits2"] = hj_cfg_bits
         line = {
             "metric": ("billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)
                        if world == 1 else
@@ -790,7 +824,7 @@ def main():
                                     "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
                        "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
                        "partition_layout_R_S": layout, "matches": int(got)},
-            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat,
+            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat, "config2_as_stated": as_stated,
             "cpu_baseline": cpu, "dist": dist_info, "lib_sha256": lib_sha256(),
             "timing": "value/ms_per_step: %d steps with no kernel events (library default); kernels/roofline/probe_phase: %d "
                       "further steps with HIP events around the data-moving kernels" % (a.steps, isteps),

@@ -1830,7 +1830,7 @@ int hj_fill_payload(hj_ctx *c, int32_t *d_pays, uint64_t n, int mode, uint64_t f
 
 int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p, uint64_t n,
               uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch) {
-    if (!c || (kind != 0 && kind != 1) || !reps) return HJ_EINVAL;
+    if (!c || kind < 0 || kind > 3 || !reps) return HJ_EINVAL;
     if (n < 32 || !d_in_k || !d_in_p || !d_out_k || !d_out_p) return fail(c, HJ_EINVAL, "hj_ubench needs four columns of >= 32 tuples");
     if (((uintptr_t)d_in_k | (uintptr_t)d_in_p | (uintptr_t)d_out_k | (uintptr_t)d_out_p) & 15) return fail(c, HJ_EINVAL, "columns must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1847,7 +1847,7 @@ int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p,
     uint64_t lines = n / 32, pow2 = 1;
     while (pow2 * 2 <= lines) pow2 *= 2;
     if (avg_ms) *avg_ms = (double)ms / reps;
-    if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * 16; // 8 B read + 8 B written per tuple
+    if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * (kind >= 2 ? 8 : 16); // 8 B read + 8 B written per tuple (one-way kinds: one of them)
     return HJ_OK;
 }
 

@@ -13,6 +13,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <system_error>
 #include <thread>
@@ -55,12 +56,14 @@ bool host_has_streaming_stores() { return false; }
 void wc_fence() {}
 #endif
 
-void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
+// false: the write-combining buffers could not be allocated (nothing was written)
+bool wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
                                                       const uint64_t *start, int32_t *oK, int32_t *oP, bool stream) {
     // line[p]: 64-byte-aligned output position of the line being filled; fill[p]: next slot; first[p]: first valid slot
     std::vector<uint64_t> line(parts);
     std::vector<uint8_t> fill(parts), first(parts);
-    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4);
+    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = oP ? (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4) : nullptr;
+    if (!bufK || (oP && !bufP)) { free(bufK); free(bufP); return false; }
     for (uint32_t p = 0; p < parts; p++) {
         line[p] = start[p] & ~(uint64_t)(HWC - 1);
         fill[p] = first[p] = (uint8_t)(start[p] & (HWC - 1));
@@ -90,11 +93,11 @@ void wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t
     wc_fence();
     free(bufK);
     free(bufP);
+    return true;
 }
 
 } // namespace
 
-// false: a host thread could not be started (pids limit of the container): nothing usable was written
 int host_numa_nodes() {
     int nodes = 0;
     for (int i = 0; i < 64; i++) {
@@ -129,6 +132,8 @@ std::vector<int> host_node_cpus(int node) {
     return out;
 }
 
+// false: a host thread could not be started (pids limit of the container) or a write-combining buffer could not be allocated:
+// nothing usable was written (the callers report HJ_ENOMEM)
 bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
                        int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
     if (threads < 1) threads = 1;
@@ -169,10 +174,12 @@ bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
     // threads may share the destination line where their runs of a partition meet: both write their own slots with plain
     // stores (first/last line)
     const bool stream = host_has_streaming_stores() && (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
-    return parallel([&](uint32_t t) {
+    std::atomic<bool> scattered{true};
+    const bool started = parallel([&](uint32_t t) {
         uint64_t lo, hi; chunk(t, lo, hi);
-        wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream);
+        if (!wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream)) scattered = false;
     });
+    return started && scattered;
 }
 
 

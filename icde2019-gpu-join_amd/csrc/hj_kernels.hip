@@ -1016,6 +1016,24 @@ __global__ __launch_bounds__(256) void k_ubench(const int4 *__restrict__ ik, con
     }
 }
 
+// KIND 2 / 3: both columns streamed in only (folded into a word that is practically never stored) / streamed out only (a constant):
+// what HBM gives pure reads and pure writes of this shape.  A kernel that reads R bytes and writes W bytes cannot beat
+// (R + W) / (R / read_rate + W / write_rate): the ceiling of ITS mix (the materialising join writes 59 % of its bytes at config 4).
+__global__ __launch_bounds__(256) void k_ubench_oneway(const int4 *__restrict__ ik, const int4 *__restrict__ ip, int4 *__restrict__ ok,
+                                                       int4 *__restrict__ op, uint64_t n16, bool write) {
+    uint32_t acc = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 512; base < n16; base += (uint64_t)gridDim.x * 512) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u >= n16) continue;
+            if (write) { const int4 v = make_int4((int)u, 1, 2, 3); ok[u] = v; op[u] = v; }
+            else { const int4 a = ik[u], b = ip[u]; acc += (uint32_t)(a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w); }
+        }
+    }
+    if (!write && acc == 0x9E3779B9u) ok[0] = make_int4(0, 0, 0, 0); // practically never: keeps the loads alive
+}
+
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n) {
     const uint64_t n16 = n / 4;
     uint64_t lines = n16 / 8, pow2 = 1;
@@ -1031,6 +1049,10 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
     dim3 g(blocks), b(256);
     const uint64_t mul = 0x9E3779B97F4A7C15ULL | 1;
 #define UB(K_, U_) hipLaunchKernelGGL((k_ubench<K_, U_>), g, b, 0, st, (const int4 *)ik, (const int4 *)ip, (int4 *)ok, (int4 *)op, used16, K_ ? pow2 - 1 : (uint64_t)0, mul, nt)
+    if (kind == 2 || kind == 3) { // read-only / write-only streams of both columns: the two ends of a kernel's read:write mix
+        hipLaunchKernelGGL(k_ubench_oneway, g, b, 0, st, (const int4 *)ik, (const int4 *)ip, (int4 *)ok, (int4 *)op, n16, kind == 3);
+        return hipGetLastError();
+    }
     if (kind == 0) { if (unr == 1) UB(0, 1); else if (unr == 2) UB(0, 2); else if (unr == 8) UB(0, 8); else UB(0, 4); }
     else { if (unr == 1) UB(1, 1); else if (unr == 2) UB(1, 2); else if (unr == 8) UB(1, 8); else UB(1, 4); }
 #undef UB

@@ -322,10 +322,11 @@ class HashJoin:
         self._ck(self._L.hj_fill_payload(self._h, _dev_ptr(d_pays), n, _PAYLOAD[payload], first_rowid))
 
     def ubench(self, kind, in_k, in_p, out_k, out_p, n, reps=5):
-        """HBM ceiling of a radix pass's access pattern with no partitioning work: kind 'copy' or 'line_scatter'.
-        Returns GB/s (bytes read + written per second)."""
+        """HBM ceiling of a radix pass's access pattern with no partitioning work: kind 'copy' or 'line_scatter'; 'read' / 'write':
+        both columns streamed in only / out only (the two ends of a kernel's read:write mix).  Returns GB/s (bytes read + written
+        per second)."""
         ms, nb = C.c_double(), C.c_uint64()
-        self._ck(self._L.hj_ubench(self._h, {"copy": 0, "line_scatter": 1}[kind], _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(out_k),
+        self._ck(self._L.hj_ubench(self._h, {"copy": 0, "line_scatter": 1, "read": 2, "write": 3}[kind], _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(out_k),
                                    _dev_ptr(out_p), n, reps, C.byref(ms), C.byref(nb)))
         return nb.value / (ms.value * 1e-3) / 1e9
 

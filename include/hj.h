@@ -252,7 +252,9 @@ int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_
 /* ---- measurement: on-box HBM ceilings of the two access patterns of a radix pass, no partitioning work.
  *      kind 0 = stream copy of a (key, payload) column pair, 16 bytes per lane; kind 1 = same streaming reads, every
  *      128-byte line stored at a pseudo-random aligned line position (the write pattern of the write-combining
- *      flush).  avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
+ *      flush); kind 2 = both input columns streamed in only, kind 3 = both output columns streamed out only (what HBM gives
+ *      pure reads / pure writes: a kernel reading R and writing W bytes is bounded by (R + W) / (R / read + W / write)).
+ *      avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
 int hj_ubench(hj_ctx *ctx, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p,
               uint64_t n, uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch);
 

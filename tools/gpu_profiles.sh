@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-3 evidence: bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/r3prof/ (copy what should be judged
+# round-4 evidence: bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/r4prof/ (copy what should be judged
 # into profiles/).  --pmc runs are separate from --kernel-trace --stats runs and never combined with sys/runtime tracing.
 cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
-OUT=$ROOT/gpurun_out/r3prof
+OUT=$ROOT/gpurun_out/r4prof
 mkdir -p $OUT
 cd $ROOT
 sha256sum icde2019-gpu-join_amd/libhj.so > $OUT/libhj.sha256
@@ -12,6 +12,8 @@ python bench.py --steps 10 --warmup 3 --log2n 27 > $OUT/bench_2p27.json 2>/dev/n
 python bench.py --steps 10 --warmup 3 --exact-only --no-cpu-baseline > $OUT/bench_2p30_exact.json 2>/dev/null
 python bench.py --workload zipf --steps 5 --warmup 2 > $OUT/bench_zipf.json 2>/dev/null; echo "zipf rc=$?"
 python bench.py --workload zipf --steps 5 --warmup 2 --exact-only --no-cpu-baseline > $OUT/bench_zipf_exact.json 2>/dev/null; echo "zipf exact rc=$?"
+python bench.py --workload zipf --zipf-sizes 24 27 --build-side 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_zipf_24_27_pk_builds.json 2>/dev/null
+python bench.py --workload zipf --zipf-sizes 24 27 --build-side 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_zipf_24_27_zipf_builds.json 2>/dev/null; echo "zipf-builds rc=$?"
 python bench.py --workload stream --steps 3 --warmup 1 > $OUT/bench_stream.json 2>/dev/null; echo "stream rc=$?"
 python bench.py --workload coprocess --log2n 27 --steps 3 --warmup 1 > $OUT/bench_coprocess.json 2>/dev/null; echo "coprocess rc=$?"
 python bench.py --steps 5 --warmup 2 --force-dist --no-cpu-baseline > $OUT/bench_forcedist.json 2>/dev/null; echo "forcedist rc=$?"
@@ -19,7 +21,6 @@ for g in 2 4 8; do python bench.py --steps 5 --warmup 2 --force-dist --phantom $
 python bench.py --steps 5 --warmup 2 --force-dist --phantom 8 --single-group --no-cpu-baseline > $OUT/bench_phantom8_single_group.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --force-dist --dist-impl torch --no-cpu-baseline > $OUT/bench_forcedist_torch.json 2>/dev/null
 python tools/step_vs_size.py 2>/dev/null > $OUT/step_vs_size.txt
-python tools/handoff_gate.py 2>/dev/null > $OUT/handoff_gate.txt
 for l in 24 27 30; do python bench.py --workload baselines --log2n $l --steps 3 --warmup 1 2>/dev/null; done > $OUT/bench_baselines.json
 cd /tmp
 # per-kernel durations: the passes of R and S serialised (HJ_FORK_LOG2=0), as in bench.py's instrumented steps — with the two
@@ -32,9 +33,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python
 for d in stats30 stats27 statszipf; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; done
 unset HJ_FORK_LOG2
 cd $ROOT
-tools/pmc_collect.sh r3prof/pmc30
-tools/pmc_collect.sh r3prof/pmc30_mat --with-materialize
-tools/pmc_collect.sh r3prof/pmc27 --log2n 27
-tools/pmc_collect.sh r3prof/pmczipf --workload zipf --warmup 1
-rm -rf $OUT/pmc30/p? $OUT/pmc30_mat/p? $OUT/pmc27/p? $OUT/pmczipf/p?
+tools/pmc_collect.sh r4prof/pmc30
+tools/pmc_collect.sh r4prof/pmc30_mat --with-materialize
+tools/pmc_collect.sh r4prof/pmc27 --log2n 27
+tools/pmc_collect.sh r4prof/pmczipf --workload zipf --warmup 1
+tools/pmc_collect.sh r4prof/pmczipf_mat --with-materialize --workload zipf --warmup 1
+rm -rf $OUT/pmc30/p? $OUT/pmc30_mat/p? $OUT/pmc27/p? $OUT/pmczipf/p? $OUT/pmczipf_mat/p?
 ls -la $OUT

@@ -13,18 +13,23 @@ import sys
 
 def main():
     d = sys.argv[1]
-    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
             if not any(x in name for x in ("k_scatter", "k_hist", "k_join", "k_part", "k_copy")):
                 continue
-            a = agg[name][r["Counter_Name"]]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
+            vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
-    for k, cs in sorted(agg.items()):
-        e = {c: {"launches": n, "per_launch": v / n} for c, (n, v) in sorted(cs.items())}
+    for k, cs in sorted(vals.items()):
+        # Launches that did nothing are left out of the per-launch means: a kernel that finds its relation's overflow flag up returns
+        # at once (the optimistic attempt on a skewed relation, the join behind it), and averaging those in would make a launch look
+        # as if it moved less than its algorithmic bytes.  "Did nothing" = below 2 % of the largest launch of that kernel and counter.
+        e = {}
+        for c, v in sorted(cs.items()):
+            top = max(v)
+            kept = [x for x in v if top <= 0 or x >= 0.02 * top]
+            e[c] = {"launches": len(kept), "per_launch": sum(kept) / len(kept), "empty_launches_dropped": len(v) - len(kept)}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE"]["per_launch"] + e["WRITE_SIZE"]["per_launch"]) * 1024
         if "SQ_LDS_IDX_ACTIVE" in e and "SQ_LDS_BANK_CONFLICT" in e and e["SQ_LDS_IDX_ACTIVE"]["per_launch"]:
