@@ -699,7 +699,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok = true) {
     // workgroup looping over hundreds of table chunks.
     // The same items serve a designated build relation that is the LARGER one (hj_config.build_side): the radix bits follow the smaller
     // relation (choose_bits), so its partitions would not fit the table either.
-    const bool general = gen_ok && (B.sampled || B.prefer_exact || B.n > Pb.n);
+    const bool general = gen_ok && (B.sampled || B.prefer_exact || (B.n > Pb.n && !c->force_build_r)); // (streaming probe: R builds by design, bits follow |R|)
     // sampled probe side: several ranges per partition.  Whole ranges are packed into list items (one table build for all of them)
     const bool lists = Pb.sampled && Pb.pr0;
     const uint32_t nparts = (lists || general) ? Pb.nparts : Pb.nranges; // planning threads: partitions, or probe RANGES (== partitions unless sampled)
@@ -1380,8 +1380,6 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
     c->rel[HJ_REL_S].sampled_failed = false; c->rel[HJ_REL_S].sp.valid = false;
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
-    const bool saved_plain = c->plain_items;
-    c->plain_items = h_out != nullptr; // the per-segment second probe reads plain items
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
     c->rel[HJ_REL_S].in_k = (const int32_t *)c->seg_k[0].p;
     c->rel[HJ_REL_S].in_p = (const int32_t *)c->seg_p[0].p;
@@ -1449,59 +1447,122 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
         }
         goto done;
     }
-    if (!rc && nseg) rc = issue_copy(0);
-    for (uint64_t i = 0; i < nseg && !rc; i++) {
-        const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
-        const int b = (int)(i & 1);
-        // the other buffer is free: the segment that used it was joined (and synchronised) last iteration
-        if (i + 1 < nseg) { rc = issue_copy(i + 1); if (rc) break; }
-        hipError_t e = hipStreamWaitEvent(c->stream, c->seg_ready[b], 0);
-        if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
-        if (payload_mode != HJ_PAYLOAD_GIVEN) {
-            e = launch_fill(c->stream, (int32_t *)c->seg_p[b].p, cnt, payload_mode, off); // row ids are global
-            if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "fill: %s", hipGetErrorString(e)); break; }
+    if (!rc && nseg) {
+        // ---- materialising (hjcp.cu:1917-1961): ONE probe per segment writes (key, payR, payS) into double-buffered device columns
+        // (k_join_mat_reg; the two-probe form this replaces counted every segment, read the count back, then probed again).  The
+        // size of a segment's output is known on the device only, and the D2H copy needs it on the host — so the host looks at
+        // segment i's cursor ONE SEGMENT LATER: while it waits for it, the device already has segment i+1's copy, partition passes
+        // and probe queued, and never idles (the reference chains its segments by events, hjcp.cu:1897-1965, and folds what does
+        // not fit its ring, D6; here every tuple is kept).  Output columns are sized for one match per probe tuple; a segment that
+        // produces more (duplicates in R), or whose slots overflowed (skew in S), wrote nothing usable: those few are redone at the
+        // end through the blocking path, with exact sizes. ----
+        if ((rc = resolve_layout(c, R))) goto done; // R's flag is read once, before the loop [sync]
+        uint64_t *sc = (uint64_t *)c->scalars.p;
+        hipEvent_t ev_done[2] = {nullptr, nullptr};
+        uint64_t *h_seg = nullptr; // pinned: per parity {cursor, S's overflow flag, aggregate}
+        std::vector<uint64_t> redo;
+        Buf d_seg;
+        const uint64_t ocap = seg + seg / 8 + 1024;
+        if (hipHostMalloc((void **)&h_seg, 2 * 4 * 8, hipHostMallocDefault) != hipSuccess) { rc = fail(c, HJ_ENOMEM, "pinned result block"); goto done; }
+        for (int b = 0; b < 2 && !rc; b++) {
+            if (hipEventCreateWithFlags(&ev_done[b], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
+            if (!rc) rc = ensure(c, c->out_k[b], (size_t)(ocap + PAD) * 4);
+            if (!rc) rc = ensure(c, c->out_p1[b], (size_t)(ocap + PAD) * 4);
+            if (!rc) rc = ensure(c, c->out_p2[b], (size_t)(ocap + PAD) * 4);
         }
-        Rel &S = c->rel[HJ_REL_S];
-        S.in_k = (const int32_t *)c->seg_k[b].p; S.in_p = (const int32_t *)c->seg_p[b].p; S.n = cnt; S.bound = true;
-        invalidate(c, HJ_REL_S);
-        if ((rc = partition_rel(c, HJ_REL_S))) break;
-        uint64_t m = 0, a = 0;
-        if ((rc = hj_join_count(c, &m, &a))) break; // [sync]: the next copy is already in flight
-        if (h_out && m) {
-            // the device output buffers of this parity were last read by the D2H copies of segment i-2
+        if (!rc) rc = ensure(c, d_seg, 2 * 4 * 8);
+        // what segment j left behind: copy its output to the host columns, or put it on the redo list
+        auto finalize = [&](uint64_t j) -> int {
+            const int b = (int)(j & 1);
+            if (hipEventSynchronize(ev_done[b]) != hipSuccess) return fail(c, HJ_EHIP, "hipEventSynchronize");
+            const uint64_t m = h_seg[4 * b], flagged = h_seg[4 * b + 1] & 0xFFFFFFFFu, a = h_seg[4 * b + 2];
+            if (flagged || m > ocap) { redo.push_back(j); return 0; }
+            const uint64_t room = tot_m < out_cap ? out_cap - tot_m : 0, take = m < room ? m : room;
+            if (take) {
+                if (hipStreamWaitEvent(c->d2h, ev_done[b], 0) != hipSuccess) return fail(c, HJ_EHIP, "hipStreamWaitEvent");
+                const void *src[3] = {c->out_k[b].p, c->out_p1[b].p, c->out_p2[b].p};
+                for (int q = 0; q < 3; q++)
+                    if (hipMemcpyAsync(h_out[q] + tot_m, src[q], take * 4, hipMemcpyDeviceToHost, c->d2h) != hipSuccess) return fail(c, HJ_EHIP, "D2H of the output");
+            }
+            if (hipEventRecord(c->out_free[b], c->d2h) != hipSuccess) return fail(c, HJ_EHIP, "event");
+            out_used[b] = true;
+            tot_m += m; tot_a += a;
+            return 0;
+        };
+        if (!rc) rc = issue_copy(0);
+        for (uint64_t i = 0; i < nseg && !rc; i++) {
+            const uint64_t off = i * seg, cnt = (off + seg <= n) ? seg : n - off;
+            const int b = (int)(i & 1);
+            // staging buffer b^1 was last read by the probe of segment i-1 (still queued or running): the copy of segment i+1 waits for it
+            if (i + 1 < nseg) {
+                if (i >= 1 && hipStreamWaitEvent(c->copy, ev_done[b ^ 1], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
+                if ((rc = issue_copy(i + 1))) break;
+            }
+            if (hipStreamWaitEvent(c->stream, c->seg_ready[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
+            if (payload_mode != HJ_PAYLOAD_GIVEN && launch_fill(c->stream, (int32_t *)c->seg_p[b].p, cnt, payload_mode, off) != hipSuccess) { rc = fail(c, HJ_EHIP, "fill"); break; } // row ids are global
+            Rel &S = c->rel[HJ_REL_S];
+            S.in_k = (const int32_t *)c->seg_k[b].p; S.in_p = (const int32_t *)c->seg_p[b].p; S.n = cnt; S.bound = true;
+            invalidate(c, HJ_REL_S);
+            if ((rc = partition_rel(c, HJ_REL_S))) break;
+            // the device output columns of this parity were last read by the D2H copies of segment i-2
             if (out_used[b] && hipStreamWaitEvent(c->stream, c->out_free[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent"); break; }
-            if ((rc = ensure(c, c->out_k[b], (size_t)(m + PAD) * 4)) || (rc = ensure(c, c->out_p1[b], (size_t)(m + PAD) * 4)) ||
-                (rc = ensure(c, c->out_p2[b], (size_t)(m + PAD) * 4))) break;
-            JoinArgs ja = c->last_args; // item list + per-wave counts of this segment are on the device
-            if ((rc = scan_wave_counts(c))) break;
-            ja.wave_scanned = (const uint64_t *)c->wave_counts.p;
-            ja.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
+            JoinArgs ja;
+            bool tag16 = false;
+            if ((rc = plan_join(c, ja, tag16))) break;
             ja.out_key = (int32_t *)c->out_k[b].p;
             ja.out_bpay = (int32_t *)c->out_p1[b].p; // R builds: build payload = payR
             ja.out_ppay = (int32_t *)c->out_p2[b].p;
-            ja.out_cap = m;
-            { Timed t(c, "k_join_mat_2nd_probe");
-              if (launch_join(c->stream, ja, c->max_items, c->last_tag16, 1) != hipSuccess) { rc = fail(c, HJ_EHIP, "materialise launch"); break; } }
+            ja.out_cap = ocap;
+            { Timed tm(c, "k_join_materialize"); if (launch_join_mat_reg(c->stream, ja, c->max_items, tag16) != hipSuccess) { rc = fail(c, HJ_EHIP, "materialise launch"); break; } }
             c->join_planned = false;
-            if (hipEventRecord(c->out_ready[b], c->stream) != hipSuccess || hipStreamWaitEvent(c->d2h, c->out_ready[b], 0) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); break; }
-            const uint64_t room = tot_m < out_cap ? out_cap - tot_m : 0, take = m < room ? m : room;
-            if (take) {
-                const void *src[3] = {c->out_k[b].p, c->out_p1[b].p, c->out_p2[b].p};
-                for (int q = 0; q < 3 && !rc; q++)
-                    if (hipMemcpyAsync(h_out[q] + tot_m, src[q], take * 4, hipMemcpyDeviceToHost, c->d2h) != hipSuccess) rc = fail(c, HJ_EHIP, "D2H of the output");
-                if (rc) break;
-            }
-            if (hipEventRecord(c->out_free[b], c->d2h) != hipSuccess) { rc = fail(c, HJ_EHIP, "event"); break; }
-            out_used[b] = true;
+            uint64_t *slot = (uint64_t *)d_seg.p + 4 * b;
+            if (hipMemsetAsync(slot + 2, 0, 8, c->stream) != hipSuccess ||
+                launch_dot(c->stream, (const int32_t *)c->out_p1[b].p, (const int32_t *)c->out_p2[b].p, sc + 10, ocap, slot + 2) != hipSuccess ||
+                hipMemcpyAsync(slot, sc + 10, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(slot + 1, sc + 8 + HJ_REL_S, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(h_seg + 4 * b, slot, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipEventRecord(ev_done[b], c->stream) != hipSuccess) { rc = fail(c, HJ_EHIP, "segment result"); break; }
+            if (i >= 1 && (rc = finalize(i - 1))) break; // one segment behind: the device has segment i queued while the host waits here
         }
-        tot_m += m; tot_a += a;
+        if (!rc && nseg) rc = finalize(nseg - 1);
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(c, HJ_EHIP, "hipStreamSynchronize");
+        (void)hipStreamSynchronize(c->copy);
+        // the few segments that did not fit / overflowed their slots: blocking redo with exact sizes (count, then one probe)
+        for (size_t r = 0; r < redo.size() && !rc; r++) {
+            const uint64_t j = redo[r], off = j * seg, cnt = (off + seg <= n) ? seg : n - off;
+            if (hipMemcpy(c->seg_k[0].p, h_keys + off, cnt * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                (payload_mode == HJ_PAYLOAD_GIVEN && hipMemcpy(c->seg_p[0].p, h_pays + off, cnt * 4, hipMemcpyHostToDevice) != hipSuccess)) { rc = fail(c, HJ_EHIP, "H2D"); break; }
+            if (payload_mode != HJ_PAYLOAD_GIVEN && launch_fill(c->stream, (int32_t *)c->seg_p[0].p, cnt, payload_mode, off) != hipSuccess) { rc = fail(c, HJ_EHIP, "fill"); break; }
+            Rel &S = c->rel[HJ_REL_S];
+            S.in_k = (const int32_t *)c->seg_k[0].p; S.in_p = (const int32_t *)c->seg_p[0].p; S.n = cnt; S.bound = true;
+            S.prefer_exact = false; S.sampled_failed = false; S.sp.valid = false;
+            invalidate(c, HJ_REL_S);
+            if ((rc = partition_rel(c, HJ_REL_S))) break;
+            uint64_t m = 0, a = 0;
+            if ((rc = hj_join_count(c, &m, &a))) break; // [sync]; re-partitions S along the skew ladder
+            if (m) {
+                if (hipStreamSynchronize(c->d2h) != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamSynchronize"); break; } // the columns may grow: nothing may still read them
+                if ((rc = ensure(c, c->out_k[0], (size_t)(m + PAD) * 4)) || (rc = ensure(c, c->out_p1[0], (size_t)(m + PAD) * 4)) ||
+                    (rc = ensure(c, c->out_p2[0], (size_t)(m + PAD) * 4))) break;
+                uint64_t nout = 0;
+                if ((rc = hj_join_materialize(c, (int32_t *)c->out_k[0].p, (int32_t *)c->out_p1[0].p, (int32_t *)c->out_p2[0].p, m, &nout))) break;
+                const uint64_t room = tot_m < out_cap ? out_cap - tot_m : 0, take = m < room ? m : room;
+                const void *src[3] = {c->out_k[0].p, c->out_p1[0].p, c->out_p2[0].p};
+                for (int q = 0; q < 3 && !rc && take; q++)
+                    if (hipMemcpy(h_out[q] + tot_m, src[q], take * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, HJ_EHIP, "D2H of the output");
+            }
+            tot_m += m; tot_a += a;
+        }
+        for (int b = 0; b < 2; b++) if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
+        if (c->d2h) (void)hipStreamSynchronize(c->d2h);
+        if (h_seg) (void)hipHostFree(h_seg);
+        release(d_seg);
     }
 done:
     // on every exit path: the H2D copy of the next segment may still be reading the caller's columns
     (void)hipStreamSynchronize(c->copy);
     if (c->d2h) (void)hipStreamSynchronize(c->d2h);
     c->force_build_r = saved_force;
-    c->plain_items = saved_plain;
     c->rel[HJ_REL_S].bound = false; // the staging buffers are not a user relation: S is unbound afterwards (hj.h)
     c->rel[HJ_REL_S].n = 0;
     invalidate(c, HJ_REL_S);

@@ -149,6 +149,7 @@ hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, con
                              uint64_t np, int32_t *lookup, uint64_t range, uint64_t *out2);
 hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *bp, uint64_t nb, const int32_t *pk, const int32_t *pp,
                              uint64_t np, uint32_t log_slots, int32_t *head, int32_t *next, uint64_t *out2);
+hipError_t launch_dot(hipStream_t st, const int32_t *a, const int32_t *b, const uint64_t *n_ptr, uint64_t cap, uint64_t *out);
 hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out);
 hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first);
 hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);

@@ -1751,6 +1751,22 @@ __global__ __launch_bounds__(256) void k_sum2(const uint64_t *__restrict__ cnt, 
     }
 }
 
+// sum of a[i] * b[i] (int32 x int32 -> int64, mod 2^64) over the first min(*n_ptr, cap) elements, added to *out: the aggregate
+// (sum payR * payS) of a materialised output whose length is known on the device only (streaming materialising probe)
+__global__ __launch_bounds__(256) void k_dot(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const unsigned long long *__restrict__ n_ptr,
+                                             uint64_t cap, unsigned long long *__restrict__ out) {
+    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+    uint64_t s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        s += (uint64_t)((int64_t)a[i] * (int64_t)b[i]);
+    s = wave_sum64(s);
+    if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+hipError_t launch_dot(hipStream_t st, const int32_t *a, const int32_t *b, const uint64_t *n_ptr, uint64_t cap, uint64_t *out) {
+    hipLaunchKernelGGL(k_dot, dim3(1024), dim3(256), 0, st, a, b, reinterpret_cast<const unsigned long long *>(n_ptr), cap, reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
 // sum of a device-sized uint64 array (per-wave aggregates) into *out (zeroed by the caller)
 __global__ __launch_bounds__(256) void k_reduce64(const uint64_t *__restrict__ data, const uint32_t *__restrict__ len_ptr,
                                                   uint64_t mul, unsigned long long *__restrict__ out) {

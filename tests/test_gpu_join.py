@@ -597,6 +597,41 @@ def test_stream_probe_materialize(P, seg):
         assert ei.value.code == -4 and all(np.all(x[em // 2:] == -7) for x in out)
 
 
+def test_stream_probe_materialize_segments_that_do_not_fit_are_redone(P):
+    """The materialising streaming loop writes every segment's output in ONE probe into device columns sized for one match per
+    probe tuple and looks at a segment's cursor one segment later (no blocking read per segment).  A segment that produces more
+    (every R key three times here), or whose slots overflowed (half of a segment one key), left nothing usable: it is redone at
+    the end with exact sizes.  The multiset over all segments must still equal the oracle's, the aggregate too."""
+    rng = np.random.default_rng(79)
+    nR, nS, seg = 3 * 20_000, 1 << 19, 1 << 17
+    base = rng.permutation(20_000).astype(np.int32)
+    R = np.concatenate([base, base, base])                          # 3 matches per probe tuple: every segment exceeds its columns
+    S = base[rng.integers(0, 20_000, nS)].astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = np.arange(nS, dtype=np.int32)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    assert em == 3 * nS
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=4, bits2=3)
+        hj.load_host(P.REL_R, R, Pr)
+        (k, pr, ps), agg = hj.join_stream_probe_materialize(S, Ps, segment_tuples=seg)
+        assert len(k) == em and agg == eagg and o.triples_checksum(k, pr, ps) == echk
+    # unique R, two of four segments skewed (slot overflow -> redo), the others take the one-probe road
+    R = rng.permutation(1 << 16).astype(np.int32)
+    S = R[rng.integers(0, 1 << 16, nS)].astype(np.int32)
+    S[: seg // 2] = R[5]
+    S[2 * seg: 2 * seg + seg // 2] = R[9]
+    Pr = np.arange(len(R), dtype=np.int32)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=5, bits2=4)
+        hj.load_host(P.REL_R, R, Pr)
+        for _ in range(2):
+            (k, pr, ps), agg = hj.join_stream_probe_materialize(S, Ps, segment_tuples=seg)
+            assert len(k) == em and agg == eagg and o.triples_checksum(k, pr, ps) == echk
+            assert np.array_equal(R[pr], k) and np.array_equal(S[ps], k)
+
+
 def test_stream_probe_edge_cases(P):
     R = np.arange(100, dtype=np.int32)
     with P.HashJoin(0) as hj:
