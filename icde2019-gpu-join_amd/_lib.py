@@ -20,7 +20,7 @@ vp = C.c_void_p
 class Config(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("force_bits", C.c_uint32),
                 ("build_side", C.c_uint32), ("lds_capacity", C.c_uint32), ("lds_heads", C.c_uint32),
-                ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("materialize_two_pass", C.c_uint32),
+                ("probe_chunk", C.c_uint32), ("exact_only", C.c_uint32), ("reserved1", C.c_uint32),
                 ("reserved0", C.c_uint32), ("graph", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 

@@ -754,11 +754,10 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok = true) {
     return 0;
 }
 
-// work-item list + per-wave counts (the scan of the counts is only run when the two-probe materialising path follows)
+// work-item list + per-wave counts + their sums
 int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nullptr) {
-    // general items are for the count kernel and the one-probe materialiser; the late-materialising kernel and a count whose wave
-    // counts feed the second probe of the two-probe path want plain items
-    RET(plan_join(c, a_out, tag16, !late && !c->cfg.materialize_two_pass && !c->plain_items));
+    // general items are for the count kernel and the one-probe materialiser; the late-materialising kernel wants plain items
+    RET(plan_join(c, a_out, tag16, !late));
     JoinArgs &a = a_out;
     hipStream_t st = c->stream;
     uint64_t *sc = (uint64_t *)c->scalars.p;
@@ -772,22 +771,8 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     }
     // n_items is a uint64 on the device; the reductions take its low word as their length (little endian)
     const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
-    // matches and aggregate in one launch into sc[1], sc[2] (zeroed by k_join_plan); the exclusive scan of the per-wave
-    // counts — the output offsets — is only run when a materialising call follows (scan_wave_counts)
+    // matches and aggregate in one launch into sc[1], sc[2] (zeroed by k_join_plan)
     { Timed t(c, "k_sum2"); HIPCHK(c, launch_sum2(st, a.wave_counts, a.wave_agg, len, JOIN_WAVES, sc + 1)); }
-    c->waves_scanned = false;
-    return 0;
-}
-
-// exclusive scan of the per-wave match counts of the last run_count, in place: the materialising kernel's offsets
-int scan_wave_counts(hj_ctx *c) {
-    if (c->waves_scanned) return 0;
-    uint64_t *sc = (uint64_t *)c->scalars.p;
-    const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
-    const uint64_t nwave = (uint64_t)c->max_items * JOIN_WAVES;
-    { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u64(c->stream, (uint64_t *)c->wave_counts.p, len, JOIN_WAVES, nwave, (uint64_t *)c->jchunk_sums.p,
-                                                      (uint64_t *)c->jchunk_prefix.p, sc + 3)); }
-    c->waves_scanned = true;
     return 0;
 }
 
@@ -950,6 +935,7 @@ int hj_configure(hj_ctx *c, const hj_config *cfg) {
     if (cfg->bits1 > 9 || cfg->bits2 > 9) return fail(c, HJ_EINVAL, "at most 9 radix bits per pass");
     if (cfg->lds_capacity > 65535) return fail(c, HJ_EINVAL, "lds_capacity must be <= 65535 (16-bit chain links)");
     if (cfg->lds_heads & (cfg->lds_heads - 1)) return fail(c, HJ_EINVAL, "lds_heads must be a power of two");
+    if (cfg->reserved0 || cfg->reserved1) return fail(c, HJ_EINVAL, "hj_config.lds_stage / materialize_two_pass were removed (one-probe materialisation is the only form): the fields must be 0");
     c->cfg = *cfg;
     invalidate(c);
     drop_graph(c);
@@ -965,7 +951,6 @@ int hj_get_config(const hj_ctx *c, hj_config *cfg) {
     cfg->build_side = c->build == HJ_REL_R ? 1 : 2;
     cfg->lds_capacity = c->cap; cfg->lds_heads = c->nh; cfg->probe_chunk = c->chunk;
     cfg->exact_only = c->cfg.exact_only || !c->fast_path;
-    cfg->materialize_two_pass = c->cfg.materialize_two_pass;
     cfg->graph = c->cfg.graph;
     return HJ_OK;
 }
@@ -1039,32 +1024,6 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
 
 namespace {
 
-// the two-probe path: count (unless the counts of these partitions are on the device already), scan, second probe writing
-// at the scanned per-wave positions: deterministic given the partitions, no output atomics (hj_config.materialize_two_pass)
-int materialize_two_pass(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
-    JoinArgs a;
-    bool tag16;
-    const bool reuse = c->join_planned;
-    if (reuse) { a = c->last_args; tag16 = c->last_tag16; }
-    else {
-        RET(count_and_fetch(c, a, tag16)); // the count also proves the partitions valid (overflow flags)
-        c->last_matches = c->h_scalars[1]; c->last_agg = c->h_scalars[2];
-    }
-    RET(scan_wave_counts(c));
-    a.wave_scanned = (const uint64_t *)c->wave_counts.p;
-    a.wave_chunk_prefix = (const uint64_t *)c->jchunk_prefix.p;
-    a.out_key = d_key;
-    a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
-    a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
-    a.out_cap = cap;
-    { Timed t(c, "k_join_mat_2nd_probe"); HIPCHK(c, launch_join(c->stream, a, c->max_items, tag16, 1)); }
-    c->join_planned = false; // conservative: one reuse per count
-    RET(fetch_scalars(c));   // [sync]: the output columns are complete when this returns
-    c->h_scalars[1] = c->last_matches; c->h_scalars[2] = c->last_agg;
-    if (n_out) *n_out = c->h_scalars[1];
-    return 0;
-}
-
 // ONE probe: plan the work items, k_join_mat_reg finds, reserves and writes; the cursor comes back with the result block
 int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -1104,8 +1063,7 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t n = 0;
-    if (c->cfg.materialize_two_pass) RET(materialize_two_pass(c, d_key, d_payR, d_payS, cap, &n));
-    else RET(materialize_one_probe(c, d_key, d_payR, d_payS, cap, &n));
+    RET(materialize_one_probe(c, d_key, d_payR, d_payS, cap, &n));
     if (n_out) *n_out = n;
     if (n > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu", (unsigned long long)n, (unsigned long long)cap);
     return HJ_OK;

@@ -85,7 +85,6 @@ struct hj_ctx {
     Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
-    bool waves_scanned = false;    // ... and the per-wave counts have been scanned into output offsets
     hj::JoinArgs last_args{};
     bool last_tag16 = false;
     uint64_t last_matches = 0, last_agg = 0;
@@ -96,7 +95,6 @@ struct hj_ctx {
     int ncu = 256;                  // CUs of the device
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
-    bool plain_items = false;       // ... and its per-segment second probe wants plain work items (no general items)
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)

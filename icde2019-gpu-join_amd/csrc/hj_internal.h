@@ -95,7 +95,6 @@ struct JoinArgs {
     const uint64_t *n_items;
     uint32_t radix_bits, cap, nh, chunk;
     uint64_t *wave_counts, *wave_agg;                     // count kernel outputs [items * JOIN_WAVES]
-    const uint64_t *wave_scanned, *wave_chunk_prefix;     // materialise: scanned wave_counts
     int32_t *out_key, *out_bpay, *out_ppay;
     uint64_t out_cap;
     unsigned long long *out_cursor; // one-probe materialisation: next free output position (zeroed by k_join_plan)
@@ -109,8 +108,6 @@ hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n, uint32_t 
 hipError_t launch_plan(hipStream_t st, const PassArgs &pa);
 hipError_t launch_hist(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
-hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
                            uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out);
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff);
 hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
@@ -141,7 +138,7 @@ hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts
                               const uint64_t *chunk_prefix, JoinItem *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t join_set_lds_limit(int device, size_t bytes);
-hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count, 1 materialise (second probe, scanned positions), 2 late materialisation
+hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16, int jm); // jm: 0 count + aggregate, 2 late materialisation
 size_t join_mat_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);
 hipError_t launch_join_mat_reg(hipStream_t st, const JoinArgs &a, uint32_t max_items, bool tag16); // materialise in ONE probe, matches held in registers
 hipError_t launch_np_max(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t *out_max);

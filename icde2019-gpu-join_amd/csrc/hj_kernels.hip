@@ -1281,7 +1281,7 @@ hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t np
 // what the reference does for build partitions that do not fit its table (jp.cu:929-1003).  Count and aggregate are symmetric.
 template <bool TAG16, int JM, bool GEN = false>
 __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
-    constexpr bool MAT = JM == 1;
+    static_assert(JM == 0 || JM == 2, "JM: 0 = count + aggregate, 2 = late materialisation (the second probe of round 2's two-probe materialiser, JM 1, is gone)");
     static_assert(!GEN || JM == 0, "general items: count kernel and k_join_mat_reg only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t item = blockIdx.x;
@@ -1321,13 +1321,6 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; };
 
     uint64_t my_matches = 0, my_agg = 0;
-    uint64_t cur = 0; // MAT: next output slot of this wave
-    if (MAT) {
-        uint64_t idx = (uint64_t)item * JOIN_WAVES + wave;
-        cur = a.wave_scanned[idx] + a.wave_chunk_prefix[idx >> SCAN_CHUNK_LOG];
-    }
-    const uint64_t lt_mask = ((uint64_t)1 << lane_id()) - 1;
-
     while (tb < te) { // one table chunk per iteration: the next cap tuples of the table side
         uint64_t gb = tb;
         uint32_t nbc = (uint32_t)(te - tb < a.cap ? te - tb : a.cap), filled = 0;
@@ -1441,63 +1434,34 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 const int32_t ppay = elem(pv, e);
                 uint32_t pos = valid ? head[hidx(key)] : 0xFFFFFFFFu;
                 pos &= 0xFFFFu; // chain links are 16 bit; 0xFFFF = end
-                if (!MAT) {
-                    while (pos != 0xFFFFu) {
-                        const uint2 en = ent[pos];
-                        const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
-                        if (eq) {
-                            my_matches++;
-                            if (JM == 2) {
-                                // late materialisation (join_partitioned_varpayload, jp.cu:1524-1533): payloads are
-                                // row ids; gather the extra columns of both sides and add them up
-                                const int32_t bval = (int32_t)en.y;
-                                int64_t acc = 0;
-                                for (uint32_t z = 0; z < a.ncp; z++) acc += a.Dp[(uint64_t)(uint32_t)ppay + z * a.sp];
-                                for (uint32_t z = 0; z < a.ncb; z++) acc += a.Db[(uint64_t)(uint32_t)bval + z * a.sb];
-                                my_agg += (uint64_t)acc;
-                            } else {
-                                my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)ppay);
-                            }
+                while (pos != 0xFFFFu) {
+                    const uint2 en = ent[pos];
+                    const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
+                    if (eq) {
+                        my_matches++;
+                        if (JM == 2) {
+                            // late materialisation (join_partitioned_varpayload, jp.cu:1524-1533): payloads are
+                            // row ids; gather the extra columns of both sides and add them up
+                            const int32_t bval = (int32_t)en.y;
+                            int64_t acc = 0;
+                            for (uint32_t z = 0; z < a.ncp; z++) acc += a.Dp[(uint64_t)(uint32_t)ppay + z * a.sp];
+                            for (uint32_t z = 0; z < a.ncb; z++) acc += a.Db[(uint64_t)(uint32_t)bval + z * a.sb];
+                            my_agg += (uint64_t)acc;
+                        } else {
+                            my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)ppay);
                         }
-                        pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                     }
-                } else {
-                    // every step of the wave: each lane advances to its next matching entry, the
-                    // matching lanes are ranked by a 64-bit ballot and write one coalesced run
-                    for (;;) {
-                        uint2 en = make_uint2(0, 0);
-                        while (pos != 0xFFFFu) {
-                            en = ent[pos];
-                            const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
-                            if (eq) break;
-                            pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
-                        }
-                        const bool m = pos != 0xFFFFu;
-                        const uint64_t mask = __ballot(m);
-                        if (!mask) break;
-                        if (m) {
-                            uint64_t o = cur + __popcll(mask & lt_mask);
-                            if (o < a.out_cap) {
-                                a.out_key[o] = (int32_t)key;
-                                a.out_bpay[o] = (int32_t)en.y;
-                                a.out_ppay[o] = ppay;
-                            }
-                            pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
-                        }
-                        cur += __popcll(mask);
-                    }
+                    pos = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[pos];
                 }
             }
         }
         __syncthreads();
     }
-    if (!MAT) {
-        my_matches = wave_sum64(my_matches);
-        my_agg = wave_sum64(my_agg);
-        if (lane_id() == 0) {
-            a.wave_counts[(uint64_t)item * JOIN_WAVES + wave] = my_matches;
-            a.wave_agg[(uint64_t)item * JOIN_WAVES + wave] = my_agg;
-        }
+    my_matches = wave_sum64(my_matches);
+    my_agg = wave_sum64(my_agg);
+    if (lane_id() == 0) {
+        a.wave_counts[(uint64_t)item * JOIN_WAVES + wave] = my_matches;
+        a.wave_agg[(uint64_t)item * JOIN_WAVES + wave] = my_agg;
     }
 }
 
@@ -1945,22 +1909,6 @@ hipError_t launch_scan_u32(hipStream_t st, uint32_t *data, const uint32_t *len_p
     return hipSuccess;
 }
 
-hipError_t launch_scan_u64(hipStream_t st, uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t max_len,
-                           uint64_t *chunk_sums, uint64_t *chunk_prefix, uint64_t *total_out) {
-    uint32_t nchunks = (uint32_t)((max_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    if (nchunks == 0) nchunks = 1;
-    if (nchunks == 1) { // the whole scan in one workgroup: chunk_prefix[0..1] and the total come from the same launch
-        hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(1), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, chunk_prefix, total_out);
-        HJ_LAUNCH_CHECK();
-        return hipSuccess;
-    }
-    hipLaunchKernelGGL(k_scan_local<uint64_t>, dim3(nchunks), dim3(SCAN_THREADS), 0, st, data, len_ptr, mul, chunk_sums, (uint64_t *)nullptr, (uint64_t *)nullptr);
-    HJ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk_sums, len_ptr, mul, chunk_prefix, total_out);
-    HJ_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
 hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64_t *coff) {
     uint64_t nthreads = (uint64_t)pa.nparents * pa.P + 1;
     hipLaunchKernelGGL(k_offsets, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, st, pa.hist, pa.chunk_prefix,
@@ -2031,9 +1979,8 @@ hipError_t join_set_lds_limit(int device, size_t bytes) {
     static size_t limit[64] = {};
     std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (device >= 0 && device < 64 && bytes <= limit[device]) return hipSuccess;
-    const void *fns[] = {reinterpret_cast<const void *>(&k_join<true, 0>), reinterpret_cast<const void *>(&k_join<true, 1>),
-                         reinterpret_cast<const void *>(&k_join<true, 2>), reinterpret_cast<const void *>(&k_join<false, 0>),
-                         reinterpret_cast<const void *>(&k_join<false, 1>), reinterpret_cast<const void *>(&k_join<false, 2>),
+    const void *fns[] = {reinterpret_cast<const void *>(&k_join<true, 0>), reinterpret_cast<const void *>(&k_join<true, 2>),
+                         reinterpret_cast<const void *>(&k_join<false, 0>), reinterpret_cast<const void *>(&k_join<false, 2>),
                          reinterpret_cast<const void *>(&k_join<true, 0, true>), reinterpret_cast<const void *>(&k_join<false, 0, true>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -2092,13 +2039,12 @@ hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bo
         HJ_LAUNCH_CHECK();
         return hipSuccess;
     }
+    if (jm != 0 && jm != 2) return hipErrorInvalidValue;
     if (tag16) {
         if (jm == 0) hipLaunchKernelGGL((k_join<true, 0>), g, b, lds, st, a);
-        else if (jm == 1) hipLaunchKernelGGL((k_join<true, 1>), g, b, lds, st, a);
         else hipLaunchKernelGGL((k_join<true, 2>), g, b, lds, st, a);
     } else {
         if (jm == 0) hipLaunchKernelGGL((k_join<false, 0>), g, b, lds, st, a);
-        else if (jm == 1) hipLaunchKernelGGL((k_join<false, 1>), g, b, lds, st, a);
         else hipLaunchKernelGGL((k_join<false, 2>), g, b, lds, st, a);
     }
     HJ_LAUNCH_CHECK();

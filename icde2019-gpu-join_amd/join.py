@@ -83,16 +83,16 @@ class HashJoin:
         self._ck(self._L.hj_set_stream(self._h, own if stream is None else C.c_void_p(int(stream))))
 
     def configure(self, bits1=0, bits2=0, force_bits=False, build_side=0, lds_capacity=0, lds_heads=0,
-                  probe_chunk=0, exact_only=False, materialize_two_pass=False, graph=False):
+                  probe_chunk=0, exact_only=False, graph=False):
         cfg = _lib.Config(bits1=bits1, bits2=bits2, force_bits=int(force_bits), build_side=build_side,
                           lds_capacity=lds_capacity, lds_heads=lds_heads, probe_chunk=probe_chunk,
-                          exact_only=int(exact_only), materialize_two_pass=int(materialize_two_pass), graph=int(graph))
+                          exact_only=int(exact_only), graph=int(graph))
         self._ck(self._L.hj_configure(self._h, C.byref(cfg)))
 
     def config(self):
         cfg = _lib.Config()
         self._ck(self._L.hj_get_config(self._h, C.byref(cfg)))
-        return {k: getattr(cfg, k) for k, _ in _lib.Config._fields_ if k != "reserved"}
+        return {k: getattr(cfg, k) for k, _ in _lib.Config._fields_ if not k.startswith("reserved")}
 
     def sync(self):
         self._ck(self._L.hj_sync(self._h))

@@ -56,12 +56,8 @@ typedef struct hj_config {
                             * bump-allocated buckets of jp.cu:138-192 without their atomics) and falls back to the exact
                             * passes when skew overflows a slot (the overflow flag travels with the join's result block; a
                             * flagged relation is re-partitioned and the join re-run inside the same call). */
-    uint32_t materialize_two_pass; /* 0: hj_join_materialize writes the output in ONE probe (matches held in registers — 10 probe tuples
-                            * per lane, one exact reservation on a global output cursor per round of a 5120-tuple sub-chunk — where
-                            * join_partitioned_results jp.cu:1228-1261 reserves per warp; LDS holds the table alone: 3 workgroups per CU).
-                            * 1: count, scan, second probe writing at the scanned positions — no output atomics, the order of the
-                            * output is a function of the partitions alone; also what the streaming materialising path uses per
-                            * segment, whose output columns are sized from the count. */
+    uint32_t reserved1;    /* was materialize_two_pass (round 2's count + scan + second probe; hj_join_materialize writes its output in
+                            * ONE probe since round 3, the streaming path since round 4: removed); must be 0 */
     uint32_t reserved0;    /* was lds_stage (round 3's LDS-staged one-probe kernel, measured 20 % slower, removed); must be 0 */
     uint32_t graph;        /* 1: hj_join replays the whole step (both partition passes, plan, build+probe, result copy) from a
                             * captured hipGraph — one host call per step instead of ~14-22 launches; pays below ~2^24 tuples,

@@ -54,13 +54,6 @@ def _check_join_1(P, R, Pr, S, Ps, cfg=None, materialize=True):
             # ... on fresh partitions with no count before it (the timed shape: partition both, materialise) ...
             hj.partition_both()
             check(*hj.join_materialize(cap=em), "one probe, no count")
-            # ... and the two-probe path (count, scan, second probe at scanned positions)
-            hj.configure(**dict(cfg or {}, materialize_two_pass=True))
-            assert hj.join() == (em, eagg)
-            check(*hj.join_materialize(), "two probes")
-            hj.partition(P.REL_R)
-            hj.partition(P.REL_S)
-            check(*hj.join_materialize(cap=em), "two probes, no count")
         # the step replayed from a captured hipGraph (hj_config.graph): eager call, capturing call, replays
         hj.configure(**dict(cfg or {}, graph=True))
         for _ in range(4):

@@ -169,10 +169,6 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
         hj.partition(P.REL_S)
         k, pr, ps = hj.join_materialize(cap=em)                       # one probe, no count before it
         assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
-        hj.configure(**dict(cfg or {}, materialize_two_pass=True))   # configure keeps what was learned about the binding
-        assert hj.join() == (em, eagg)
-        k, pr, ps = hj.join_materialize()
-        assert o.triples_checksum(k, pr, ps) == echk
         # small probe chunks: runs of whole ranges are closed when the next range would not fit, long ranges are cut
         hj.configure(**dict(cfg or {}, probe_chunk=3000))
         assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
@@ -248,11 +244,6 @@ def test_skewed_build_side_one_launch_passes_and_flipped_roles(P, cfg, nR, nS, b
         hj.partition_both()
         k, pr, ps = hj.join_materialize(cap=em)                       # one probe on fresh partitions, no count before it
         assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
-        # the two-probe path and the late-materialising kernel take plain items: the sampled build side is redone exact for them
-        hj.configure(**dict(cfg, materialize_two_pass=True))
-        assert hj.join() == (em, eagg)
-        k, pr, ps = hj.join_materialize()
-        assert o.triples_checksum(k, pr, ps) == echk
         hj.configure(**dict(cfg, probe_chunk=3000))
         assert hj.join() == (em, eagg)
         k, pr, ps = hj.join_materialize(cap=em)
