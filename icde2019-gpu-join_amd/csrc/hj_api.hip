@@ -850,7 +850,7 @@ void hj_invalidate_all(hj_ctx *c) {
 // ================================================================================================
 extern "C" {
 
-const char *hj_version(void) { return "hj-mi355x 0.1 (gfx950)"; }
+const char *hj_version(void) { return "hj-mi355x 0.4 (gfx950)"; }
 
 int hj_create(hj_ctx **out, int device) {
     if (!out) return HJ_EINVAL;
