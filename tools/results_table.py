@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the results tables of README.md / DESIGN.md / BASELINE.md from profiles/r3_bench_*.json (so that the documents quote
+"""Print the results tables of README.md / DESIGN.md / BASELINE.md from profiles/r4_bench_*.json (so that the documents quote
 the committed evidence, not a remembered number)."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
-    return [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r3_bench_%s.json" % name)) if l.startswith("{")]
+    return [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r4_bench_%s.json" % name)) if l.startswith("{")]
 
 
 def main():
@@ -21,13 +21,24 @@ def main():
         print("| %s | **%.1f** | %.3f | 2×`k_part1_fast` %.2f ms, 2×`k_part2_fast` %.2f ms, `k_join` %.2f ms; dominant `%s` %.3f ms = %.2f of 8 TB/s, %.2f of the same-run copy ceiling (%.0f GB/s); probe %.2f of 8 TB/s |"
               % (name, d["value"], d["ms_per_step"], k["k_part1_fast"]["ms_per_step"], k["k_part2_fast"]["ms_per_step"], k["k_join_count"]["ms_per_step"],
                  r["kernel"], r["avg_launch_ms"], r["frac"], r["frac_of_stream_copy"], r["stream_copy_ceiling"], p["frac_of_8TBs"]))
-        print("| same, materialising %d `(key,payR,payS)` tuples in ONE probe | %.1f | %.3f | `k_join_mat` %.2f ms = %.0f GB/s = %.2f of 8 TB/s; %d probe launch per step |"
-              % (m["output_tuples"], m["value"], m["ms_per_step"], m["k_join_materialize_ms"], m["k_join_materialize_GBs"], m["k_join_materialize_frac_of_8TBs"], m["probes_per_step"]))
+        print("| same, materialising %d `(key,payR,payS)` tuples in ONE probe | %.1f | %.3f | `k_join_mat_reg` %.2f ms = %.0f GB/s = %.2f of 8 TB/s, %.2f of the read/write-mix ceiling (%.0f GB/s at %.0f %% writes) |"
+              % (m["output_tuples"], m["value"], m["ms_per_step"], m["k_join_materialize_ms"], m["k_join_materialize_GBs"], m["k_join_materialize_frac_of_8TBs"],
+                 m["frac_of_mix_ceiling"], m["mix_ceiling_GBs"], 100 * m["write_share_of_bytes"]))
+        if d.get("config2_as_stated"):
+            s = d["config2_as_stated"]
+            print("| same size, configs[1] AS STATED: one 9-bit pass | %.1f | %.3f | 2^18-tuple partitions, the LDS table rebuilt ~60 times per partition: why the default is two passes |" % (s["value"], s["ms_per_step"]))
     print("| 2^30, exact (histogram) passes only | %.1f | %.3f | |" % (bx["value"], bx["ms_per_step"]))
     k = bz["kernels"]
-    print("| PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0 (configs[3]) | **%.1f** | %.3f | S: `k_part1_var` %.2f + `k_part2_var` %.2f ms (sampled capacities, no histogram), join %.2f ms; first call on a fresh binding %.0f ms; exact passes for everything: %.1f Gtuples/s |"
-          % (bz["value"], bz["ms_per_step"], k["k_part1_var"]["ms_per_step"], k["k_part2_var"]["ms_per_step"], k["k_join_count"]["ms_per_step"], bz["first_call_ms"], bzx["value"]))
-    print("| S (2^30) streamed from pinned host memory against R (2^27) | %.1f | %.1f | %.1f GB/s H2D, transfer-bound |" % (st["value"], st["ms_per_step"], st["h2d_GBs"]))
+    print("| PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0 (configs[3]) | **%.1f** | %.3f | S: `k_part1_var` %.2f + `k_part2_var` %.2f ms (sampled capacities, no histogram), join %.2f ms (probe %.2f of 8 TB/s); dominant `%s` = %.2f of 8 TB/s; first call on a fresh binding %.0f ms (%s); exact passes for everything: %.1f Gtuples/s |"
+          % (bz["value"], bz["ms_per_step"], k["k_part1_var"]["ms_per_step"], k["k_part2_var"]["ms_per_step"], k["k_join_count"]["ms_per_step"], bz["probe_phase"]["frac_of_8TBs"],
+             bz["roofline"]["kernel"], bz["roofline"]["frac"], bz["first_call_ms"], bz["first_call_split_ms"], bzx["value"]))
+    m = bz["materialize"]
+    print("| same, materialising %d tuples in ONE probe | **%.1f** | %.3f | `k_join_mat_reg` (list items) %.2f ms = %.0f GB/s = %.2f of 8 TB/s, %.2f of the mix ceiling (%.0f GB/s at %.0f %% writes); digest-checked |"
+          % (m["output_tuples"], m["value"], m["ms_per_step"], m["k_join_materialize_ms"], m["k_join_materialize_GBs"], m["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], m["mix_ceiling_GBs"], 100 * m["write_share_of_bytes"]))
+    for nm, lab in (("zipf_24_27_pk_builds", "PK–FK 2^24 ⋈ 2^27 Zipf, the PK side builds"), ("zipf_24_27_zipf_builds", "same, the ZIPF side designated to build (general items)")):
+        z = load(nm)[0]
+        print("| %s | %.1f | %.3f | layouts %s; materialising %.3f ms |" % (lab, z["value"], z["ms_per_step"], z["config"]["partition_layout_R_S"], z["materialize"]["ms_per_step"]))
+    print("| S (2^30) streamed from pinned host memory against R (2^27) | %.1f | %.1f | %.1f GB/s H2D, transfer-bound; materialising 2^28 tuples back to the host: %.1f ms, %.1f GB/s D2H |" % (st["value"], st["ms_per_step"], st["h2d_GBs"], st["materialize"]["ms"], st["materialize"]["d2h_GBs"]))
     print("| R, S (2^27 each) in host memory, CPU–GPU co-processing | %.2f | %.0f | host split %.0f GB/s; NUMA %s |" % (co["value"], co["ms_per_step"], co["host_split_GBs"], co.get("numa")))
     for d in load("baselines"):
         r = d["results"]
