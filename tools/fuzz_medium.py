@@ -1,5 +1,7 @@
 """Medium-size randomized differential run (GPU box): 2^18..2^23-tuple relations, default configuration (histogram-free
-passes with fallback) and exact_only, several key distributions, count + aggregate + partition digests against the oracle."""
+passes with fallback) and exact_only, several key distributions, the build side left to the library / forced to R / forced to S
+(round 4: a skewed or larger designated build side runs on general work items), count + aggregate + partition digests against
+the oracle."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +15,7 @@ for seed in range(n_cases):
     rng = np.random.default_rng(7000 + seed)
     nR = int(rng.integers(1 << 18, 1 << 22)); nS = int(rng.integers(1 << 18, 1 << 23))
     kind = seed % 6
+    bside = (seed // 6) % 3   # 0 = the smaller relation builds, 1 = R, 2 = S
     if kind == 0:
         R = rng.permutation(nR); S = rng.integers(0, nR + 100, nS)
     elif kind == 1:   # zipf-ish probe side
@@ -32,7 +35,7 @@ for seed in range(n_cases):
     lays = []
     for exact in (False, True):
         with P.HashJoin(0) as hj:
-            hj.configure(exact_only=exact)
+            hj.configure(exact_only=exact, build_side=bside)
             hj.load_host(P.REL_R, R, Pr); hj.load_host(P.REL_S, S, Ps)
             got = hj.join()
             c = hj.config(); bits = c["bits1"] + c["bits2"]
@@ -50,11 +53,11 @@ for seed in range(n_cases):
                 hj.partition(P.REL_R); hj.partition(P.REL_S)
                 k, pr, ps = hj.join_materialize(cap=em)
                 okc = okc and len(k) == em and o.triples_checksum(k, pr, ps) == echk
-            hj.configure(exact_only=exact, graph=True)
+            hj.configure(exact_only=exact, build_side=bside, graph=True)
             for _ in range(3):
                 okc = okc and hj.join() == (em, eagg)
         if not okc:
             bad += 1; print("FAIL seed", seed, "kind", kind, "exact", exact, got, (em, eagg), lay, flush=True)
-    print("seed %d kind %d nR %d nS %d matches %d layouts (first join -> second join) default %s -> %s, exact_only %s -> %s"
-          % (seed, kind, len(R), len(S), em, lays[0][0], lays[0][1], lays[1][0], lays[1][1]), flush=True)
+    print("seed %d kind %d build_side %d nR %d nS %d matches %d layouts (first join -> second join) default %s -> %s, exact_only %s -> %s"
+          % (seed, kind, bside, len(R), len(S), em, lays[0][0], lays[0][1], lays[1][0], lays[1][1]), flush=True)
 print("medium fuzz: %d cases, %d failures, %.0f s" % (n_cases, bad, time.time() - t0))
