@@ -677,8 +677,8 @@ int exact_for_introspection(hj_ctx *c, Rel &R) {
 }
 
 // work-item list of the current partitions: k_join_plan + scan + k_join_expand (decompose_chains, jp.cu:843-874)
-// gen_ok: the kernel that follows takes general items (the count kernel and the one-probe materialiser do; the second probe of the
-// two-probe path and the late-materialising kernel do not: a sampled build side is redone with the exact passes for them)
+// gen_ok: the kernel that follows takes general items (the count kernel and the one-probe materialiser do; the late-materialising
+// kernel does not: a sampled build side is redone with the exact passes for it)
 int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok = true) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];

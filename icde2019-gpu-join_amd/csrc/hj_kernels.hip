@@ -21,11 +21,11 @@
 //     (key,payload) pairs to per-digit 128-byte LDS write-combining lines and flushes only whole, 128-byte-aligned
 //     lines with 16-byte stores, at any fan-out from 2 to 512 (the multi-GPU shard split uses the same kernel).
 //     Nothing is read back to the host between kernels; grids are launched at their upper bound.
-//   * the join kernel builds a chained hash table in LDS per build partition (16-bit tags when the
-//     radix bits leave <= 16 key bits, full keys otherwise) and probes it with coalesced 16-byte
-//     loads; work items split the probe side (<= probe_chunk tuples); counts are kept per wave so
-//     that the materialising kernel writes (key,payR,payS) at exact, contention-free positions
-//     (no global output cursor, no FOLD ring: jp.cu:1097-1101 D6).
+//   * the join kernels build a chained hash table in LDS per partition (16-bit tags at >= 16 radix bits, full keys
+//     otherwise) and probe it with coalesced 16-byte loads; work items split the streamed side (<= probe_chunk tuples);
+//     k_join counts per wave; k_join_mat_reg materialises (key,payR,payS) in the same probe, one exact reservation on
+//     an output cursor per round, every tuple kept (no FOLD ring: jp.cu:1097-1101 D6); general items (GEN): tables
+//     built from range lists, the smaller partition builds (role flip, jp.cu:929-1003).
 //   All arithmetic is integer; there is no MFMA-shaped work on this path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -47,7 +47,7 @@ typedef struct hj_config {
     uint32_t bits1;        /* radix bits of pass 1 (key bits [bits2, bits2+bits1)); 0 = auto */
     uint32_t bits2;        /* radix bits of pass 2 (key bits [0, bits2)); 0 with bits1!=0 = single pass */
     uint32_t force_bits;   /* 1: take bits1/bits2 literally (bits1=bits2=0 → no partitioning) */
-    uint32_t build_side;   /* 0 auto (smaller relation, ties → R), 1 = R, 2 = S */
+    uint32_t build_side;   /* 0 auto (smaller relation, ties → R), 1 = R, 2 = S — a hint: bits follow the smaller relation, and a skewed or larger build relation lets the smaller PARTITION build (jp.cu:929-1003) */
     uint32_t lds_capacity; /* build tuples per LDS hash table; 0 = default */
     uint32_t lds_heads;    /* hash-table heads (power of two); 0 = default */
     uint32_t probe_chunk;  /* probe tuples per work item (decompose_chains threshold, hjcp.cu:904); 0 = default */
