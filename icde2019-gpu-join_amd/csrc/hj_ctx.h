@@ -111,7 +111,8 @@ struct hj_ctx {
     hipEvent_t seg_ready[2] = {};
     hipEvent_t seg_joined[2] = {};  // streaming probe, count-only: the join of the segment in staging buffer b is done
     Buf seg_res;                    // ... per segment {matches, aggregate, S's overflow flag, -}
-    hipStream_t aux = nullptr;      // small inputs: S's partition passes run beside R's
+    hipStream_t aux = nullptr;      // S's partition passes run beside R's
+    hipStream_t aux_hi = nullptr;   // ... relations of very different sizes: the larger one's passes, at high priority (partition_both)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // hj_config.graph: the captured step and what it is tied to
     hipGraphExec_t graph_exec = nullptr;
