@@ -1088,18 +1088,37 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t *__restrict__ k, 
 // j < nr[p].  Whole ranges are packed into LIST items of <= chunk probe tuples (the table of the partition is built once for all
 // of them); a range longer than a chunk is cut into chunk items as above.  emit(index, list, q0, q1): list items carry
 // (first range, number of ranges) in (q0, q1).
-template <class F>
+// A range longer than a chunk goes to emit_big(index of its first item, b, e, number of chunk items) as a whole: the heavy hitter of
+// config 4 is one partition of ~1700 chunk items, which ONE thread used to write one after the other (k_join_expand 100 us).
+template <class F, class G>
 __device__ inline uint32_t walk_ranges(const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend, uint32_t r0, uint32_t nr,
-                                       uint32_t stride, uint32_t chunk, F emit) {
+                                       uint32_t stride, uint32_t chunk, F emit, G emit_big) {
     uint32_t items = 0, run0 = 0, runlen = 0;
     uint64_t acc = 0;
+    // the ranges are fetched eight at a time, ahead of the data-dependent packing below: one thread walks its partition's list alone
+    // and a dependent global load per range (~2 us each) made the two planning kernels of config 4 80-105 us long (the 64 partitions
+    // of the pass-1 digit that holds the heavy hitter have ~28 ranges each)
+    constexpr uint32_t WR_BATCH = 8;
+    uint64_t bb[WR_BATCH], ee[WR_BATCH];
     for (uint32_t j = 0; j < nr; j++) {
+        if ((j & (WR_BATCH - 1)) == 0) {
+#pragma unroll
+            for (uint32_t t = 0; t < WR_BATCH; t++) {
+                const uint32_t rt = r0 + (j + t < nr ? j + t : nr - 1) * stride;
+                bb[t] = pbeg[rt]; ee[t] = pend[rt];
+            }
+        }
         const uint32_t r = r0 + j * stride;
-        const uint64_t b = pbeg[r], e = pend[r], len = e - b;
+        uint64_t b = bb[0], e = ee[0];
+#pragma unroll
+        for (uint32_t t = 1; t < WR_BATCH; t++) if ((j & (WR_BATCH - 1)) == t) { b = bb[t]; e = ee[t]; }
+        const uint64_t len = e - b;
         if (len > chunk) {
             if (runlen && acc) { emit(items, true, (uint64_t)run0, (uint64_t)runlen); items++; }
             runlen = 0; acc = 0;
-            for (uint64_t q = b; q < e; q += chunk) { emit(items, false, q, q + chunk < e ? q + chunk : e); items++; }
+            const uint32_t nck = (uint32_t)((len + chunk - 1) / chunk);
+            emit_big(items, b, e, nck);
+            items += nck;
         } else {
             if (acc + len > chunk) { emit(items, true, (uint64_t)run0, (uint64_t)runlen); items++; runlen = 0; acc = 0; }
             if (!runlen) run0 = r;
@@ -1123,7 +1142,7 @@ __global__ void k_join_plan(const uint64_t *__restrict__ bbeg, const uint64_t *_
     if (i >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) { items_cnt[i] = 0; return; }
     if (pr0) {
-        items_cnt[i] = bend[i] != bbeg[i] ? walk_ranges(pbeg, pend, pr0[i], pnr[i], rstride, chunk, [](uint32_t, bool, uint64_t, uint64_t) {}) : 0u;
+        items_cnt[i] = bend[i] != bbeg[i] ? walk_ranges(pbeg, pend, pr0[i], pnr[i], rstride, chunk, [](uint32_t, bool, uint64_t, uint64_t) {}, [](uint32_t, uint64_t, uint64_t, uint32_t) {}) : 0u;
         return;
     }
     const uint32_t p = rpart ? rpart[i] : i;
@@ -1139,20 +1158,43 @@ __global__ void k_join_expand(const uint64_t *__restrict__ bbeg, const uint64_t 
                               const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag, const uint32_t *__restrict__ rpart,
                               const uint32_t *__restrict__ pr0, const uint32_t *__restrict__ pnr, uint32_t rstride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparts) return;
     if ((bflag && *bflag) || (pflag && *pflag)) return; // ranges not valid (k_join_plan counted no items)
-    uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
-    if (pr0) {
-        const uint64_t b0 = bbeg[i], nb = bend[i] - b0;
-        if (!nb) return;
-        walk_ranges(pbeg, pend, pr0[i], pnr[i], rstride, chunk, [&](uint32_t idx, bool list, uint64_t q0, uint64_t q1) {
+    if (pr0) { // (no lane leaves before the wave-wide part below)
+        const bool act = i < nparts;
+        const uint64_t at = act ? (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG] : 0;
+        const uint64_t b0 = act ? bbeg[i] : 0, nb = act ? bend[i] - b0 : 0;
+        const uint32_t r0 = act ? pr0[i] : 0u, nr = (act && nb) ? pnr[i] : 0u;
+        bool has_big = false;
+        // the thread's own walk writes the list items; ranges longer than a chunk are only noted ...
+        walk_ranges(pbeg, pend, r0, nr, rstride, chunk, [&](uint32_t idx, bool list, uint64_t q0, uint64_t q1) {
             JoinItem it;
             it.b0 = b0; it.nb = (uint32_t)nb; it.p = i | (list ? JOIN_ITEM_LIST : 0u);
             it.q0 = q0; it.q1 = q1;
             items[at + idx] = it;
-        });
+        }, [&](uint32_t, uint64_t, uint64_t, uint32_t) { has_big = true; });
+        // ... and written by the whole wave: every lane repeats the walk of a partition that has some (uniform values: scalar loads),
+        // the chunk items of a long range are dealt to the 64 lanes
+        const uint32_t ln = lane_id();
+        for (uint64_t pending = __ballot(has_big); pending; pending &= pending - 1) {
+            const int L = __ffsll((unsigned long long)pending) - 1;
+            const uint64_t atL = uniform64(__shfl(at, L)), b0L = uniform64(__shfl(b0, L));
+            const uint32_t nbL = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((uint32_t)nb, L));
+            const uint32_t iL = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(i, L));
+            const uint32_t r0L = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(r0, L)), nrL = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nr, L));
+            walk_ranges(pbeg, pend, r0L, nrL, rstride, chunk, [](uint32_t, bool, uint64_t, uint64_t) {},
+                        [&](uint32_t idx0, uint64_t b, uint64_t e, uint32_t nck) {
+                for (uint32_t ck = ln; ck < nck; ck += 64) {
+                    JoinItem it;
+                    it.b0 = b0L; it.nb = nbL; it.p = iL;
+                    it.q0 = b + (uint64_t)ck * chunk; it.q1 = it.q0 + chunk < e ? it.q0 + chunk : e;
+                    items[atL + idx0 + ck] = it;
+                }
+            });
+        }
         return;
     }
+    if (i >= nparts) return;
+    uint64_t at = (uint64_t)items_scanned[i] + chunk_prefix[i >> SCAN_CHUNK_LOG];
     const uint32_t p = rpart ? rpart[i] : i;
     uint64_t nb = bend[p] - bbeg[p], np = pend[i] - pbeg[i];
     uint32_t c = (nb && np) ? (uint32_t)((np + chunk - 1) / chunk) : 0u;
@@ -1200,6 +1242,12 @@ __device__ inline uint32_t general_items(const JoinArgs &a, uint32_t i, F emit) 
             JoinItem it = base;
             it.q0 = q0; it.q1 = q1; if (list) it.p |= JOIN_ITEM_LIST;
             emit(idx, it);
+        }, [&](uint32_t idx0, uint64_t b, uint64_t e, uint32_t nck) {
+            for (uint32_t ck = 0; ck < nck; ck++) {
+                JoinItem it = base;
+                it.q0 = b + (uint64_t)ck * a.chunk; it.q1 = it.q0 + a.chunk < e ? it.q0 + a.chunk : e;
+                emit(idx0 + ck, it);
+            }
         });
     uint32_t n = 0;
     for (uint64_t q = S.beg[i]; q < S.end[i]; q += a.chunk, n++) {
