@@ -174,6 +174,11 @@ def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
         assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
         k, pr, ps = hj.join_materialize(cap=em)
         assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        # tiny chunks: most partitions of a wave have ranges longer than a chunk (k_join_expand writes their chunk items wave-wide)
+        hj.configure(**dict(cfg or {}, probe_chunk=257))
+        assert hj.join() == (em, eagg) and hj.partition_layout(P.REL_S) == "sampled"
+        k, pr, ps = hj.join_materialize(cap=em)
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
         hj.configure(**(cfg or {}))
         assert hj.join() == (em, eagg)
         # introspection: gap-free partitions identical to the oracle's (the relation is redone with the exact passes for it)
