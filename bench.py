@@ -414,7 +414,7 @@ def _fmix64(x):
 
 
 def mix_triple(key, pr, ps):
-    """hj_digest_triples' per-tuple mix (csrc/hj_kernels.hip: mix_triple), for digest arithmetic on the host."""
+    """hj_digest_triples' per-tuple mix (csrc/hj_device.h: mix_triple), for digest arithmetic on the host."""
     m = (1 << 64) - 1
     pair = _fmix64((((key & 0xFFFFFFFF) << 32) | (pr & 0xFFFFFFFF)) & m)
     return _fmix64(pair ^ (((ps & 0xFFFFFFFF) * 0x9E3779B97F4A7C15) & m))

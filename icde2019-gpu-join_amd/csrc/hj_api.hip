@@ -264,7 +264,7 @@ void invalidate(hj_ctx *c, int rel) {
     c->join_planned = false;
 }
 
-// Geometry of the histogram-free passes for a relation of n tuples (see hj_kernels.hip): spans of pass 1, slot
+// Geometry of the histogram-free passes for a relation of n tuples (see hj_part.hip): spans of pass 1, slot
 // capacities of both passes.  false when the slotted layout would not fit 32-bit positions.
 bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &f) {
     if (n == 0) return false;

@@ -1,4 +1,4 @@
-// hj_internal.h — shared between the kernels (hj_kernels.hip) and the host side (hj_api.hip).
+// hj_internal.h — shared between the kernel files (hj_part.hip, hj_join.hip, hj_util.hip; device helpers: hj_device.h) and the host side (hj_api.hip).
 #ifndef HJ_INTERNAL_H_
 #define HJ_INTERNAL_H_
 
@@ -47,7 +47,7 @@ struct PassArgs {
 
 // The histogram-free ("optimistic") passes.  Output slots have a fixed capacity: pass 1 gives every
 // (digit, span) pair a slot of cap tuples, pass 2 every final partition; a slot that would overflow raises
-// *ovf and the exact passes redo the relation.  See hj_kernels.hip.
+// *ovf and the exact passes redo the relation.  See hj_part.hip.
 struct FastArgs {
     const int32_t *keys, *pays;  // input columns
     uint64_t n;                  // pass 1: tuples of the (contiguous) input
@@ -114,7 +114,7 @@ hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
-// the sampled path of skewed relations (hj_kernels.hip: k_part1_var, k_part2_var)
+// the sampled path of skewed relations (hj_part.hip: k_part1_var, k_part2_var)
 struct VarArgs {
     const uint32_t *vbase, *vcap; // pass 1: per digit [P]; pass 2: per (parent, child) [nparents*P]
     const uint32_t *lt, *own;     // lines dealt: (lines << 16 | first line) per digit [P] (pass 2: per parent row), owner digit per LDS line [512]
