@@ -568,8 +568,11 @@ int partition_rel(hj_ctx *c, int r) {
     R.part_off = nullptr;
     R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
     // known to be skewed: the sampled path — on either side of the join since round 4 (a build partition that is a list of ranges
-    // is built into the LDS table piece by piece: general items, plan_join)
-    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 15 && c->fast_path && !c->cfg.exact_only &&
+    // is built into the LDS table piece by piece: general items, plan_join).  Up to 17 radix bits: at 16 (2^28 x 2^31 Zipf) it takes
+    // 18.9 ms where the exact passes take 24.6, at 17 bits 23.6 against 26.9; at 18 bits both passes are 512-way, a heavy digit has
+    // ONE LDS line and most of its tuples bypass it: no faster than the exact passes, the materialising join slower (profiles/
+    // r4_sampled_16_17_bits.txt)
+    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 17 && c->fast_path && !c->cfg.exact_only &&
         R.n >= ((uint64_t)1 << 20)) {
         bool done = false;
         RET(partition_sampled(c, r, b1, b2, flag, &done));

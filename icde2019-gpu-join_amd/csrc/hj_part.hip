@@ -642,35 +642,45 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
 // reference partitions any distribution in one launch per pass (bump-allocated buckets, jp.cu:138-192); here a skewed
 // relation keeps the one-launch passes of the uniform case, with slots sized to what the sample says each digit receives.
 // A slot that still overflows raises the flag: the exact passes are the fallback. ----
-__global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict__ keys, uint64_t n, uint32_t mask, uint32_t stride,
+// More than 15 radix bits: 2^bits counters no longer fit a workgroup's LDS (128 KiB = 2^15), so the id space is cut into 2^(bits-15)
+// SLICES and a workgroup counts the ids of ONE slice only; workgroups of the same slice share the sample between them, every slice
+// reads the whole sample (keys only, 1/stride of the relation: 2-8 x ~1 GiB for 2^31 tuples at 16-18 bits, once per binding).
+constexpr uint32_t SAMPLE_LDS_BITS = 15;
+__global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict__ keys, uint64_t n, uint32_t mask, uint32_t stride, uint32_t slice_bits,
                                                        uint32_t *__restrict__ hist, unsigned long long *__restrict__ sampled) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    for (uint32_t i = threadIdx.x; i <= mask; i += 1024) h[i] = 0;
+    const uint32_t slice = blockIdx.x & ((1u << slice_bits) - 1), wg = blockIdx.x >> slice_bits, nwg = gridDim.x >> slice_bits;
+    const uint32_t lmask = slice_bits ? (1u << SAMPLE_LDS_BITS) - 1 : mask; // the bins of one workgroup
+    for (uint32_t i = threadIdx.x; i <= lmask; i += 1024) h[i] = 0;
     __syncthreads();
     // blocks of 4096 tuples, every stride-th one; the heavy key would serialise a wave's LDS atomics: aggregated rank
     uint64_t cnt = 0;
-    for (uint64_t b = (uint64_t)blockIdx.x * stride; b * 4096 < n; b += (uint64_t)gridDim.x * stride) {
+    for (uint64_t b = (uint64_t)wg * stride; b * 4096 < n; b += (uint64_t)nwg * stride) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint64_t i = b * 4096 + (uint64_t)u * 1024 + threadIdx.x;
             const bool valid = i < n;
-            (void)rank_in_digit(h, valid ? ((uint32_t)keys[i] & mask) : 0u, valid);
+            const uint32_t id = valid ? ((uint32_t)keys[i] & mask) : 0u;
+            const bool mine = valid && (id >> SAMPLE_LDS_BITS) == (slice_bits ? slice : id >> SAMPLE_LDS_BITS);
+            (void)rank_in_digit(h, mine ? (id & lmask) : 0u, mine);
             cnt += valid;
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i <= mask; i += 1024)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
+    for (uint32_t i = threadIdx.x; i <= lmask; i += 1024)
+        if (h[i]) atomicAdd(&hist[slice_bits ? ((slice << SAMPLE_LDS_BITS) | i) : i], h[i]);
     cnt = wave_sum64(cnt);
-    if (lane_id() == 0 && cnt) atomicAdd(sampled, (unsigned long long)cnt);
+    if (slice == 0 && lane_id() == 0 && cnt) atomicAdd(sampled, (unsigned long long)cnt); // (every slice sees the whole sample: counted once)
 }
 
 hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled) {
     static bool set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const size_t lds = ((size_t)1 << bits) * 4;
+    if (bits > SAMPLE_LDS_BITS + 3) return hipErrorInvalidValue;
+    const uint32_t slice_bits = bits > SAMPLE_LDS_BITS ? bits - SAMPLE_LDS_BITS : 0u;
+    const size_t lds = ((size_t)1 << (slice_bits ? SAMPLE_LDS_BITS : bits)) * 4;
     {
         std::lock_guard<std::mutex> lock(g_attr_mutex);
         if (dev < 0 || dev >= 64 || !set[dev]) {
@@ -679,7 +689,7 @@ hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, 
             if (dev >= 0 && dev < 64) set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_sample_joint, dim3(256), dim3(1024), lds, st, keys, n, (1u << bits) - 1, stride, hist, reinterpret_cast<unsigned long long *>(sampled));
+    hipLaunchKernelGGL(k_sample_joint, dim3(256), dim3(1024), lds, st, keys, n, (1u << bits) - 1, stride, slice_bits, hist, reinterpret_cast<unsigned long long *>(sampled));
     return hipGetLastError();
 }
 

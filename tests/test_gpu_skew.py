@@ -135,7 +135,10 @@ def test_skewed_exact_passes_deal_lines_by_need(P, cfg):
 
 
 @pytest.mark.parametrize("cfg,nR,nS", [(dict(bits1=5, bits2=4), 1 << 16, 1 << 20), (dict(bits1=8, bits2=7), 1 << 18, 3 << 20),
-                                       (None, 1 << 22, 1 << 23)])
+                                       (None, 1 << 22, 1 << 23),
+                                       # 16 / 17 radix bits: the sample histogram no longer fits one workgroup's LDS (sliced sampling pass)
+                                       (dict(bits1=9, bits2=7), 1 << 20, 1 << 24), (dict(bits1=9, bits2=8), 1 << 20, 3 << 22),
+                                       (dict(bits1=8, bits2=8), 1 << 21, 1 << 24)])
 def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
     """A skewed relation on the probe side: the first join finds its slots overflowing, samples the key distribution once and
     from then on partitions it with the histogram-free passes at per-digit capacities (layout 'sampled': a partition is a list
@@ -209,7 +212,7 @@ def test_skewed_build_side_one_launch_passes_and_flipped_roles(P, cfg, nR, nS, b
     smaller is joined with the roles flipped (the reference's jp.cu:929-1003): the heavy hitter becomes many items instead of
     one workgroup looping over hundreds of table chunks.  Count, aggregate and the materialised (key, payR, payS) multiset —
     payloads in the right columns whichever side built — against the oracle; `both`: R is skewed too (lists on both sides);
-    8+8 bits: no sampled path at 16 radix bits (exact layout), flipped roles alone."""
+    8+8 bits: 16 radix bits, where the sampling pass counts the partition ids in two slices (one workgroup's LDS holds 2^15 counters)."""
     import torch
     rng = np.random.default_rng(94)
     R = rng.permutation(nR).astype(np.int32)
@@ -228,7 +231,7 @@ def test_skewed_build_side_one_launch_passes_and_flipped_roles(P, cfg, nR, nS, b
         hj.bind_device(P.REL_S, dS, dPs)
         c0 = hj.config()
         assert c0["build_side"] == 2
-        sampled_ok = c0["bits2"] > 0 and c0["bits1"] + c0["bits2"] <= 15     # default bits follow the SMALLER relation (2^22: 9+1)
+        sampled_ok = c0["bits2"] > 0 and c0["bits1"] + c0["bits2"] <= 17     # default bits follow the SMALLER relation (2^22: 9+1)
         for i in range(3):     # overflow -> sample -> sampled passes + general items; then twice from the remembered tables
             assert hj.join() == (em, eagg), i
             assert hj.partition_layout(P.REL_S) == ("sampled" if sampled_ok else "exact"), i
