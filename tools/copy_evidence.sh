@@ -4,8 +4,13 @@
 # are in place and tools/gpu_bench_lines.sh has run) lines.
 set -e
 S=gpurun_out/r4prof; D=profiles
+LIB=$(sha256sum icde2019-gpu-join_amd/libhj.so | cut -d" " -f1)
+same_binary() { # the results must come from the library that is in the tree now
+  grep -q "$LIB" "$1" || { echo "copy_evidence: $1 is not from the current libhj.so ($LIB): rerun the GPU script first"; exit 2; }
+}
 case "$1" in
 profiles)
+  same_binary $S/libhj.sha256
   for f in 2p30_exact zipf_exact zipf_24_27_pk_builds zipf_24_27_zipf_builds stream coprocess baselines forcedist forcedist_torch phantom2 phantom4 phantom8 phantom8_single_group; do cp $S/bench_$f.json $D/r4_bench_$f.json; done
   for f in 2p30 2p27 zipf; do cp $S/bench_$f.json $D/r4_bench_${f}_evidence_call.json; done
   cp $S/stats30.kernel_stats.csv $D/r4_kernel_stats_2p30.csv; cp $S/stats27.kernel_stats.csv $D/r4_kernel_stats_2p27.csv; cp $S/statszipf.kernel_stats.csv $D/r4_kernel_stats_zipf.csv
@@ -13,8 +18,10 @@ profiles)
   cp $S/pmczipf/pmc.json $D/r4_pmc_zipf.json; cp $S/pmczipf_mat/pmc.json $D/r4_pmc_zipf_materialize.json
   cp $S/step_vs_size.txt $D/r4_step_vs_size.txt; cp $S/libhj.sha256 $D/r4_libhj.sha256 ;;
 final)
+  same_binary gpurun_out/final/libhj.sha256
   cp gpurun_out/final/gpu_tests.txt $D/r4_gpu_tests.txt; cp gpurun_out/final/fuzz.txt $D/r4_fuzz.txt ;;
 lines)
+  same_binary gpurun_out/r4lines/bench_2p30.json
   for f in 2p30 2p27 zipf; do cp gpurun_out/r4lines/bench_$f.json $D/r4_bench_$f.json; done ;;
 *) echo "usage: copy_evidence.sh profiles|final|lines"; exit 1 ;;
 esac

@@ -11,4 +11,4 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
   timeout 900 python tools/fuzz_medium.py 36 2>&1
   timeout 600 python tools/fuzz_more.py 40 400 2>&1 | tail -1; } > $OUT/fuzz.txt
 tail -2 $OUT/fuzz.txt
-sha256sum icde2019-gpu-join_amd/libhj.so
+sha256sum icde2019-gpu-join_amd/libhj.so | tee $OUT/libhj.sha256
