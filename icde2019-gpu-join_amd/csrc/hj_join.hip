@@ -459,7 +459,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
 // wave, the eight wave totals meet in LDS -> ONE exact reservation on the output cursor for the whole workgroup -> every wave
 // writes its matches as runs of coalesced 4-byte-per-lane stores (key and probe payload from registers, build payload from the
 // table entry, whose link is also where the next round starts).  Unique build keys: one productive round per sub-chunk and one
-// that finds nothing; duplicates take as many rounds as the longest run of equal keys.  LDS = the table alone: 3 workgroups per CU.
+// that finds nothing — not run where the table was checked for repeated keys behind its build (tables that serve many sub-chunks);
+// duplicates take as many rounds as the longest run of equal keys.  LDS = the table alone: 3 workgroups per CU.
 // tuples per lane per sub-chunk: two 16-byte groups + one 8-byte group = 10 -> 5120 probe tuples per sub-chunk: a ~4096-tuple
 // partition plus 8 sigma (4608) in ONE sub-chunk (one reservation), at 30 state registers instead of the 36 that three 16-byte
 // groups need (which spill at 80 VGPRs = three workgroups per CU)
@@ -539,6 +540,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
             }
             if (!built) {
                 for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
+                if (tid == 0) red[18] = 0; // "some key occurs twice in this table" (set by the check behind the build)
                 __syncthreads();
                 uint32_t filled = 0;
                 for (;;) { // the pieces of this table chunk (one piece unless the table side is a list)
@@ -576,6 +578,24 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                 }
                 __syncthreads();
                 built = true;
+                // Unique keys in the table = at most one match per streamed tuple = the round that would find nothing (a chain walk, a
+                // reduction and a barrier per sub-chunk) need not run.  Whether they are unique costs about one such round to find
+                // out (every entry looks down the rest of its chain for its own key), so it is asked only where the table serves
+                // many sub-chunks: list items, general items, chunks of a long streamed side (config 4: 13 sub-chunks per table).
+                if (LISTS || GEN || it.q1 - it.q0 > 2 * (uint64_t)MR_SUB) {
+                    const uint32_t nfill = GEN ? filled : nbc0;
+                    bool dup = false;
+                    for (uint32_t sl = tid; sl < nfill; sl += JOIN_THREADS) {
+                        const uint2 me = ent[sl];
+                        uint32_t s_ = TAG16 ? (me.x & 0xFFFFu) : (uint32_t)lnext[sl];
+                        while (s_ != END) {
+                            const uint2 en = ent[s_];
+                            if (TAG16 ? ((en.x >> 16) == (me.x >> 16)) : (en.x == me.x)) { dup = true; break; }
+                            s_ = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[s_];
+                        }
+                    }
+                    if (dup) red[18] = 1; // (read behind the first barrier of the rounds)
+                } else if (tid == 0) red[18] = 1; // not asked: as if
 #pragma unroll
                 for (int t = 1; t < MR_IT; t++) fetch(t);
             }
@@ -627,6 +647,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
 #pragma unroll
                 for (uint32_t w = 0; w < (uint32_t)JOIN_WAVES; w++) { const uint32_t v = red[par * JOIN_WAVES + w]; wbase += w < wave ? v : 0u; T += v; }
                 if (!T) break; // workgroup-uniform: nobody found anything this round
+                const bool unique_table = red[18] == 0;
                 if (tid == 0) {
                     const unsigned long long base = atomicAdd(a.out_cursor, (unsigned long long)T); // ONE reservation per round
                     red[16] = (uint32_t)base; red[17] = (uint32_t)(base >> 32);
@@ -655,6 +676,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                     }
                 mm = 0;
                 // red[16..17] are rewritten only behind the next round's first barrier; the totals alternate by parity
+                if (unique_table) break; // nothing further down any chain: the next round would find nothing
             }
             par ^= 1u;
         }
