@@ -242,6 +242,24 @@ def test_tag16_vs_full_key_paths(P):
         _check_join(P, R, np.arange(len(R), dtype=np.int32), S, np.arange(len(S), dtype=np.int32), cfg)
 
 
+def test_long_streams_through_one_table_with_and_without_repeated_keys(P):
+    """One table, many sub-chunks of the streamed side (65536-tuple work items against a <= 4608-entry table): the materialising kernel
+    asks whether the table holds a key twice and, if not, ends every sub-chunk after its first round.  Unique build keys (the shortcut),
+    one repeated key, every key repeated, and a build side of several table chunks — all against the oracle's multiset."""
+    rng = np.random.default_rng(77)
+    nS = 300_001
+    for nR, dup in ((3000, 0), (3000, 1), (3000, 2), (4608, 0), (12000, 1)):
+        R = rng.permutation(50_000)[:nR].astype(np.int32)
+        if dup == 1:
+            R[17] = R[1234]                                   # exactly one key twice
+        elif dup == 2:
+            R[nR // 2:] = R[: nR - nR // 2]                    # every key twice
+        S = R[rng.integers(0, nR, nS)].astype(np.int32)
+        S[::7] = -5                                            # tuples without a partner
+        for cfg in (dict(force_bits=True), dict(bits1=1), dict(bits1=2, bits2=1, probe_chunk=20_000)):
+            _check_join_1(P, R, np.arange(nR, dtype=np.int32), S, np.arange(nS, dtype=np.int32) * 3 + 1, cfg)
+
+
 # ---- histogram-free passes: taken on uniform keys, abandoned (on the device) under skew -------------------------
 def test_fast_path_layout_and_fallback(P):
     rng = np.random.default_rng(55)
