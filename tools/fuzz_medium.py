@@ -10,6 +10,10 @@ from hjtest import pkg
 from oracle import pyoracle as o
 P = pkg()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+# "hibits": every case with 16-18 forced radix bits (9+7, 8+8, 9+8, 9+9 in turn): tag tables, the sliced sampling pass of the sampled path
+# at 16 / 17 bits, exact passes for a skewed relation at 18 — partitions of a few tuples, most of them empty
+HIBITS = len(sys.argv) > 2 and sys.argv[2] == "hibits"
+HB = [dict(bits1=9, bits2=7), dict(bits1=8, bits2=8), dict(bits1=9, bits2=8), dict(bits1=9, bits2=9)]
 t0 = time.time(); bad = 0
 for seed in range(n_cases):
     rng = np.random.default_rng(7000 + seed)
@@ -35,7 +39,8 @@ for seed in range(n_cases):
     lays = []
     for exact in (False, True):
         with P.HashJoin(0) as hj:
-            hj.configure(exact_only=exact, build_side=bside)
+            fb = HB[seed % 4] if HIBITS else {}
+            hj.configure(exact_only=exact, build_side=bside, **fb)
             hj.load_host(P.REL_R, R, Pr); hj.load_host(P.REL_S, S, Ps)
             got = hj.join()
             c = hj.config(); bits = c["bits1"] + c["bits2"]
@@ -53,11 +58,11 @@ for seed in range(n_cases):
                 hj.partition(P.REL_R); hj.partition(P.REL_S)
                 k, pr, ps = hj.join_materialize(cap=em)
                 okc = okc and len(k) == em and o.triples_checksum(k, pr, ps) == echk
-            hj.configure(exact_only=exact, build_side=bside, graph=True)
+            hj.configure(exact_only=exact, build_side=bside, graph=True, **fb)
             for _ in range(3):
                 okc = okc and hj.join() == (em, eagg)
         if not okc:
             bad += 1; print("FAIL seed", seed, "kind", kind, "exact", exact, got, (em, eagg), lay, flush=True)
     print("seed %d kind %d build_side %d nR %d nS %d matches %d layouts (first join -> second join) default %s -> %s, exact_only %s -> %s"
           % (seed, kind, bside, len(R), len(S), em, lays[0][0], lays[0][1], lays[1][0], lays[1][1]), flush=True)
-print("medium fuzz: %d cases, %d failures, %.0f s" % (n_cases, bad, time.time() - t0))
+print("medium fuzz%s: %d cases, %d failures, %.0f s" % (" (16-18 forced radix bits)" if HIBITS else "", n_cases, bad, time.time() - t0))
