@@ -276,7 +276,7 @@ def bench_baselines(a, pkg, torch, dev, local):
         dt = (time.perf_counter() - t0) / a.steps
         out[name] = {"ms": round(dt * 1e3, 3), "Gtuples_per_s": round(2 * n / dt / 1e9, 2)}
     print(json.dumps({"metric": "partitioned vs non-partitioned join, 2^%d x 2^%d unique uniform int32, 1 GPU" % (a.log2n, a.log2n),
-                      "results": out}))
+                      "results": out, "lib_sha256": lib_sha256()}))
 
 
 def bench_stream(a, pkg, torch, dev, local):
@@ -326,7 +326,8 @@ def bench_stream(a, pkg, torch, dev, local):
     print(json.dumps({"metric": "billion tuples/sec, streaming probe side: R 2^27 in HBM, S 2^30 in pinned host memory",
                       "value": round((nR + nS) / dt / 1e9, 3), "unit": "billion tuples/s", "n_gpus": 1,
                       "ms_per_step": round(dt * 1e3, 2), "h2d_GBs": round(nS * 4 / dt / 1e9, 1), "materialize": mat,
-                      "config": {"workload": "PK-FK 2^27 x 2^30, S streamed from pinned host memory in segments of max(|R|/4, 2^24)"}}))
+                      "config": {"workload": "PK-FK 2^27 x 2^30, S streamed from pinned host memory in segments of max(|R|/4, 2^24)"},
+                      "lib_sha256": lib_sha256()}))
 
 
 def bench_coprocess(a, pkg, torch, dev, local):
@@ -357,7 +358,7 @@ def bench_coprocess(a, pkg, torch, dev, local):
                       "host_split_GBs": round(sum(gbs) / len(gbs), 2), "cpu_model": cpu_model(),
                       "numa": dict(zip(("nodes", "gpu_node", "workers_bound_to_cpus_of_that_node"), hj.coprocess_numa())),
                       "config": {"workload": "unique uniform int32, 16 level-0 partitions, host split on the box's CPU quota, "
-                                             "double-buffered upload + GPU join per partition"}}))
+                                             "double-buffered upload + GPU join per partition"}, "lib_sha256": lib_sha256()}))
 
 
 def launch_ranks(n):
