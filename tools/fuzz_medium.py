@@ -15,7 +15,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 HIBITS = len(sys.argv) > 2 and sys.argv[2] == "hibits"
 HB = [dict(bits1=9, bits2=7), dict(bits1=8, bits2=8), dict(bits1=9, bits2=8), dict(bits1=9, bits2=9)]
 t0 = time.time(); bad = 0
-for seed in range(n_cases):
+FIRST = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # first seed (a soak run continues where an earlier one stopped)
+for seed in range(FIRST, FIRST + n_cases):
     rng = np.random.default_rng(7000 + seed)
     nR = int(rng.integers(1 << 18, 1 << 22)); nS = int(rng.integers(1 << 18, 1 << 23))
     kind = seed % 6

@@ -6,8 +6,12 @@ import test_gpu_join as T
 from hjtest import pkg
 P = pkg()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # seconds; 0 = no limit (a soak stops by itself and still prints its summary)
 t0 = time.time(); bad = 0
 for seed in range(lo, hi):
+    if budget and time.time() - t0 > budget:
+        hi = seed
+        break
     try:
         T.test_fuzz_against_oracle(P, seed)
     except Exception as e:  # noqa: BLE001
