@@ -149,6 +149,10 @@ int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg);
 int hj_join_count_enqueue(hj_ctx *c);
 void hj_invalidate_all(hj_ctx *c);
 void drop_graph(hj_ctx *c);
+// (hj_stream.hip: the host-memory paths drive the same partition / plan / join steps)
+int partition_rel(hj_ctx *c, int r);
+int resolve_layout(hj_ctx *c, hj_ctx::Rel &R);
+int plan_join(hj_ctx *c, hj::JoinArgs &a_out, bool &tag16, bool gen_ok = true);
 
 // RAII: HIP events on a stream around one kernel launch (per-kernel statistics, hj_timings)
 struct Timed {
