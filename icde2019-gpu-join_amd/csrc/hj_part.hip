@@ -709,7 +709,10 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    wc_fast<U, 0, 0, false, HEAVY, true, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    // 512 digits: every digit has exactly one of the 512 lines, there is nothing to deal — the fixed-geometry rounds (no per-digit
+    // line table in the inner loops) with the sampled slot capacities (a 512-way pass under skew: 9.8 -> see r4_sampled_16_17_bits.txt)
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    else wc_fast<U, 0, 0, false, HEAVY, true, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
 template <int U>
@@ -741,6 +744,11 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     // workgroup-uniform: parents dominated by one child rank with the wave-aggregated atomic (as k_scatter_wc does per span)
+    if (a.P == (uint32_t)MAX_PARTS) { // one line per child: the fixed-geometry rounds (see k_part1_var)
+        if (v.heavy[d]) wc_fast<U, 1, 1, false, true, false, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+        else wc_fast<U, 1, 1, false, false, false, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+        return;
+    }
     if (v.heavy[d]) wc_fast<U, 0, 1, false, true, true, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 1, false, false, true, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
