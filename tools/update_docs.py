@@ -32,6 +32,11 @@ def kms(d, k):  # per-launch ms of a kernel (the instrumented steps)
     return v["ms_per_step"] / v["launches_per_step"]
 
 
+def tp(d):  # "[three processes on one box: a-b] " when the line is the median of three
+    t = d.get("three_processes")
+    return ("[median of three processes on one box: %.1f–%.1f] " % (min(t["values"]), max(t["values"]))) if t else ""
+
+
 def readme_rows():
     b30, e30 = both("2p30")
     b27, e27 = both("2p27")
@@ -42,9 +47,9 @@ def readme_rows():
     base = load("baselines")
     out = ["| workload | Gtuples/s | ms/step | notes |", "|---|---|---|---|"]
     r, re_, p, pe, m, me = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"]
-    out.append("| 2^30 ⋈ 2^30 unique uniform int32, count-only (headline) | **%.1f** (%.1f; r3 driver 140.9; r2 driver 124.3) | %.2f (%.2f) | "
+    out.append(("| 2^30 ⋈ 2^30 unique uniform int32, count-only (headline) | **%.1f** " + tp(b30) + "(%.1f; r3 driver 140.9; r2 driver 124.3) | %.2f (%.2f) | "
                "`k_part1_fast` %.2f (%.2f) ms, `k_part2_fast` %.2f (%.2f) ms per launch, `k_join` %.2f (%.2f) ms; dominant `%s` %.2f (%.2f) of 8 TB/s = "
-               "%.2f (%.2f) of the same-run copy ceiling; probe %.2f (%.2f) of 8 TB/s; HBM traffic %.3f × algorithmic |"
+               "%.2f (%.2f) of the same-run copy ceiling; probe %.2f (%.2f) of 8 TB/s; HBM traffic %.3f × algorithmic |")
                % (b30["value"], e30["value"], b30["ms_per_step"], e30["ms_per_step"], kms(b30, "k_part1_fast"), kms(e30, "k_part1_fast"),
                   kms(b30, "k_part2_fast"), kms(e30, "k_part2_fast"), kms(b30, "k_join_count"), kms(e30, "k_join_count"), r["kernel"], r["frac"], re_["frac"],
                   r["frac_of_stream_copy"], re_["frac_of_stream_copy"], p["frac_of_8TBs"], pe["frac_of_8TBs"], r["traffic"] / r["algorithmic_bytes_per_launch"]))
@@ -54,17 +59,17 @@ def readme_rows():
                   m["k_join_materialize_frac_of_8TBs"], me["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"]))
     out.append("| 2^30, exact (histogram) passes only | %.1f | %.2f | |" % (bx["value"], bx["ms_per_step"]))
     r, re_, p, pe, m, me = b27["roofline"], e27["roofline"], b27["probe_phase"], e27["probe_phase"], b27["materialize"], e27["materialize"]
-    out.append("| 2^27 ⋈ 2^27 (configs[1]), default 9+6 bits | **%.1f** (%.1f; round 2: 113.9) | %.2f (%.2f) | dominant `%s` %.2f (%.2f) of 8 TB/s = %.2f (%.2f) of the "
-               "copy ceiling, probe %.2f (%.2f) (stated target 0.68 NOT met: a 0.45-ms launch carries ~60 µs of fixed cost, DESIGN §10.1); materialising %.1f (%.1f) |"
+    out.append(("| 2^27 ⋈ 2^27 (configs[1]), default 9+6 bits | **%.1f** " + tp(b27) + "(%.1f; round 2: 113.9) | %.2f (%.2f) | dominant `%s` %.2f (%.2f) of 8 TB/s = %.2f (%.2f) of the "
+               "copy ceiling, probe %.2f (%.2f) (stated target 0.68 NOT met: a 0.45-ms launch carries ~60 µs of fixed cost, DESIGN §10.1); materialising %.1f (%.1f) |")
                % (b27["value"], e27["value"], b27["ms_per_step"], e27["ms_per_step"], r["kernel"], r["frac"], re_["frac"], r["frac_of_stream_copy"], re_["frac_of_stream_copy"],
                   p["frac_of_8TBs"], pe["frac_of_8TBs"], m["value"], me["value"]))
     s, se = b27["config2_as_stated"], e27["config2_as_stated"]
     out.append("| 2^27 ⋈ 2^27 **as configs[1] states it: ONE 9-bit pass** | %.1f (%.1f) | %.1f (%.1f) | 2^18-tuple partitions rebuild the LDS table ~60 × each: why the default is two passes |"
                % (s["value"], se["value"], s["ms_per_step"], se["ms_per_step"]))
     r, re_, p, pe, m, me = bz["roofline"], ez["roofline"], bz["probe_phase"], ez["probe_phase"], bz["materialize"], ez["materialize"]
-    out.append("| **PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0 (configs[3])**, count | **%.1f** (%.1f; round 3: 128 on its fastest box; round 2: 94.1) | %.2f (%.2f) | "
+    out.append(("| **PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0 (configs[3])**, count | **%.1f** " + tp(bz) + "(%.1f; round 3: 128 on its fastest box; round 2: 94.1) | %.2f (%.2f) | "
                "S: `k_part1_var` %.2f (%.2f) + `k_part2_var` %.2f (%.2f) ms — sampled capacities, no histogram (dominant `%s` %.2f (%.2f) of 8 TB/s, traffic %.3f ×); "
-               "join %.2f (%.2f) ms = %.2f (%.2f); the larger relation's passes on a high-priority stream (DESIGN §3.5); everything exact: %.1f |"
+               "join %.2f (%.2f) ms = %.2f (%.2f); the larger relation's passes on a high-priority stream (DESIGN §3.5); everything exact: %.1f |")
                % (bz["value"], ez["value"], bz["ms_per_step"], ez["ms_per_step"], kms(bz, "k_part1_var"), kms(ez, "k_part1_var"), kms(bz, "k_part2_var"), kms(ez, "k_part2_var"),
                   r["kernel"], r["frac"], re_["frac"], r["traffic"] / r["algorithmic_bytes_per_launch"], kms(bz, "k_join_count"), kms(ez, "k_join_count"),
                   p["frac_of_8TBs"], pe["frac_of_8TBs"], bzx["value"]))
@@ -118,9 +123,9 @@ def baseline_rows():
     m8 = load("phantom8")[0]["dist"]["model"]
     out = ["| config | GPUs | Gtuples/s | dominant pass kernel GB/s (algorithmic) | probe GB/s (algorithmic) | % of 8 TB/s (pass / probe) | CPU baseline Gtuples/s (cores) |", "|---|---|---|---|---|---|---|"]
     r, re_, p, pe, m, me, c, ce = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"], b30["cpu_baseline"], e30["cpu_baseline"]
-    out.append("| 3: 2^30 ⋈ 2^30 uniform, count-only | 1 | **%.1f**, %.2f ms (evidence call %.1f, %.2f ms; driver r3 140.9, r2 124.3; round 1: 105–107) | %.0f (`%s`, %.2f ms; evidence call %.0f; PMC traffic %.2f GB for %.2f); "
+    out.append(("| 3: 2^30 ⋈ 2^30 uniform, count-only | 1 | **%.1f**, %.2f ms " + tp(b30) + "(evidence call %.1f, %.2f ms; driver r3 140.9, r2 124.3; round 1: 105–107) | %.0f (`%s`, %.2f ms; evidence call %.0f; PMC traffic %.2f GB for %.2f); "
                "same-run stream-copy ceiling %.0f | %.0f (%.2f ms) | %.1f %% / %.1f %% (evidence call %.1f %% / %.1f %%) | %.2f (%.2f) (%d threads = the box's cgroup CPU quota, same workload at full size, oracle port); "
-               "reference `joinCpu` port %.2f at 2^22 |"
+               "reference `joinCpu` port %.2f at 2^22 |")
                % (b30["value"], b30["ms_per_step"], e30["value"], e30["ms_per_step"], r["achieved"], r["kernel"], r["avg_launch_ms"], re_["achieved"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9,
                   r["stream_copy_ceiling"], p["achieved_GBs"], p["avg_launch_ms"], 100 * r["frac"], 100 * p["frac_of_8TBs"], 100 * re_["frac"], 100 * pe["frac_of_8TBs"], c["value"], ce["value"], c["cores"], c["joinCpu"]["value"]))
     out.append("| 3: same, materialising 2^30 output tuples in ONE probe | 1 | **%.1f** (evidence call %.1f; driver r3 121.2; round 2, two probes: 93.6) | same | `k_join_mat_reg` %.0f (%.0f) (8 B/tuple + 12 B/match) | "
@@ -157,8 +162,8 @@ def design_rows():
     m8 = load("phantom8")[0]["dist"]["model"]
     out = ["| config | Gtuples/s | ms/step | dominant pass kernel: ms, of 8 TB/s, of same-run copy ceiling | probe of 8 TB/s | CPU baseline Gtuples/s |", "|---|---|---|---|---|---|"]
     r, re_, p, pe, m, me, c = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"], b30["cpu_baseline"]
-    out.append("| 3: 2^30 ⋈ 2^30 uniform, count-only | **%.1f** (evidence call %.1f; r3 driver 140.9; r2 driver 124.3; r1 105–107) | %.2f (%.2f) | `%s` %.2f ms, %.2f, %.2f (copy %.2f TB/s) (evidence call %.2f ms, %.2f, %.2f); "
-               "traffic %.2f GB for %.2f | %.2f (%.2f) | %.2f (radix port, %d threads, full size); `joinCpu` port %.2f at 2^22 |"
+    out.append(("| 3: 2^30 ⋈ 2^30 uniform, count-only | **%.1f** " + tp(b30) + "(evidence call %.1f; r3 driver 140.9; r2 driver 124.3; r1 105–107) | %.2f (%.2f) | `%s` %.2f ms, %.2f, %.2f (copy %.2f TB/s) (evidence call %.2f ms, %.2f, %.2f); "
+               "traffic %.2f GB for %.2f | %.2f (%.2f) | %.2f (radix port, %d threads, full size); `joinCpu` port %.2f at 2^22 |")
                % (b30["value"], e30["value"], b30["ms_per_step"], e30["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"], r["frac_of_stream_copy"], r["stream_copy_ceiling"] / 1e3,
                   re_["avg_launch_ms"], re_["frac"], re_["frac_of_stream_copy"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9, p["frac_of_8TBs"], pe["frac_of_8TBs"], c["value"], c["cores"], c["joinCpu"]["value"]))
     out.append("| 3: same, materialising 2^30 tuples in one probe | **%.1f** (evidence call %.1f; r3 driver 121.2; r2 93.6–96.4) | %.2f (%.2f) | — | `k_join_mat_reg` %.2f (%.2f) = %.2f (%.2f) of the read/write-mix ceiling | — |"
