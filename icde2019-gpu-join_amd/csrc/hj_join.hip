@@ -327,11 +327,20 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
             while (w0 >= nq1 && rr + 1 < nr) { rr++; stream_range(rr, nq0, nq1); w0 = (nq0 & ~(uint64_t)3) + (uint64_t)wave * 256; }
         };
         skip_empty();
-        int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0);
-        if (w0 + (uint64_t)lane_id() * 4 < nq1) {
-            nk = load4(sk, w0 + (uint64_t)lane_id() * 4, s_nalloc);
-            np = load4(sp, w0 + (uint64_t)lane_id() * 4, s_nalloc);
-        }
+        // TWO blocks of the stream are requested ahead of the one being probed, the first two before the table is built: their loads fly
+        // during the build (same box, three rounds: k_join 0.454-0.461 -> 0.435-0.441 ms at 2^27, 2.86-2.88 -> 2.80-2.81 at 2^30; a long
+        // stream — config 4 — does not care: 3.25 both)
+        uint64_t w1, q01, q11, w2, q02, q12; // the staged blocks: position and range (wave-uniform)
+        int4 nk = make_int4(0, 0, 0, 0), np = make_int4(0, 0, 0, 0), nk2 = make_int4(0, 0, 0, 0), np2 = make_int4(0, 0, 0, 0);
+        auto issue = [&](int4 &k_, int4 &p_, uint64_t &w_, uint64_t &q0_, uint64_t &q1_) { // the block at the cursor; the cursor moves on
+            w_ = w0; q0_ = nq0; q1_ = nq1;
+            k_ = make_int4(0, 0, 0, 0); p_ = make_int4(0, 0, 0, 0);
+            const uint64_t i_ = w0 + (uint64_t)lane_id() * 4;
+            if (i_ < nq1) { k_ = load4(sk, i_, s_nalloc); p_ = load4(sp, i_, s_nalloc); }
+            if (w0 < nq1) { w0 += (uint64_t)JOIN_THREADS * 4; skip_empty(); }
+        };
+        issue(nk, np, w1, q01, q11);
+        if (!GEN) issue(nk2, np2, w2, q02, q12); // (general items: one block ahead — the second one costs the third workgroup per CU: 85 VGPRs)
         for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
         __syncthreads();
         for (;;) { // the pieces of this chunk: [gb, gb + nbc) goes to slots filled ... (one piece unless the table side is a list)
@@ -369,16 +378,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
         // the loop bound is wave-uniform (w0), so every lane of a wave stays in the loop together:
         // the ballot ranks and the wave's output cursor depend on it.  The next iteration's loads are issued before
         // this iteration's chains are walked.
-        while (w0 < nq1) {
-            const uint64_t i = w0 + (uint64_t)lane_id() * 4, q0 = nq0, q1 = nq1;
+        while (w1 < q11) {
+            const uint64_t i = w1 + (uint64_t)lane_id() * 4, q0 = q01, q1 = q11;
             const int4 kv = nk, pv = np;
-            {
-                w0 += (uint64_t)JOIN_THREADS * 4;
-                skip_empty();
-                const uint64_t inext = w0 + (uint64_t)lane_id() * 4;
-                nk = make_int4(0, 0, 0, 0); np = make_int4(0, 0, 0, 0);
-                if (inext < nq1) { nk = load4(sk, inext, s_nalloc); np = load4(sp, inext, s_nalloc); }
-            }
+            if (!GEN) { nk = nk2; np = np2; w1 = w2; q01 = q02; q11 = q12; issue(nk2, np2, w2, q02, q12); }
+            else issue(nk, np, w1, q01, q11);
             if (JM == 0) {
                 // count-only: the four bucket heads of this lane's four tuples are fetched first and the four
                 // chains are walked in lockstep, so their LDS reads overlap instead of completing one by one
