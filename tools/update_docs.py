@@ -218,6 +218,35 @@ BLOCKS = {
 }
 
 
+def sync_profiles_readme(check):
+    """profiles/README.md: the binary's hash, the kernel-stats sentence, the GPU suite's count — from the files."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "README.md")
+    s = orig = open(path).read()
+    s = re.sub(r"final binary `libhj\.so` sha256 `[0-9a-f]{8}…`", "final binary `libhj.so` sha256 `%s…`" % sha()[:8], s)
+    rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_kernel_stats_2p30.csv")))}
+
+    def avg(sub):
+        for k, r in rows.items():
+            if sub in k:
+                return float(r["AverageNs"]) / 1e6, r["Calls"]
+    e = load("2p30_evidence_call")[0]
+    k = e["kernels"]
+    m = re.search(r"2\^30: `k_part2_fast` \d+ calls avg [0-9.]+ ms.*?\(the bench line of that call: [^)]*\)\.", s)
+    if m:
+        s = s.replace(m.group(0), "2^30: `k_part2_fast` %s calls avg %.3f ms, `k_part1_fast` %.3f ms, `k_join` %.3f ms, `k_join_mat_reg` %s calls %.3f ms (the bench line of that call: %.2f / %.2f / %.2f / %.2f)."
+                      % (avg("k_part2_fast")[1], avg("k_part2_fast")[0], avg("k_part1_fast")[0], avg("k_join<")[0], avg("k_join_mat_reg")[1], avg("k_join_mat_reg")[0],
+                         k["k_part2_fast"]["ms_per_step"] / 2, k["k_part1_fast"]["ms_per_step"] / 2, k["k_join_count"]["ms_per_step"], e["materialize"]["k_join_materialize_ms"]))
+    t = open(os.path.join(ROOT, "profiles", "r4_gpu_tests.txt")).read().strip().split("\n")[-1]
+    mm = re.search(r"(\d+) passed, (\d+) skipped.* in ([0-9.]+)s", t)
+    if mm:
+        s = re.sub(r"`pytest -m gpu` of the final binary: \d+ passed, \d+ skipped \(the two RCCL world-2 tests\), \d+ s;",
+                   "`pytest -m gpu` of the final binary: %s passed, %s skipped (the two RCCL world-2 tests), %.0f s;" % (mm.group(1), mm.group(2), float(mm.group(3))), s)
+    if s != orig and not check:
+        open(path, "w").write(s)
+    return s != orig
+
+
 def main():
     check = "--check" in sys.argv
     stale = []
@@ -238,6 +267,8 @@ def main():
             stale.append(fname)
             if not check:
                 open(path, "w").write(s)
+    if sync_profiles_readme(check):
+        stale.append("profiles/README.md")
     print(("stale: " if check else "updated: ") + (", ".join(stale) or "nothing"))
     return 1 if (check and stale) else 0
 
