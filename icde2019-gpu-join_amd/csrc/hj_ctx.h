@@ -105,6 +105,7 @@ struct hj_ctx {
     size_t host_cap[2] = {0, 0};    // elements
     int numa_nodes = 0, numa_gpu_node = -1, numa_pinned_cpus = 0; // co-processing: host topology seen by the last call
     double host_split_gbs = 0;      // throughput of the last host level-0 split (bytes read + written per second)
+    uint32_t coprocess_groups = 0;  // residency groups of the last co-processing call
     Buf out_k[2], out_p1[2], out_p2[2]; // streamed materialisation: double-buffered device output columns
     hipStream_t d2h = nullptr;      // third stream: output columns back to the host (hjcp.cu:1947-1961)
     hipEvent_t out_ready[2] = {}, out_free[2] = {};

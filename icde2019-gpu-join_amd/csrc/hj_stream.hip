@@ -353,10 +353,33 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         // bytes read + written by the scatter (keys + payloads), like partition-primitives.cu:218
         c->host_split_gbs = dt > 0 ? 16.0 * (double)(nR + nS) / dt / 1e9 : 0;
     }
+    // Residency groups (the reference schedules which level-0 partitions are resident together with a knapsack over PARTS_RESIDENT
+    // slots, groupOptimal2, pp.cu:307-468 / hjcp.cu:1357-1363).  Here a group is a run of CONSECUTIVE level-0 pairs — contiguous in the
+    // split arrays, so one upload per column and ONE join per group — as long as the group's tuples fit the budget: staging (double
+    // buffered) + both relations' partition buffers ~ 35 bytes per tuple, half of the free device memory (HJ_COPROCESS_GROUP_TUPLES
+    // overrides: tests force small groups).  On a 288-GB card everything up to ~2^31 tuples is one group.
+    std::vector<uint32_t> gstart;
+    if (!rc) {
+        uint64_t budget = 0;
+        if (const char *e = getenv("HJ_COPROCESS_GROUP_TUPLES")) budget = strtoull(e, nullptr, 10);
+        if (!budget) {
+            size_t free_b = 0, total_b = 0;
+            budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? (uint64_t)free_b / 2 / 35 : ((uint64_t)1 << 28);
+        }
+        uint64_t cur = 0;
+        for (uint32_t p = 0; p < level0_parts; p++) {
+            const uint64_t t = (off[0][p + 1] - off[0][p]) + (off[1][p + 1] - off[1][p]);
+            if (p == 0 || cur + t > budget) { gstart.push_back(p); cur = 0; }
+            cur += t;
+        }
+        gstart.push_back(level0_parts);
+    }
+    const uint32_t ngroups = gstart.empty() ? 0u : (uint32_t)gstart.size() - 1;
+    c->coprocess_groups = ngroups;
     uint64_t maxp[2] = {0, 0};
     if (!rc)
         for (int r = 0; r < 2; r++)
-            for (uint32_t p = 0; p < level0_parts; p++) maxp[r] = std::max(maxp[r], off[r][p + 1] - off[r][p]);
+            for (uint32_t g = 0; g < ngroups; g++) maxp[r] = std::max(maxp[r], off[r][gstart[g + 1]] - off[r][gstart[g]]);
     if (!rc && !c->copy) { if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) rc = fail(c, HJ_EHIP, "copy stream"); }
     for (int i = 0; i < 2 && !rc; i++) {
         if (!c->seg_ready[i] && hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
@@ -365,9 +388,9 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         if (!rc) rc = ensure(c, c->seg_k[i], (size_t)(maxp[1] + PAD) * 4);
         if (!rc) rc = ensure(c, c->seg_p[i], (size_t)(maxp[1] + PAD) * 4);
     }
-    auto upload = [&](uint32_t p) -> int {
-        const int b = (int)(p & 1);
-        const uint64_t r0 = off[0][p], rn = off[0][p + 1] - r0, s0 = off[1][p], sn = off[1][p + 1] - s0;
+    auto upload = [&](uint32_t g) -> int {
+        const int b = (int)(g & 1);
+        const uint64_t r0 = off[0][gstart[g]], rn = off[0][gstart[g + 1]] - r0, s0 = off[1][gstart[g]], sn = off[1][gstart[g + 1]] - s0;
         if (rn) { HIPCHK(c, hipMemcpyAsync(c->cop_k[b].p, pk[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy));
                   HIPCHK(c, hipMemcpyAsync(c->cop_p[b].p, pp[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy)); }
         if (sn) { HIPCHK(c, hipMemcpyAsync(c->seg_k[b].p, pk[1] + s0, sn * 4, hipMemcpyHostToDevice, c->copy));
@@ -376,13 +399,13 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         return 0;
     };
     uint64_t tot_m = 0, tot_a = 0;
-    if (!rc) rc = upload(0);
-    for (uint32_t p = 0; p < level0_parts && !rc; p++) {
-        const int b = (int)(p & 1);
-        if (p + 1 < level0_parts && (rc = upload(p + 1))) break; // the other pair of buffers was joined + synchronised last round
+    if (!rc && ngroups) rc = upload(0);
+    for (uint32_t g = 0; g < ngroups && !rc; g++) {
+        const int b = (int)(g & 1);
+        if (g + 1 < ngroups && (rc = upload(g + 1))) break; // the other pair of buffers was joined + synchronised last round
         hipError_t e = hipStreamWaitEvent(c->stream, c->seg_ready[b], 0);
         if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
-        const uint64_t rn = off[0][p + 1] - off[0][p], sn = off[1][p + 1] - off[1][p];
+        const uint64_t rn = off[0][gstart[g + 1]] - off[0][gstart[g]], sn = off[1][gstart[g + 1]] - off[1][gstart[g]];
         if ((rc = hj_bind_device(c, HJ_REL_R, (const int32_t *)c->cop_k[b].p, (const int32_t *)c->cop_p[b].p, rn))) break;
         if ((rc = hj_bind_device(c, HJ_REL_S, (const int32_t *)c->seg_k[b].p, (const int32_t *)c->seg_p[b].p, sn))) break;
         uint64_t m = 0, a = 0;
@@ -403,6 +426,12 @@ int hj_coprocess_numa(const hj_ctx *c, int *nodes, int *gpu_node, int *pinned_cp
     if (nodes) *nodes = c->numa_nodes;
     if (gpu_node) *gpu_node = c->numa_gpu_node;
     if (pinned_cpus) *pinned_cpus = c->numa_pinned_cpus;
+    return HJ_OK;
+}
+
+int hj_coprocess_groups(const hj_ctx *c, uint32_t *groups) {
+    if (!c) return HJ_EINVAL;
+    if (groups) *groups = c->coprocess_groups;
     return HJ_OK;
 }
 

@@ -208,6 +208,12 @@ class HashJoin:
         self._ck(self._L.hj_coprocess_numa(self._h, C.byref(a), C.byref(b), C.byref(d)))
         return a.value, b.value, d.value
 
+    def coprocess_groups(self):
+        """Residency groups of the last join_coprocess call (runs of level-0 pairs uploaded and joined together)."""
+        v = C.c_uint32()
+        self._ck(self._L.hj_coprocess_groups(self._h, C.byref(v)))
+        return v.value
+
     def host_split_throughput(self):
         v = C.c_double()
         self._ck(self._L.hj_host_split_throughput(self._h, C.byref(v)))

@@ -179,6 +179,10 @@ int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t
  * socket): NUMA nodes of the host, the node closest to the context's GPU (-1 unknown: pinned staging is allocated there by
  * hipHostMalloc), and how many of that node's CPUs the split's workers were bound to (0: not bound — one node, HJ_NUMA=0). */
 int hj_coprocess_numa(const hj_ctx *ctx, int *nodes, int *gpu_node, int *pinned_cpus);
+/* Residency groups of the last hj_join_coprocess call: runs of consecutive level-0 pairs that were uploaded and joined together (one
+ * upload per column, one join per group) because their tuples fit the device-memory budget — what the reference's knapsack over
+ * PARTS_RESIDENT slots decides (groupOptimal2, partition-primitives.cu:307-468; hjcp.cu:1357-1363).  1 on a card that holds everything. */
+int hj_coprocess_groups(const hj_ctx *ctx, uint32_t *groups);
 /* GB/s of the host split inside the last hj_join_coprocess call of this context. */
 int hj_host_split_throughput(const hj_ctx *ctx, double *gbs);
 

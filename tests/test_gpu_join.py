@@ -740,12 +740,34 @@ def test_coprocess(P, parts, threads):
         assert hj.join_coprocess(R, Pr, S, Ps, parts, threads) == (em, eagg)
         assert hj.join_coprocess(R, None, S, None, parts, threads) == o.join_count(R, None, S, None, checksum=False)[:2]
         assert hj.host_split_throughput() > 0                       # the host split reports its GB/s (pp.cu:218)
+        assert hj.coprocess_groups() == 1                           # everything fits the card: one residency group, one join
         e = np.empty(0, np.int32)
         assert hj.join_coprocess(e, None, S, None, parts, threads) == (0, 0)
         # the resident path is usable afterwards
         hj.load_host(P.REL_R, R, Pr)
         hj.load_host(P.REL_S, S, Ps)
         assert hj.join() == (em, eagg)
+
+
+def test_coprocess_residency_groups(P, monkeypatch):
+    """Level-0 pairs are uploaded and joined in residency groups — runs of consecutive pairs whose tuples fit a device-memory budget
+    (the reference's groupOptimal2, pp.cu:307-468).  A small budget forces many groups, a partition above the budget is a group of its
+    own; the result does not depend on the grouping."""
+    rng = np.random.default_rng(404)
+    nR, nS = 200_000, 900_000
+    R = rng.integers(0, 150_000, nR).astype(np.int32)
+    S = rng.integers(0, 150_000, nS).astype(np.int32)
+    S[: nS // 3] = 77                                               # one level-0 partition far above any small budget
+    Pr, Ps = np.arange(nR, dtype=np.int32), np.arange(nS, dtype=np.int32)
+    expect = o.join_count(R, Pr, S, Ps, checksum=False)[:2]
+    seen = []
+    for budget in ("0", "1", "60000", "150000", "400000", "100000000"):
+        monkeypatch.setenv("HJ_COPROCESS_GROUP_TUPLES", budget)
+        with P.HashJoin(0) as hj:
+            assert hj.join_coprocess(R, Pr, S, Ps, 16, 4) == expect, budget
+            seen.append(hj.coprocess_groups())
+    assert seen[0] == 1 and seen[1] == 16 and seen[-1] == 1            # no override: the card's budget; 1 tuple: every pair alone
+    assert seen[1] >= seen[2] >= seen[3] >= seen[4] >= seen[5]
 
 
 def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
