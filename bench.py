@@ -175,7 +175,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     achieved = 16.0 * tuples / (avg_ms * 1e-3) / 1e9
     traffic = None
     try:
-        pmf = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_zipf.json")))
+        pmf = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_zipf.json")))
         key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
         if key and pmf.get("lib_sha256") == lib_sha256():
             traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
@@ -184,6 +184,11 @@ def bench_zipf(a, pkg, torch, dev, local):
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": 16.0 * tuples}
+    if not a.no_extras:
+        nub = min(nS, 1 << 30)
+        tk, tp = (torch.empty(nub, dtype=torch.int32, device=dev) for _ in range(2))
+        roof.update(mix_ceiling(hj, Sk, Sp, tk, tp, nub, 8.0 * tuples, 8.0 * tuples, achieved))
+        del tk, tp
     jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
     probe = None
     if jc["launches"]:
@@ -462,6 +467,95 @@ def join_cpu_baseline(hj, torch, dev, threads, log2n=22):
                       % (log2n, log2n, threads, dt)}
 
 
+def dist_materialize_leg(a, pkg, torch, dist, hj, dj, cols, n, world, rank, expect, dup, cdev, barrier):
+    """N > 1: the sharded MATERIALISING join (hj_dist_rank_join_materialize): every rank writes the (key, payR, payS) tuples of the
+    partitions it owns into its own device columns; timed like the headline (barrier + synchronize on both sides, max over ranks).
+    Output columns sized at the even share + 10 % (hash sharding of uniform keys is even to a fraction of a percent); a rank whose
+    share does not fit makes every rank raise (HJ_ECAPACITY).  Full-size property check outside the timed region: the sum over the
+    ranks of the order-independent digest of each share equals the digest of {(k,1,1) : k in R} (unique keys, payloads 1)."""
+    Rk, Rp, Sk, Sp = cols
+    G = a.phantom if (world == 1 and a.phantom > 1) else world
+    share = expect if world == 1 else (expect // world + expect // (10 * world) + 4096)
+    dev = Rk.device
+    ok, opr, ops = (torch.empty(share, dtype=torch.int32, device=dev) for _ in range(3))
+
+    def mstep():
+        return dj.join_materialize(Rk, Rp, Sk, Sp, ok, opr, ops, cap=share)
+
+    m, _, nloc, nall = mstep()                       # warm-up: first touch of the output columns
+    assert m == expect and sum(nall) == expect, (m, expect, nall)
+    barrier()
+    reps = max(1, a.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m, _, nloc, nall = mstep()
+    barrier()
+    dtm = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dtm], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtm = float(t.item())
+    dtm /= reps
+    assert m == expect and sum(nall) == expect and nall[rank] == nloc
+    digest_checked = False
+    if dup == 1:
+        got_d, want_d = hj.digest_triples(ok, opr, ops, nloc), hj.digest_triples(Rk, Rp, Sp, n)
+        if world > 1:
+            both = [None] * world
+            dist.all_gather_object(both, (got_d, want_d))
+            got_d, want_d = sum(x for x, _ in both) % (1 << 64), sum(y for _, y in both) % (1 << 64)
+        assert got_d == want_d, "materialised output digest (union of the ranks' shares)"
+        digest_checked = True
+    st = dj.stats()
+    out = {"value": round(2.0 * n * world / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3), "scaling": "weak",
+           "output_tuples_total": int(m), "output_tuples_per_rank": [int(x) for x in nall], "output_capacity_per_rank": int(share),
+           "digest_checked": digest_checked, "path": st["path"], "probe_groups": st["probe_groups"],
+           "output": "sharded: every GPU keeps the (key,payR,payS) tuples of the partitions it owns (SURVEY §8(e)); no tuple crosses a link twice",
+           "rank0_stage_ms": {k: st[k] for k in ("split_ms", "pass1_ms", "pass2_join_ms", "early_pass2_join_ms", "first_split_ms", "last_pass1_ms", "exchange_ms", "wall_ms")}}
+    if st["path"] == "sliced" and G > 1:
+        LINK_GBS = 76.8
+        link_ms = st["link_bytes"] / (G - 1) / (LINK_GBS * 1e9) * 1e3
+        local_ms = sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"]
+        exposed = st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"]
+        out["model"] = {"gpus": G, "phantom": bool(world == 1), "link_ms": round(link_ms, 3), "local_ms_total": round(local_ms, 3),
+                        "exposed_local_ms": round(exposed, 3), "modelled_step_ms": round(max(link_ms, local_ms - exposed) + exposed, 3),
+                        "modelled_Gtuples_per_s_per_gpu": round(2.0 * n / ((max(link_ms, local_ms - exposed) + exposed) * 1e-3) / 1e9, 2),
+                        "note": "as dist.model, with the materialising probe in place of the count (the earlier probe-side group writes its "
+                                "output under the exchange, the last group in the tail)"}
+    del ok, opr, ops
+    return out
+
+
+def strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier):
+    """N > 1: the strong-scaling point of BASELINE.json's metric read as "2^30 ⋈ 2^30 over 1/2/4/8 GPUs": 2^log2n tuples per relation
+    in TOTAL, 1/N of each on every GPU (slices of the same two permutations of [0, 2^log2n) the N=1 run joins)."""
+    ns = n // world
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Rk, Rp, Sk, Sp = (torch.empty(ns, dtype=torch.int32, device=dev) for _ in range(4))
+    hj.gen_unique(Rk, ns, rank * ns, n, 1)
+    hj.gen_unique(Sk, ns, rank * ns, n, 2)
+    hj.fill_payload(Rp, ns, "ones")
+    hj.fill_payload(Sp, ns, "ones")
+    hj.sync()
+    for _ in range(max(1, a.warmup)):
+        assert dj.join(Rk, Rp, Sk, Sp)[0] == n
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = dj.join(Rk, Rp, Sk, Sp)[0]
+    barrier()
+    dt = time.perf_counter() - t0
+    assert got == n
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    st = dj.stats()
+    return {"value": round(2.0 * n * a.steps / dt / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "scaling": "strong", "steps": a.steps, "tuples_per_relation_total": n, "tuples_per_relation_per_gpu": ns, "matches": int(got),
+            "path": st["path"], "slices": st["slices"], "exchange_ms": round(st["exchange_ms"], 3),
+            "workload": "2^%d ⋈ 2^%d unique uniform int32 in total, 1/%d of each relation per GPU, count-only" % (a.log2n, a.log2n, world)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; default: WORLD_SIZE under a launcher, else 1")
@@ -488,6 +582,7 @@ def main():
                          "locally instead of crossing a link) and model the link time beside the measured local stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg (2^log2n tuples per relation in TOTAL, 1/N per GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM ceilings and the phase split (profiling runs)")
     a = ap.parse_args()
     if a.gpus is None:   # `torchrun ... bench.py` without --gpus: the launcher's world size is the GPU count
@@ -660,6 +755,13 @@ def main():
                                       "modelled_Gtuples_per_s_per_gpu": round(2.0 * n / ((max(link_ms, local_ms - exposed) + exposed) * 1e-3) / 1e9, 2),
                                       "note": "split(i+1) || exchange(i) || pass-1(i-1); exposed = first split + last pass 1 + pass 2 and join of the probe side's last group of slices"}
 
+    # ---- N > 1 (or the multi-GPU path on one GPU): the materialising sharded join and the strong-scaling point ----
+    dist_mat, strong = None, None
+    if use_dist and c_impl and not a.no_materialize:
+        dist_mat = dist_materialize_leg(a, pkg, torch, dist, hj, dj, (Rk, Rp, Sk, Sp), n, world, rank, expect, dup, cdev, barrier)
+    if use_dist and c_impl and world > 1 and not a.no_strong:
+        strong = strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier)
+
     # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
     passes = ("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter")
@@ -676,7 +778,7 @@ def main():
         # ... and only if that file was collected from THIS build of libhj.so (its sha256 is stored in the file)
         traffic, src = None, None
         try:
-            src = "profiles/r4_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
+            src = "profiles/r5_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
             pmf = json.load(open(os.path.join(ROOT, src)))
             key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
             if key and pmf.get("lib_sha256") == lib_sha256():
@@ -692,15 +794,18 @@ def main():
                             "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
                             "committed kernel stats are taken with HJ_FORK_LOG2=0)"}
         if not a.no_extras:
-            # on-box ceilings, same run: what HBM gives this access pattern with no partitioning work at all
+            # The bound of THIS box, same run: a pass reads 8 B and writes 8 B per tuple, and no kernel with that mix can beat
+            # (R + W) / (R / read_only + W / write_only), the two one-way streams measured by hj_ubench kinds 2 / 3 on the same columns.
+            # Two further micro-benchmarks are kept as named REFERENCE POINTS, not ceilings (a naive two-column copy and the same copy
+            # with every 128-B line stored at a pseudo-random aligned position: the passes beat both, round 4's line said 1.03 / 1.07).
             tk, tp = torch.empty_like(Rk), torch.empty_like(Rp)
+            roof.update(mix_ceiling(hj, Rk, Rp, tk, tp, n, 8.0 * tuples_per_launch, 8.0 * tuples_per_launch, achieved))
             copy = hj.ubench("copy", Rk, Rp, tk, tp, n)
             scat = hj.ubench("line_scatter", Rk, Rp, tk, tp, n)
             del tk, tp
-            roof.update({"stream_copy_ceiling": round(copy, 1), "frac_of_stream_copy": round(achieved / copy, 4),
-                         "line_scatter_ceiling": round(scat, 1), "frac_of_line_scatter": round(achieved / scat, 4),
-                         "ceilings": "hj_ubench, same run: 16 B/lane copy of a 2^%d-tuple column pair; same reads with every 128-B "
-                                     "line stored at a pseudo-random aligned line position" % a.log2n})
+            roof.update({"reference_points": {"stream_copy_GBs": round(copy, 1), "line_scatter_GBs": round(scat, 1),
+                                              "what": "hj_ubench kinds 0 / 1, same run: a plain 16 B/lane copy of a 2^%d-tuple column pair; the same "
+                                                      "reads with every 128-B line stored at a pseudo-random aligned line position.  Not bounds." % a.log2n}})
     if use_dist and c_impl and dist_info and dist_info["rank0"]["path"] == "sliced" and (world > 1 or a.phantom > 1):
         # N > 1: the step is bound by the links, not by HBM: every ordered pair of GPUs has its own xGMI link, and a
         # rank's bytes to ONE peer cross ONE link direction.  achieved = those bytes over the device time the exchange was in
@@ -818,7 +923,8 @@ def main():
         hj.configure()
 
     cpu = None
-    if rank == 0 and not use_dist and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline and not (a.phantom > 1):
+        # rank 0 at every N (the other ranks wait at the final barrier): the same bounded sample of the per-GPU workload
         cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
         cpu["cpu_model"] = cpu_model()
         cpu["joinCpu"] = join_cpu_baseline(hj, torch, dev, cpu["cores"])
@@ -830,10 +936,15 @@ def main():
             "metric": ("billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)
                        if world == 1 else
                        "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform per GPU, %d GPUs" % (a.log2n, a.log2n, world))
-                      + (" [PLUMBING RUN over gloo on ONE GPU: not a measurement]" if backend == "gloo" else ""),
+                      + (" [PLUMBING RUN over gloo on ONE GPU: not a measurement]" if backend == "gloo" else "")
+                      + (" [PHANTOM: ONE GPU running the local stages in the shape of a %d-GPU job, nothing crosses a link; value = this "
+                         "GPU's local work only, the modelled step is dist.model: not a measurement of the metric]" % a.phantom
+                         if (use_dist and world == 1 and a.phantom > 1) else "")
+                      + (" [multi-GPU code path forced at world size 1: not the headline]" if (use_dist and world == 1 and a.phantom <= 1) else ""),
             # not a measurement: the gloo plumbing mode, and any N > 1 line produced by the torch.distributed FALLBACK driver when
             # hj_dist was asked for (a communicator could not be made): a scaling number from it must not pass for hj_dist's
-            "is_measurement": backend != "gloo" and not (use_dist and a.dist_impl == "c" and not c_impl and backend != "gloo" and a.balance == "hash"),
+            "is_measurement": backend != "gloo" and not (use_dist and a.dist_impl == "c" and not c_impl and backend != "gloo" and a.balance == "hash")
+                              and not (use_dist and world == 1 and a.phantom > 1),
             "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -843,7 +954,8 @@ def main():
                                     "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
                        "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
                        "partition_layout_R_S": layout, "matches": int(got)},
-            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat, "config2_as_stated": as_stated,
+            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat if not use_dist else dist_mat,
+            "strong_scaling": strong, "config2_as_stated": as_stated,
             "cpu_baseline": cpu, "dist": dist_info, "lib_sha256": lib_sha256(),
             "timing": "value/ms_per_step: %d steps with no kernel events (library default); kernels/roofline/probe_phase: %d "
                       "further steps with HIP events around the data-moving kernels" % (a.steps, isteps),

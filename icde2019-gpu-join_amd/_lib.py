@@ -37,7 +37,7 @@ class Args(C.Structure):  # include/hj_reference_abi.h  (src/common-host.h:39-52
 
 class DistConfig(C.Structure):  # include/hj_dist.h
     _fields_ = [("slices", C.c_uint32), ("exact_only", C.c_uint32), ("self_via_link", C.c_uint32), ("phantom_world", C.c_uint32),
-                ("single_group", C.c_uint32), ("balance_size", C.c_uint32), ("timeout_ms", C.c_uint32), ("test_stall_rank", C.c_uint32)]
+                ("single_group", C.c_uint32), ("balance_size", C.c_uint32), ("timeout_ms", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DistStats(C.Structure):
@@ -45,7 +45,8 @@ class DistStats(C.Structure):
                 ("slices", C.c_uint32), ("spans_per_slice", C.c_uint32), ("slot_capacity", C.c_uint32 * 2),
                 ("split_ms", C.c_float * 2), ("pass1_ms", C.c_float * 2), ("pass2_join_ms", C.c_float),
                 ("first_split_ms", C.c_float), ("last_pass1_ms", C.c_float), ("wall_ms", C.c_float), ("early_pass2_join_ms", C.c_float), ("probe_groups", C.c_uint32),
-                ("balanced", C.c_uint32), ("exchange_ms", C.c_float), ("reserved", C.c_uint32 * 4)]
+                ("balanced", C.c_uint32), ("exchange_ms", C.c_float), ("materializing", C.c_uint32), ("materialized", C.c_uint64),
+                ("reserved", C.c_uint32 * 1)]
 
 
 class LastResult(C.Structure):
@@ -118,6 +119,8 @@ SIGNATURES = {
     "hj_dist_configure": (C.c_int, [vp, C.POINTER(DistConfig)]),
     "hj_dist_bind": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_uint64]),
     "hj_dist_join": (C.c_int, [vp, u64p, u64p]),
+    "hj_dist_bind_output": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint64]),
+    "hj_dist_join_materialize": (C.c_int, [vp, u64p, u64p, u64p]),
     "hj_dist_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(DistStats)]),
     "hj_dist_unique_id": (C.c_int, [vp]),
     "hj_dist_rank_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, vp]),
@@ -125,6 +128,7 @@ SIGNATURES = {
     "hj_dist_rank_error": (C.c_char_p, [vp]),
     "hj_dist_rank_configure": (C.c_int, [vp, C.POINTER(DistConfig)]),
     "hj_dist_rank_join": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, u64p, u64p]),
+    "hj_dist_rank_join_materialize": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p, u64p, u64p, u64p]),
     "hj_dist_rank_get_stats": (C.c_int, [vp, C.POINTER(DistStats)]),
     "hashJoinClusteredProbe": (C.c_uint, [C.POINTER(Args), vp]),
     "hj_reference_last_result": (None, [C.POINTER(LastResult)]),

@@ -199,11 +199,20 @@ CpuJoin cpu_join(const int32_t *R, uint64_t nR, const int32_t *S, uint64_t nS) {
 // 1/N of R and of S (contiguous slices of the host columns, uploaded untimed like hjcp.cu:874-879), and hj_dist_join does
 // the rest in C++: level-0 split on the GPUs, sliced all-to-all over xGMI (RCCL), local passes + build/probe, all-reduce.
 // Fewer than N visible GPUs: refused (non-zero), nothing is emulated on the host.
-struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = 0; std::string transport, path; hj_dist_stats st{}; };
+// The reference's lead timed run writes its output (hjcp.cu:913, 937-940; per level-0 partition in the co-processing analogue,
+// hjcp.cu:1503-1618): with N GPUs every GPU writes the (key, payR, payS) tuples of the partitions it owns into its own columns
+// (hj_dist_join_materialize).  The columns are sized from the count run (+10 %); a rank whose share does not fit reports its size
+// with HJ_ECAPACITY and the run is repeated with exact sizes.
+struct MultiResult { unsigned long long matches = 0, agg = 0, materialized = 0; double seconds = 0, mat_seconds = 0; int status = 0; std::string transport, path, mat_path; hj_dist_stats st{}, mat_st{}; std::vector<uint64_t> n_out; };
 MultiResult multi_gpu_join(const args &ja, int gpus, const char *transport) {
     MultiResult out;
     hj_dist *d = nullptr;
-    out.status = hj_dist_create_transport(&d, gpus, nullptr, transport);
+    // $HJ_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank on device 0 over the in-process device-copy transport — the whole
+    // pipeline and this transcript, no link involved; said so on stdout
+    std::vector<int> share((size_t)gpus, 0);
+    const bool shared = getenv("HJ_BENCH_SHARE_GPU") && atoi(getenv("HJ_BENCH_SHARE_GPU"));
+    if (shared) printf("TEST MODE: %d ranks share GPU 0 (HJ_BENCH_SHARE_GPU): not a measurement\n", gpus);
+    out.status = hj_dist_create_transport(&d, gpus, shared ? share.data() : nullptr, shared ? nullptr : transport);
     if (out.status) { fprintf(stderr, "GPU Error: --gpus %d%s%s: hj_dist_create_transport failed (code %d): fewer GPUs visible than ranks, no GPU, or a transport these devices do not allow\n", gpus, transport ? " --transport " : "", transport ? transport : "", out.status); return out; }
     out.transport = hj_dist_transport(d);
     std::vector<void *> bufs;
@@ -234,6 +243,37 @@ MultiResult multi_gpu_join(const args &ja, int gpus, const char *transport) {
         if (out.status) fprintf(stderr, "GPU Error: %s (code %d)\n", hj_dist_error(d), out.status);
         else { hj_dist_get_stats(d, 0, &out.st); out.path = out.st.path ? "exact" : "sliced"; }
     }
+    // the materialising run (timed like the count run: one warm-up, one timed call)
+    std::vector<std::vector<void *>> outs((size_t)gpus);
+    if (!out.status) {
+        std::vector<uint64_t> cap((size_t)gpus, out.matches / (uint64_t)gpus + out.matches / (uint64_t)(10 * gpus) + 4096), n_out((size_t)gpus, 0);
+        for (int attempt = 0; attempt < 2 && !out.status; attempt++) {
+            for (int g = 0; g < gpus && !out.status; g++) {
+                hj_ctx *c = hj_dist_context(d, g);
+                for (void *p : outs[g]) hj_device_free(c, p);
+                outs[g].assign(3, nullptr);
+                for (int j = 0; j < 3 && !out.status; j++) out.status = hj_device_malloc(c, &outs[g][j], (cap[g] + 16) * 4);
+                if (!out.status) out.status = hj_dist_bind_output(d, g, (int32_t *)outs[g][0], (int32_t *)outs[g][1], (int32_t *)outs[g][2], cap[g]);
+                if (out.status) fprintf(stderr, "GPU Error: device %d: output columns of %llu tuples: %s (code %d)\n", g, (unsigned long long)cap[g], hj_error(c), out.status);
+            }
+            if (out.status) break;
+            uint64_t m = 0;
+            int rc = hj_dist_join_materialize(d, &m, nullptr, n_out.data()); // warm-up (first touch of the output columns)
+            if (rc == HJ_ECAPACITY && attempt == 0) { for (int g = 0; g < gpus; g++) cap[g] = n_out[g] + 16; continue; }
+            const double t0 = now_s();
+            if (!rc) rc = hj_dist_join_materialize(d, &m, nullptr, n_out.data());
+            out.mat_seconds = now_s() - t0;
+            out.status = rc;
+            if (rc) { fprintf(stderr, "GPU Error: %s (code %d)\n", hj_dist_error(d), rc); break; }
+            if (m != out.matches) { fprintf(stderr, "GPU Error: the materialising join produced %llu tuples, the count join %llu\n", (unsigned long long)m, out.matches); out.status = HJ_EHIP; break; }
+            out.n_out = n_out;
+            for (uint64_t v : n_out) out.materialized += v;
+            hj_dist_get_stats(d, 0, &out.mat_st); out.mat_path = out.mat_st.path ? "exact" : "sliced";
+            break;
+        }
+    }
+    for (int g = 0; g < gpus; g++)
+        for (void *p : outs[g]) if (p) hj_device_free(hj_dist_context(d, g), p);
     for (int g = 0, i = 0; g < gpus; g++)
         for (int j = 0; j < 4 && i < (int)bufs.size(); j++, i++) hj_device_free(hj_dist_context(d, g), bufs[i]);
     hj_dist_destroy(d);
@@ -241,7 +281,7 @@ MultiResult multi_gpu_join(const args &ja, int gpus, const char *transport) {
 }
 #else
 struct MultiStats { float exchange_ms = 0; unsigned long long link_bytes = 0; };
-struct MultiResult { unsigned long long matches = 0, agg = 0; double seconds = 0; int status = HJ_EHIP; std::string transport, path; MultiStats st; };
+struct MultiResult { unsigned long long matches = 0, agg = 0, materialized = 0; double seconds = 0, mat_seconds = 0; int status = HJ_EHIP; std::string transport, path, mat_path; MultiStats st, mat_st; std::vector<uint64_t> n_out; };
 MultiResult multi_gpu_join(const args &, int, const char *) { return MultiResult(); }
 #endif
 
@@ -372,6 +412,15 @@ int main(int argc, char **argv) {
         status = multi.status ? 10 : 0;
         if (!multi.status) {
             const double bytes = 2.0 * (double)(ja.R_els + ja.S_els) * sizeof(int);
+            // the reference's transcript (hjcp.cu:937-940, 986-991): the materialising run first, then the count-only one
+            printf("With materialization\n");
+            printf("Exchange: %s, %s path\n", multi.transport.c_str(), multi.mat_path.c_str());
+            printf("Total Throughput (%d GPUs) %f\n", in.gpus, bytes / multi.mat_seconds / 1000 / 1000);
+            printf("Output (sharded, one share per GPU):");
+            for (size_t g = 0; g < multi.n_out.size(); g++) printf(" %llu", (unsigned long long)multi.n_out[g]);
+            printf(" tuples\n");
+            printf("%llu results\n", multi.materialized);
+            printf("Without materialization\n");
             printf("Exchange: %s, %s path\n", multi.transport.c_str(), multi.path.c_str());
             if (multi.st.exchange_ms > 0) // what ONE link direction sustained while the exchange ran, against its 76.8 GB/s
                 printf("Links: %.2f GB to each peer in %.2f ms of exchange = %.1f GB/s per link direction (xGMI: 76.8)\n",
@@ -380,6 +429,7 @@ int main(int argc, char **argv) {
             printf("%llu results\n", multi.agg);
         }
         res.matches = multi.matches; res.agg = multi.agg; res.status = multi.status; res.join_ms[1] = multi.seconds * 1e3;
+        res.materialized = multi.materialized; res.join_ms[0] = multi.mat_seconds * 1e3;
     } else
     if (in.option == 7) { // main.cu:264-298
         ja.sharedMem = (unsigned)in.shared_mem;

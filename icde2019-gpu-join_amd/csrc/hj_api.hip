@@ -566,6 +566,7 @@ int partition_rel(hj_ctx *c, int r) {
     R.fast_tried = false;
     R.flag_known_good = false;
     R.part_off = nullptr;
+    R.n_bound = 0;
     R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
     // known to be skewed: the sampled path — on either side of the join since round 4 (a build partition that is a list of ranges
     // is built into the LDS table piece by piece: general items, plan_join).  Up to 17 radix bits: at 16 (2^28 x 2^31 Zipf) it takes
@@ -682,7 +683,8 @@ int exact_for_introspection(hj_ctx *c, Rel &R) {
 // work-item list of the current partitions: k_join_plan + scan + k_join_expand (decompose_chains, jp.cu:843-874)
 // gen_ok: the kernel that follows takes general items (the count kernel and the one-probe materialiser do; the late-materialising
 // kernel does not: a sampled build side is redone with the exact passes for it)
-int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok) {
+// keep_cursor: the planning kernel leaves the materialiser's output cursor alone (a second probe-side group appends to the first's output)
+int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cursor) {
     c->join_planned = false;
     Rel &B = c->rel[c->build], &Pb = c->rel[1 - c->build];
     if (!B.partitioned || !Pb.partitioned) return fail(c, HJ_EINVAL, "both relations must be partitioned before the join");
@@ -711,7 +713,8 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok) {
     // the table stores full keys.  (Round 3 also built 16-bit tags at 14 / 15 radix bits, the extra key bits folded into the bucket
     // index: parity-green, measured no faster than full keys, removed — profiles/r3_tag_extra_ab.txt.)
     tag16 = rbits >= 16 && c->nh >= 16;
-    const uint64_t max_items64 = (uint64_t)Pb.nranges + Pb.n / c->chunk + 1 + (general ? (uint64_t)B.nranges + B.n / c->chunk + 1 : 0); // flipped partitions are cut on the build relation
+    const uint64_t held_b = B.n_bound ? B.n_bound : B.n, held_p = Pb.n_bound ? Pb.n_bound : Pb.n; // (multi-GPU: what this rank can hold, not the nominal size)
+    const uint64_t max_items64 = (uint64_t)Pb.nranges + held_p / c->chunk + 1 + (general ? (uint64_t)B.nranges + held_b / c->chunk + 1 : 0); // flipped partitions are cut on the build relation
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
     c->max_items = (uint32_t)max_items64;
     RET(ensure(c, c->items_cnt, (size_t)nparts * 4));
@@ -742,11 +745,12 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok) {
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
     if (nparts <= 16384 && !Pb.sampled && !general) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
         Timed t(c, "k_join_plan");
-        HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, sc + 10, sc + 0));
+        HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, zero_cursor, sc + 0));
     } else {
-    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1, sc + 10)); }
+    { Timed t(c, "k_join_plan"); HIPCHK(c, launch_join_plan(st, a, nparts, (uint32_t *)c->items_cnt.p, sc + 1, zero_cursor)); }
     { Timed t(c, "k_scan"); HIPCHK(c, launch_scan_u32(st, (uint32_t *)c->items_cnt.p, nullptr, nparts, nparts, (uint64_t *)c->jchunk_sums.p,
                                                       (uint64_t *)c->jchunk_prefix.p, sc + 0)); }
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
@@ -833,6 +837,21 @@ int hj_join_count_enqueue(hj_ctx *c) {
     JoinArgs a;
     bool tag16;
     return run_count(c, a, tag16);
+}
+
+int hj_join_materialize_enqueue(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, bool keep_cursor) {
+    JoinArgs a;
+    bool tag16;
+    RET(plan_join(c, a, tag16, true, keep_cursor));
+    a.out_key = d_key;
+    a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
+    a.out_ppay = c->build == HJ_REL_R ? d_payS : d_payR;
+    a.out_cap = cap;
+    const size_t lds = join_mat_lds_bytes(a.nh, a.cap, tag16);
+    if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
+    { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join_mat_reg(c->stream, a, c->max_items, tag16)); }
+    c->join_planned = false;
+    return 0;
 }
 
 void drop_graph(hj_ctx *c) {
@@ -1026,10 +1045,10 @@ int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
 
 } // extern "C"
 
-namespace {
+namespace hjx {
 
 // ONE probe: plan the work items, k_join_mat_reg finds, reserves and writes; the cursor comes back with the result block
-int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
     for (int attempt = 0; attempt < 3; attempt++) {
         JoinArgs a;
         bool tag16;
@@ -1058,7 +1077,7 @@ int materialize_one_probe(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d
     return 0;
 }
 
-} // namespace
+} // namespace hjx
 
 extern "C" {
 
@@ -1067,7 +1086,7 @@ int hj_join_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_p
     if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t n = 0;
-    RET(materialize_one_probe(c, d_key, d_payR, d_payS, cap, &n));
+    RET(materialize_local(c, d_key, d_payR, d_payS, cap, &n));
     if (n_out) *n_out = n;
     if (n > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu", (unsigned long long)n, (unsigned long long)cap);
     return HJ_OK;

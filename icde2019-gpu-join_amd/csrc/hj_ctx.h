@@ -29,6 +29,8 @@ struct Buf {
 struct Rel {
     const int32_t *in_k = nullptr, *in_p = nullptr; // input columns (caller's or own_*)
     uint64_t n = 0;
+    uint64_t n_bound = 0;     // multi-GPU sliced path: upper bound of the tuples the CURRENT partitions can hold (sizes the work-item list;
+                              // 0 = n).  n itself stays the nominal size the radix bits and the build side were chosen from.
     bool bound = false;
     Buf own_k, own_p;         // hj_load_host copies
     Buf a_k, a_p, b_k, b_p;   // pass-1 / final partitioned columns
@@ -148,12 +150,18 @@ hipEvent_t get_event(hj_ctx *c);
 void resolve_completed(hj_ctx *c);
 int hj_join_count_noretry(hj_ctx *c, uint64_t *matches, uint64_t *agg);
 int hj_join_count_enqueue(hj_ctx *c);
+// the one-probe materialiser without any host read (hj_dist.hip: a probe-side group joined under the exchange): items planned, kernel
+// enqueued, the output cursor (scalars[10]) keeps counting across calls when keep_cursor is set
+int hj_join_materialize_enqueue(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, bool keep_cursor);
+// plan + one probe + read-back with the local redo of overflowed relations; *n_out may exceed cap (nothing beyond cap is written):
+// the caller decides what that means (hj_join_materialize: HJ_ECAPACITY; hj_dist: every rank learns it first)
+int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out);
 void hj_invalidate_all(hj_ctx *c);
 void drop_graph(hj_ctx *c);
 // (hj_stream.hip: the host-memory paths drive the same partition / plan / join steps)
 int partition_rel(hj_ctx *c, int r);
 int resolve_layout(hj_ctx *c, hj_ctx::Rel &R);
-int plan_join(hj_ctx *c, hj::JoinArgs &a_out, bool &tag16, bool gen_ok = true);
+int plan_join(hj_ctx *c, hj::JoinArgs &a_out, bool &tag16, bool gen_ok = true, bool keep_cursor = false);
 
 // RAII: HIP events on a stream around one kernel launch (per-kernel statistics, hj_timings)
 struct Timed {

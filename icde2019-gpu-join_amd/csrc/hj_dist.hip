@@ -23,6 +23,11 @@
 //   rank then repeats the join on the exact path.
 // Exact path: exact split (histogram + scatter), counts to the host, all-gather of the counts, messages of exact size,
 //   local partition + join (what dist.py did from Python in rounds 1-2).
+// Materialising join (round 5; north_star "join output = match count AND materialised tuples" x SURVEY §8(e) "Output: stays
+//   sharded"): the same two paths with the one-probe materialiser in place of the count kernel — every rank writes the
+//   (key, payR, payS) tuples of the partitions it owns into ITS caller-provided device columns (the earlier probe-side group under the
+//   exchange, the last group appending behind it on one output cursor), the per-rank output sizes are all-gathered, the global
+//   count all-reduced with the flags.  Reference: join_partitioned_results per level-0 partition, hjcp.cu:1503-1618, jp.cu:1107-1416.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -309,6 +314,16 @@ struct CopyLink : Link {
 
 } // namespace
 
+// The materialising join's output: this rank's caller-provided device columns (the tuples of the partitions it owns) — SURVEY
+// §8(e) "Output: stays sharded"; join_partitioned_results writes (payR, payS) per level-0 partition in the co-processing analogue,
+// hjcp.cu:1503-1618, jp.cu:1107-1416.
+struct MatOut {
+    int32_t *key = nullptr, *payR = nullptr, *payS = nullptr;
+    uint64_t cap = 0;
+    bool want_agg = false;
+    uint64_t n_out = 0; // result: tuples this rank produced (may exceed cap: nothing beyond cap was written)
+};
+
 // ================================================================================================
 // one rank
 // ================================================================================================
@@ -339,6 +354,9 @@ struct hj_dist_rank {
     std::vector<hipEvent_t> ev_split, ev_xchg, ev_t; // per (relation, slice); timing events
     hipEvent_t ev_misc[4] = {}, ev_coll[2] = {};
     hj_ctx::Buf x_send_k[2], x_send_p[2], x_recv_k[2], x_recv_p[2], x_counts, x_bal; // exact path
+    // the geometry the ranks last AGREED they could allocate for (grow-only buffers: the same geometry needs no second agreement)
+    uint64_t agreed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint64_t> n_out_all; // materialising join: output tuples of every rank (all-gathered)
 
     int fail(int code, const char *fmt, ...) {
         char buf[600];
@@ -443,7 +461,13 @@ int rank_init(hj_dist_rank *r) {
 void rank_free(hj_dist_rank *r) {
     if (!r) return;
     if (r->c) (void)hipSetDevice(r->c->device);
-    if (r->comm && !(r->link && r->link->failed(nullptr))) (void)hipStreamSynchronize(r->comm); // never behind a collective that was given up
+    // A group that failed (deadline, peer gone) may still have a collective kernel stuck on the communication stream: hipFree
+    // synchronises the whole device and hipStreamDestroy the stream, so both would block behind it for ever.  The link goes first —
+    // its destructor is what reaches ncclCommAbort, which takes the stuck kernel off the device — and only then the buffers, events
+    // and streams.  A healthy group drains its stream and frees in the usual order (the communicator is destroyed behind it).
+    const bool failed = r->link && r->link->failed(nullptr);
+    if (failed) r->link.reset();
+    else if (r->comm) (void)hipStreamSynchronize(r->comm);
     for (int x = 0; x < 2; x++) {
         release(r->send_k[x]); release(r->send_p[x]); release(r->recv_k[x]); release(r->recv_p[x]);
         release(r->s_beg[x]); release(r->s_end[x]); release(r->r_end[x]); release(r->seg_beg[x]); release(r->seg_end[x]);
@@ -499,6 +523,32 @@ int agree(hj_dist_rank *r, int local_rc, const char *phase) {
     return 0;
 }
 
+// Materialising join: every rank learns every rank's output size (and whether it fitted its owner's columns): one all-gather of
+// {n_out, cap} per rank on the communication stream, read by the host.  [sync, with the deadline]
+int gather_outputs(hj_dist_rank *r, MatOut *mat) {
+    hj_ctx *c = r->c;
+    uint64_t *small = (uint64_t *)r->small.p; // [24..25] mine, [512 .. 512 + 2 * world) everybody's
+    r->h_small[24] = mat->n_out; r->h_small[25] = mat->cap;
+    DCHK(r, hipMemcpyAsync(small + 24, r->h_small + 24, 16, hipMemcpyHostToDevice, c->stream));
+    LRET(r, coll_begin(r));
+    LRET(r, r->link->allgather(small + 24, small + 512, 16, r->comm, r->err));
+    LRET(r, coll_end(r));
+    DCHK(r, hipMemcpyAsync(r->h_small + 512, small + 512, (size_t)r->world * 16, hipMemcpyDeviceToHost, c->stream));
+    r->stage = "all-gather of the output sizes"; r->stage_rel = -1; r->stage_slice = -1;
+    LRET(r, wait_stream(r, c->stream, "the all-gather of the ranks' output sizes (materialising join)"));
+    LRET(r, wait_stream(r, r->comm, "the communication stream after the all-gather of the output sizes"));
+    r->n_out_all.assign((size_t)r->world, 0);
+    std::string over;
+    for (int q = 0; q < r->world; q++) {
+        r->n_out_all[q] = r->h_small[512 + 2 * q];
+        if (r->h_small[512 + 2 * q] > r->h_small[512 + 2 * q + 1])
+            over += (over.empty() ? "rank " : ", rank ") + std::to_string(q) + ": " + std::to_string(r->h_small[512 + 2 * q]) + " tuples for a capacity of " + std::to_string(r->h_small[512 + 2 * q + 1]);
+    }
+    r->st.materialized = mat->n_out;
+    if (!over.empty()) return r->fail(HJ_ECAPACITY, "materialised output does not fit its owner's columns (%s): nothing beyond a capacity was written", over.c_str());
+    return 0;
+}
+
 // Geometry of the sliced exchange of one relation: a function of (n_max over the ranks, G, K) and the radix bits only —
 // identical on every rank, which is what makes the message sizes known without asking anybody.
 struct SliceGeom {
@@ -537,8 +587,11 @@ bool plan_slices(uint64_t nmax, uint32_t G, uint32_t Kwant, uint32_t P1, uint32_
 float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f; }
 
 // ---- the sliced fixed-size pipeline.  Returns 0 with *flagged set when some slot overflowed somewhere (result void). ----
+// mat != nullptr: the materialising join — every probe-side group is joined by the one-probe materialiser into this rank's output
+// columns (the earlier group under the exchange, as it is counted otherwise); out[0] = global matches, out[1] = global aggregate (0
+// unless mat->want_agg), the per-rank output sizes are all-gathered into r->n_out_all.
 int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], const uint64_t nmax[2], uint64_t out[2], bool *flagged,
-              bool *applicable) {
+              bool *applicable, MatOut *mat) {
     hj_ctx *c = r->c;
     const bool phantom = r->world == 1 && r->cfg.phantom_world > 1; // one-GPU measurement mode: the shape of a G-GPU job
     const uint32_t G = phantom ? r->cfg.phantom_world : (uint32_t)r->world, me = (uint32_t)r->rank;
@@ -628,7 +681,17 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         for (const Want &w : wants) LRET(r, dist_ensure(r, *w.b, w.bytes));
         return 0;
     };
-    LRET(r, agree(r, prepare(), "preparing the sliced exchange (memory budget, buffers)"));
+    {   // The agreement is a host-synchronous round trip in front of the first split; buffers only grow, so a geometry the ranks have
+        // agreed on once needs no second agreement (every rank sees the same sequence of geometries: they derive from all-gathered sizes).
+        const uint64_t key[8] = {nmax[0], nmax[1], G, g[0].K, g[1].K, ((uint64_t)b1 << 32) | b2, (uint64_t)grp[0].size() | ((uint64_t)grp[1].size() << 8), 1};
+        if (memcmp(key, r->agreed, sizeof key)) {
+            memset(r->agreed, 0, sizeof r->agreed);
+            LRET(r, agree(r, prepare(), "preparing the sliced exchange (memory budget, buffers)"));
+            memcpy(r->agreed, key, sizeof key);
+        } else {
+            LRET(r, prepare());
+        }
+    }
     r->cur_maxK = maxK; r->cur_K[0] = g[0].K; r->cur_K[1] = g[1].K;
     r->enq.assign(4 * (size_t)maxK, 0); // which of this join's split / exchange events have been recorded (an older record reads "done")
     // flags of both relations down, received counters and the per-group results zero
@@ -663,8 +726,10 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     auto exchange = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
         r->stage = "exchange"; r->stage_rel = x; r->stage_slice = (int)i;
-        if (r->cfg.test_stall_rank == (uint32_t)r->rank + 1 && x == second && i == 0) // test hook: this rank stops taking part for longer than the deadline
-            std::this_thread::sleep_for(std::chrono::duration<double>(r->timeout_s * 2.5 + 0.2));
+        if (x == second && i == 0) { // test hook ($HJ_DIST_TEST_STALL_RANK = rank + 1): this rank stops taking part for longer than the deadline
+            const char *e = getenv("HJ_DIST_TEST_STALL_RANK");
+            if (e && atoi(e) == r->rank + 1) std::this_thread::sleep_for(std::chrono::duration<double>(r->timeout_s * 2.5 + 0.2));
+        }
         DCHK(r, hipStreamWaitEvent(ms, r->ev_split[x * maxK + i], 0));
         if (!xchg_started) { DCHK(r, hipEventRecord(r->ev_t[4 * 2 * maxK + 6], ms)); xchg_started = true; } // the links are busy from here ...
         const uint64_t base = (uint64_t)i * G * q.region;
@@ -739,13 +804,19 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         R.n_alloc = gr.sizeB;
         R.pb1 = b1; R.pb2 = b2;
         R.partitioned = true; R.fast_tried = true; R.flag_known_good = false;
-        R.n = (uint64_t)(gr.s1 - gr.s0) * G * q.region; // upper bound of what this rank can hold here (sizes the work-item list)
+        R.n_bound = (uint64_t)(gr.s1 - gr.s0) * G * q.region; // upper bound of what this rank can hold here (sizes the work-item list; R.n stays nominal)
         return 0;
     };
     hipEvent_t t_tail0 = r->ev_t[4 * 2 * maxK + 0], t_tail1 = r->ev_t[4 * 2 * maxK + 1];
     uint32_t joined = 0, early_mask = 0;
     // build + probe of one probe-side group against the build side; the result is parked on the device (no host read here)
     auto join_group = [&]() -> int {
+        if (mat) { // ONE probe that writes: the second group appends behind the first (the cursor is zeroed by the first group's plan only)
+            int rc = hj_join_materialize_enqueue(c, mat->key, mat->payR, mat->payS, mat->cap, joined > 0);
+            if (rc) { r->err = hj_error(c); return rc; }
+            joined++;
+            return 0;
+        }
         int rc = hj_join_count_enqueue(c);
         if (rc) { r->err = hj_error(c); return rc; }
         DCHK(r, hipMemcpyAsync(small + 20 + 2 * joined, sc + 1, 16, hipMemcpyDeviceToDevice, cs));
@@ -779,11 +850,16 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     LRET(r, pass1(order.back().x, order.back().i));
     LRET(r, after_pass1(order.back().x, order.back().i));
     // the per-group results and, with the result block, the flags of this rank's kernels; [sync]
+    if (mat && mat->want_agg) { // sum payR * payS over what was written (the cursor is on the device: k_dot reads it there)
+        DCHK(r, hipMemsetAsync(sc + 3, 0, 8, cs));
+        DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + 10, mat->cap, sc + 3));
+    }
     DCHK(r, hipMemcpyAsync(r->h_small + 16, small + 20, 32, hipMemcpyDeviceToHost, cs));
     r->stage = "pipeline drained"; r->stage_rel = -1; r->stage_slice = -1;
     LRET(r, wait_stream(r, cs, "the sliced pipeline (splits, exchanges, local passes, joins)")); // every exchange is behind this: the deadline, not a blocking sync
     if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
     uint64_t m = r->h_small[16] + r->h_small[18], a = r->h_small[17] + r->h_small[19];
+    if (mat) { m = c->h_scalars[10]; a = mat->want_agg ? c->h_scalars[3] : 0; mat->n_out = m; } // the output cursor = this rank's matches
     // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
     r->h_small[0] = m; r->h_small[1] = a; r->h_small[2] = c->h_scalars[8] & 0xFFFFFFFFu; r->h_small[3] = c->h_scalars[9] & 0xFFFFFFFFu;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 32, hipMemcpyHostToDevice, cs));
@@ -796,6 +872,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     LRET(r, wait_stream(r, ms, "the communication stream after the all-reduce"));
     out[0] = r->h_small[8]; out[1] = r->h_small[9];
     *flagged = (r->h_small[10] | r->h_small[11]) != 0;
+    if (mat && !*flagged) LRET(r, gather_outputs(r, mat));
     r->st.received[0] = r->h_small[12]; r->st.received[1] = r->h_small[13];
     // tuple bytes among the link bytes: what this rank sent to others = its local tuples minus the ones it kept (phantom world: the
     // shards other than shard 0 of what it holds)
@@ -822,7 +899,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
 }
 
 // ---- exact-count exchange: exact split, counts read by the host, messages of exact size, standard local path ----
-int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], uint64_t out[2], bool balance) {
+int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2], uint64_t out[2], bool balance, MatOut *mat) {
     hj_ctx *c = r->c;
     const uint32_t G = (uint32_t)r->world, me = (uint32_t)r->rank;
     hipStream_t cs = c->stream, ms = r->comm;
@@ -933,7 +1010,19 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     LRET(r, wait_stream(r, ms, "the exact-size exchange (grouped send/recv of both relations)")); // hj_join_count synchronises: the deadline first
     LRET(r, wait_stream(r, cs, "the local partition passes behind the exact exchange"));
     uint64_t m = 0, a = 0;
-    DRET(r, hj_join_count(c, &m, &a));
+    if (mat) { // what arrived is local from here on: the one-probe materialiser with its own redo of a skewed relation
+        DRET(r, materialize_local(c, mat->key, mat->payR, mat->payS, mat->cap, &m));
+        mat->n_out = m;
+        if (mat->want_agg) {
+            uint64_t *sc = (uint64_t *)c->scalars.p;
+            DCHK(r, hipMemsetAsync(sc + 3, 0, 8, cs));
+            DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + 10, mat->cap, sc + 3));
+            if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
+            a = c->h_scalars[3];
+        }
+    } else {
+        DRET(r, hj_join_count(c, &m, &a));
+    }
     r->h_small[0] = m; r->h_small[1] = a;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 16, hipMemcpyHostToDevice, cs));
     LRET(r, coll_begin(r));
@@ -944,6 +1033,7 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
     LRET(r, wait_stream(r, cs, "the all-reduce of the result"));
     LRET(r, wait_stream(r, ms, "the communication stream after the all-reduce"));
     out[0] = r->h_small[8]; out[1] = r->h_small[9];
+    if (mat) LRET(r, gather_outputs(r, mat));
     r->st.received[0] = recv_tot[0]; r->st.received[1] = recv_tot[1];
     r->st.path = 1; r->st.slices = 1; r->st.balanced = balance ? 1 : 0; r->st.exchange_ms = 0;
     r->st.payload_bytes = r->st.link_bytes;
@@ -951,13 +1041,13 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
 }
 
 int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
-                    uint64_t *matches, uint64_t *agg);
+                    uint64_t *matches, uint64_t *agg, MatOut *mat);
 
 // A rank that fails for any reason aborts its group on the way out: peers inside (or on their way into) a collective then leave
 // with an error that names this rank, instead of waiting for the deadline — or, in the reference's terms, instead of the
 // print-and-exit of CHK_ERROR (common.h:132-141) taking one process down while the others hang.
 int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
-              uint64_t *matches, uint64_t *agg) {
+              uint64_t *matches, uint64_t *agg, MatOut *mat = nullptr) {
     r->err.clear();
     r->cur_maxK = 0;
     r->timeout_s = r->cfg.timeout_ms ? r->cfg.timeout_ms * 1e-3 : env_timeout_s();
@@ -965,7 +1055,9 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
         std::string why;
         if (r->link->failed(&why)) return r->fail(HJ_EHIP, "rank %d: the group was aborted by an earlier failure (%s): create a new one", r->rank, why.c_str());
     }
-    const int rc = rank_join_inner(r, Rk, Rp, nR, Sk, Sp, nS, matches, agg);
+    r->st.materializing = mat ? 1u : 0u; r->st.materialized = 0;
+    const int rc = rank_join_inner(r, Rk, Rp, nR, Sk, Sp, nS, matches, agg, mat);
+    if (rc == HJ_ECAPACITY && mat) { r->stage = "idle"; return rc; } // every rank saw the same all-gathered sizes: an answer, not a failure of the group
     if (rc) {
         if (r->err.empty()) r->err = hj_error(r->c);
         r->link->abort("rank " + std::to_string(r->rank) + " failed: " + r->err);
@@ -976,9 +1068,10 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
 }
 
 int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
-                    uint64_t *matches, uint64_t *agg) {
+                    uint64_t *matches, uint64_t *agg, MatOut *mat) {
     hj_ctx *c = r->c;
     if ((nR && (!Rk || !Rp)) || (nS && (!Sk || !Sp))) return r->fail(HJ_EINVAL, "null column");
+    if (mat && mat->cap && (!mat->key || !mat->payR || !mat->payS)) return r->fail(HJ_EINVAL, "output columns == NULL");
     if ((((uintptr_t)Rk | (uintptr_t)Rp | (uintptr_t)Sk | (uintptr_t)Sp) & 15)) return r->fail(HJ_EINVAL, "device columns must be 16-byte aligned");
     DCHK(r, hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
@@ -1010,14 +1103,16 @@ int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint6
     bool done = false;
     if (!exact) {
         bool flagged = false, applicable = false;
-        rc = join_fast(r, cols, n, nmax, out, &flagged, &applicable);
+        rc = join_fast(r, cols, n, nmax, out, &flagged, &applicable, mat);
+        if (rc == HJ_ECAPACITY && mat) { if (matches) *matches = out[0]; if (agg) *agg = out[1]; }
         if (rc) return rc;
         if (applicable && !flagged) done = true;
         if (flagged) { r->prefer_exact = true; balance = true; } // every rank saw the same summed flags: everybody goes exact together
     }
     if (!done) {
         hj_invalidate_all(c);
-        rc = join_exact(r, cols, n, out, balance && r->world > 1);
+        rc = join_exact(r, cols, n, out, balance && r->world > 1, mat);
+        if (rc == HJ_ECAPACITY && mat) { if (matches) *matches = out[0]; if (agg) *agg = out[1]; }
         if (rc) return rc;
     }
     r->st.wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1037,6 +1132,7 @@ struct hj_dist {
     std::unique_ptr<CopyGroup> copy;
     std::string err, transport;
     struct Bound { const int32_t *k = nullptr, *p = nullptr; uint64_t n = 0; } bound[64][2];
+    MatOut outb[64];
 };
 
 extern "C" {
@@ -1127,7 +1223,6 @@ int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg) {
     if (!d || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) { d->err = "at most 64 slices"; return HJ_EINVAL; }
     if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && d->world != 1)) { d->err = "phantom_world needs world size 1 and <= 512 shards"; return HJ_EINVAL; }
-    if (cfg->test_stall_rank > (uint32_t)d->world) { d->err = "test_stall_rank names no rank"; return HJ_EINVAL; }
     for (auto *k : d->ranks) k->cfg = *cfg;
     if (d->copy) { std::lock_guard<std::mutex> lk(d->copy->mu); d->copy->timeout_s = cfg->timeout_ms ? cfg->timeout_ms * 1e-3 : env_timeout_s(); }
     return HJ_OK;
@@ -1158,6 +1253,40 @@ int hj_dist_join(hj_dist *d, uint64_t *matches, uint64_t *agg) {
     if (matches) *matches = m[0];
     if (agg) *agg = a[0];
     return HJ_OK;
+}
+
+int hj_dist_bind_output(hj_dist *d, int rank, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap) {
+    if (!d || rank < 0 || rank >= d->world) return HJ_EINVAL;
+    if (cap && (!d_key || !d_payR || !d_payS)) { d->err = "output columns == NULL"; return HJ_EINVAL; }
+    MatOut &o = d->outb[rank];
+    o.key = d_key; o.payR = d_payR; o.payS = d_payS; o.cap = cap;
+    return HJ_OK;
+}
+
+int hj_dist_join_materialize(hj_dist *d, uint64_t *matches, uint64_t *agg, uint64_t *n_out) {
+    if (!d) return HJ_EINVAL;
+    std::vector<int> rc(d->world, 0);
+    std::vector<uint64_t> m(d->world, 0), a(d->world, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < d->world; r++)
+        th.emplace_back([&, r] {
+            const auto &b = d->bound[r];
+            d->outb[r].want_agg = agg != nullptr;
+            rc[r] = rank_join(d->ranks[r], b[0].k, b[0].p, b[0].n, b[1].k, b[1].p, b[1].n, &m[r], &a[r], &d->outb[r]);
+        });
+    for (auto &t : th) t.join();
+    int hard = 0, soft = 0;
+    for (int r = 0; r < d->world; r++) {
+        if (rc[r] && rc[r] != HJ_ECAPACITY && !hard) { d->err = "rank " + std::to_string(r) + ": " + d->ranks[r]->err; hard = rc[r]; }
+        if (rc[r] == HJ_ECAPACITY && !soft) { soft = rc[r]; if (!hard) d->err = d->ranks[r]->err; }
+    }
+    if (hard) return hard;
+    for (int r = 1; r < d->world; r++)
+        if (m[r] != m[0] || a[r] != a[0]) { d->err = "ranks disagree on the all-reduced result"; return HJ_EHIP; }
+    if (matches) *matches = m[0];
+    if (agg) *agg = a[0];
+    if (n_out) for (int r = 0; r < d->world; r++) n_out[r] = r < (int)d->ranks[0]->n_out_all.size() ? d->ranks[0]->n_out_all[r] : 0;
+    return soft;
 }
 
 int hj_dist_get_stats(hj_dist *d, int rank, hj_dist_stats *out) {
@@ -1229,7 +1358,6 @@ int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg) {
     if (!r || !cfg) return HJ_EINVAL;
     if (cfg->slices > 64) return r->fail(HJ_EINVAL, "at most 64 slices");
     if (cfg->phantom_world > 512 || (cfg->phantom_world > 1 && r->world != 1)) return r->fail(HJ_EINVAL, "phantom_world needs world size 1 and <= 512 shards");
-    if (cfg->test_stall_rank > (uint32_t)r->world) return r->fail(HJ_EINVAL, "test_stall_rank names no rank");
     r->cfg = *cfg;
     return HJ_OK;
 }
@@ -1238,6 +1366,19 @@ int hj_dist_rank_join(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp,
                       uint64_t nS, uint64_t *matches, uint64_t *agg) {
     if (!r) return HJ_EINVAL;
     return rank_join(r, d_Rk, d_Rp, nR, d_Sk, d_Sp, nS, matches, agg);
+}
+
+int hj_dist_rank_join_materialize(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk, const int32_t *d_Sp,
+                                  uint64_t nS, int32_t *d_out_key, int32_t *d_out_payR, int32_t *d_out_payS, uint64_t cap, uint64_t *n_out,
+                                  uint64_t *n_out_all, uint64_t *matches, uint64_t *agg) {
+    if (!r) return HJ_EINVAL;
+    MatOut o;
+    o.key = d_out_key; o.payR = d_out_payR; o.payS = d_out_payS; o.cap = cap; o.want_agg = agg != nullptr;
+    const int rc = rank_join(r, d_Rk, d_Rp, nR, d_Sk, d_Sp, nS, matches, agg, &o);
+    if (rc && rc != HJ_ECAPACITY) return rc;
+    if (n_out) *n_out = o.n_out;
+    if (n_out_all) for (int q = 0; q < r->world; q++) n_out_all[q] = q < (int)r->n_out_all.size() ? r->n_out_all[q] : 0;
+    return rc;
 }
 
 int hj_dist_rank_get_stats(hj_dist_rank *r, hj_dist_stats *out) {

@@ -234,7 +234,7 @@ def _stats_dict(s):
             "split_ms": [float(s.split_ms[0]), float(s.split_ms[1])], "pass1_ms": [float(s.pass1_ms[0]), float(s.pass1_ms[1])],
             "pass2_join_ms": float(s.pass2_join_ms), "first_split_ms": float(s.first_split_ms), "last_pass1_ms": float(s.last_pass1_ms),
             "wall_ms": float(s.wall_ms), "early_pass2_join_ms": float(s.early_pass2_join_ms), "probe_groups": int(s.probe_groups), "balanced": bool(s.balanced),
-            "exchange_ms": float(s.exchange_ms)}
+            "exchange_ms": float(s.exchange_ms), "materializing": bool(s.materializing), "materialized": int(s.materialized)}
 
 
 class GroupJoin:
@@ -289,10 +289,9 @@ class GroupJoin:
         return hj
 
     def configure(self, slices=0, exact_only=False, self_via_link=False, phantom_world=0, single_group=False, balance_size=False,
-                  timeout_ms=0, test_stall_rank=0):
+                  timeout_ms=0):
         cfg = _hjlib.DistConfig(slices=slices, exact_only=int(exact_only), self_via_link=int(self_via_link), phantom_world=phantom_world,
-                                single_group=int(single_group), balance_size=int(balance_size), timeout_ms=int(timeout_ms),
-                                test_stall_rank=int(test_stall_rank))
+                                single_group=int(single_group), balance_size=int(balance_size), timeout_ms=int(timeout_ms))
         self._ck(self._L.hj_dist_configure(self._h, _C.byref(cfg)))
 
     def bind(self, rank, rel, keys, pays, n=None):
@@ -304,6 +303,23 @@ class GroupJoin:
         m, a = _C.c_uint64(), _C.c_uint64()
         self._ck(self._L.hj_dist_join(self._h, _C.byref(m), _C.byref(a)))
         return m.value, a.value
+
+    def bind_output(self, rank, key, payR, payS, cap=None):
+        """Rank `rank` writes the (key, payR, payS) tuples of the partitions it owns into these device columns (hj_dist_bind_output)."""
+        cap = int(key.numel()) if cap is None else int(cap)
+        self._keep[(rank, "out")] = (key, payR, payS)
+        self._ck(self._L.hj_dist_bind_output(self._h, rank, _dev_ptr(key), _dev_ptr(payR), _dev_ptr(payS), cap))
+
+    def join_materialize(self, agg=True):
+        """hj_dist_join_materialize: (global matches, global aggregate or None, [tuples written by every rank]).  HJError with
+        code HJ_ECAPACITY when some rank's output did not fit; .n_out then still holds the sizes."""
+        m, a = _C.c_uint64(), _C.c_uint64()
+        n_out = (_C.c_uint64 * self.world)()
+        rc = self._L.hj_dist_join_materialize(self._h, _C.byref(m), _C.byref(a) if agg else None, n_out)
+        self.n_out = [int(x) for x in n_out]
+        self.last_matches = m.value
+        self._ck(rc)
+        return m.value, (a.value if agg else None), self.n_out
 
     def stats(self, rank):
         s = _hjlib.DistStats()
@@ -334,6 +350,7 @@ class RankJoin:
         if rc:
             raise _HJError(rc, "hj_dist_rank_create(rank %d of %d) failed" % (rank, world))
         self._h = h
+        self.world = world
         self.last_received = (0, 0)
 
     def _ck(self, rc):
@@ -358,6 +375,19 @@ class RankJoin:
         st = self.stats()
         self.last_received = tuple(st["received"])
         return m.value, a.value
+
+    def join_materialize(self, Rk, Rp, Sk, Sp, out_key, out_payR, out_payS, cap=None, agg=False):
+        """hj_dist_rank_join_materialize (collective): this rank's share of the output goes to its own device columns.
+        Returns (global matches, global aggregate or None, tuples this rank wrote, [tuples of every rank])."""
+        cap = int(out_key.numel()) if cap is None else int(cap)
+        m, a, n = _C.c_uint64(), _C.c_uint64(), _C.c_uint64()
+        n_all = (_C.c_uint64 * self.world)()
+        self._ck(self._L.hj_dist_rank_join_materialize(self._h, _dev_ptr(Rk), _dev_ptr(Rp), int(Rk.numel()), _dev_ptr(Sk), _dev_ptr(Sp),
+                                                       int(Sk.numel()), _dev_ptr(out_key), _dev_ptr(out_payR), _dev_ptr(out_payS), cap,
+                                                       _C.byref(n), n_all, _C.byref(m), _C.byref(a) if agg else None))
+        st = self.stats()
+        self.last_received = tuple(st["received"])
+        return m.value, (a.value if agg else None), n.value, [int(x) for x in n_all]
 
     def stats(self):
         s = _hjlib.DistStats()

@@ -15,6 +15,7 @@ import numpy as np
 from . import _lib
 
 REL_R, REL_S = 0, 1
+EINVAL, EHIP, ENOMEM, ECAPACITY, EIO = -1, -2, -3, -4, -5   # include/hj.h
 PAYLOAD_ONES, PAYLOAD_ROWID, PAYLOAD_GIVEN = 0, 1, 2
 _PAYLOAD = {"ones": PAYLOAD_ONES, "rowid": PAYLOAD_ROWID, "given": PAYLOAD_GIVEN}
 

@@ -54,7 +54,8 @@ typedef struct hj_dist_config {
                              * all-reduce of the result, ncclCommInitRank); 0 = $HJ_DIST_TIMEOUT_S seconds, or 120 s.  On expiry the call
                              * returns HJ_EHIP and hj_dist(_rank)_error names the rank, the stage, the slices whose exchange has not
                              * completed and the peers a message is owed by; the group is unusable afterwards (create a new one). */
-    uint32_t test_stall_rank; /* tests: rank test_stall_rank - 1 stops taking part in the exchange for 2.5 deadlines (a stalled peer) */
+    uint32_t reserved;      /* ignored (round 4 kept a test-only fault-injection switch here; it is the environment variable
+                             * HJ_DIST_TEST_STALL_RANK now, read by the library's test hook only) */
 } hj_dist_config;
 
 typedef struct hj_dist_stats {
@@ -76,7 +77,9 @@ typedef struct hj_dist_stats {
     float exchange_ms;         /* sliced path: device time on the communication stream from the start of the first slice's exchange to
                                 * the end of the last one's (HIP events): link_bytes / (world - 1) / exchange_ms = the rate ONE link
                                 * direction sustained, to be held against its 76.8 GB/s */
-    uint32_t reserved[4];
+    uint32_t materializing;    /* 1: the last join was a materialising one */
+    uint64_t materialized;     /* ... and this rank wrote this many (key, payR, payS) tuples (more than its capacity: HJ_ECAPACITY) */
+    uint32_t reserved[1];
 } hj_dist_stats;
 
 /* ---- one process, G ranks ---- */
@@ -98,6 +101,18 @@ int hj_dist_configure(hj_dist *d, const hj_dist_config *cfg);
 int hj_dist_bind(hj_dist *d, int rank, int rel, const int32_t *d_keys, const int32_t *d_pays, uint64_t n);
 /* The sharded join of what the ranks have bound: global match count and sum payR*payS mod 2^64.  [sync] */
 int hj_dist_join(hj_dist *d, uint64_t *matches, uint64_t *agg);
+/* The sharded MATERIALISING join (north_star: "join output = match count and materialised (key,payloadR,payloadS) tuples"; SURVEY
+ * §8(e) "Output: stays sharded (each GPU materialises its partitions' results); global count via all-reduce"; the reference writes
+ * its output per level-0 partition in the co-processing analogue, src/hash_join_clustered_probe.cu:1503-1618 with
+ * join_partitioned_results src/join-primitives.cu:1107-1416).  Every rank writes the output tuples of the partitions it owns into
+ * ITS OWN device columns (hj_dist_bind_output: caller-owned, on the rank's device, cap tuples each; gap-free [0, n_out[rank]),
+ * order unspecified — the semantics of hj_join_materialize).  The union over the ranks is the join result; no tuple crosses a link
+ * a second time.  *matches = global count (all-reduced), *agg = global sum payR*payS mod 2^64 (NULL: not computed — it costs a
+ * pass over the output), n_out[world] = tuples each rank produced (all-gathered; may be NULL).  HJ_ECAPACITY when some rank's
+ * output did not fit its columns (nothing beyond a capacity is written; counts and n_out are still returned; the group stays
+ * usable).  [sync] */
+int hj_dist_bind_output(hj_dist *d, int rank, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap);
+int hj_dist_join_materialize(hj_dist *d, uint64_t *matches, uint64_t *agg, uint64_t *n_out);
 int hj_dist_get_stats(hj_dist *d, int rank, hj_dist_stats *out);
 
 /* ---- one process per GPU ---- */
@@ -110,6 +125,12 @@ int hj_dist_rank_configure(hj_dist_rank *r, const hj_dist_config *cfg);
 /* Collective: every rank calls it with its local slices (device columns on the context's GPU).  [sync] */
 int hj_dist_rank_join(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk,
                       const int32_t *d_Sp, uint64_t nS, uint64_t *matches, uint64_t *agg);
+/* Collective, materialising (see hj_dist_join_materialize): this rank's output goes to its own columns (cap tuples each);
+ * *n_out = tuples this rank produced, n_out_all[world] = every rank's (may be NULL), *matches / *agg global (agg NULL: not computed).
+ * HJ_ECAPACITY on EVERY rank when some rank's output did not fit.  [sync] */
+int hj_dist_rank_join_materialize(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk,
+                                  const int32_t *d_Sp, uint64_t nS, int32_t *d_out_key, int32_t *d_out_payR, int32_t *d_out_payS,
+                                  uint64_t cap, uint64_t *n_out, uint64_t *n_out_all, uint64_t *matches, uint64_t *agg);
 int hj_dist_rank_get_stats(hj_dist_rank *r, hj_dist_stats *out);
 
 #ifdef __cplusplus

@@ -4,6 +4,7 @@ exchange runs over the in-process device-copy transport (RCCL refuses duplicate 
 flag gathering and the exact fallback are the code that runs over RCCL on a multi-GPU node; RCCL itself is exercised at
 world size 1 (communicator, grouped send/recv of a rank's own share, all-gather, all-reduce) and, where two GPUs are
 visible, at world size 2."""
+import os
 from importlib import import_module
 
 import numpy as np
@@ -176,7 +177,7 @@ def _bind_group(g, P, world, R, S, misalign_rank=None):
 @pytest.mark.parametrize("world,stall", [(2, 1), (3, 0)])
 def test_a_stalled_peer_hits_the_deadline_instead_of_hanging(world, stall):
     """no wait of the multi-GPU path blocks for ever.  One rank stops taking part in the exchange of S's
-    first slice for 2.5 deadlines (hj_dist_config.test_stall_rank); the others give up at the deadline with a message that says
+    first slice for 2.5 deadlines ($HJ_DIST_TEST_STALL_RANK, read by the library's test hook); the others give up at the deadline with a message that says
     who waited for whom and where, the stalled rank finds the group aborted when it comes back, hj_dist_join returns an error —
     and the group refuses further joins (a communicator with a collective that was given up is not reused)."""
     import time
@@ -189,10 +190,14 @@ def test_a_stalled_peer_hits_the_deadline_instead_of_hanging(world, stall):
         keep = _bind_group(g, P, world, R, S)
         g.configure(slices=3, timeout_ms=1000)
         assert g.join()[0] == len(S)                       # healthy first: the deadline does not fire on a working group
-        g.configure(slices=3, timeout_ms=1000, test_stall_rank=stall + 1)
+        g.configure(slices=3, timeout_ms=1000)
+        os.environ["HJ_DIST_TEST_STALL_RANK"] = str(stall + 1)
         t0 = time.time()
-        with pytest.raises(P.HJError) as ei:
-            g.join()
+        try:
+            with pytest.raises(P.HJError) as ei:
+                g.join()
+        finally:
+            del os.environ["HJ_DIST_TEST_STALL_RANK"]
         dt = time.time() - t0
         msg = str(ei.value)
         assert "deadline" in msg and "rank" in msg and ("waited for rank(s) %d" % stall) in msg, msg
@@ -253,6 +258,127 @@ def test_transport_is_selectable():
     for bad in (("rccl", [0, 0]), ("smoke-signals", [0])):
         with pytest.raises(P.HJError):
             D.GroupJoin(bad[1], transport=bad[0])
+
+
+def _run_materialize(devices, R, S, cuts=None, dist_cfg=None, ctx_cfg=None, cap_factor=1.0, expect_paths=None):
+    """The sharded materialising join: rank r gets a contiguous cut of R and S (row-id payloads, so every output tuple names its
+    two source rows), writes its share of the output into its own columns; the UNION of the ranks' outputs must be the oracle's
+    sorted (key, payR, payS) multiset, the all-gathered sizes must be the lengths of the shares, count and aggregate the oracle's.
+    Twice: buffers and learned state are reused."""
+    import torch
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    G = len(devices)
+    cuts = cuts or [(i + 1) / G for i in range(G)]
+    Pr = np.arange(len(R), dtype=np.int32)
+    Ps = (np.arange(len(S), dtype=np.int32) * 3 - 7).astype(np.int32)
+    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    ek, epr, eps = o.join_materialize(R, Pr, S, Ps)
+    want = np.stack([ek, epr, eps], 1)
+    want = want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))]
+    cap = max(16, int(em * cap_factor))       # every rank could hold the whole result (a heavy key lands on one rank)
+    with D.GroupJoin(devices) as g:
+        if dist_cfg:
+            g.configure(**dist_cfg)
+        keep, outs = [], []
+        for r in range(G):
+            if ctx_cfg:
+                g.context(r).configure(**ctx_cfg)
+            dev = torch.device("cuda", devices[r])
+            lo = [int(round((cuts[r - 1] if r else 0) * len(X))) for X in (R, S)]
+            hi = [int(round(cuts[r] * len(X))) for X in (R, S)]
+            cols = []
+            for X, Px, a, b in ((R, Pr, lo[0], hi[0]), (S, Ps, lo[1], hi[1])):
+                cols += [torch.from_numpy(np.ascontiguousarray(X[a:b])).to(dev), torch.from_numpy(np.ascontiguousarray(Px[a:b])).to(dev)]
+            keep.append(cols)
+            g.bind(r, P.REL_R, cols[0], cols[1])
+            g.bind(r, P.REL_S, cols[2], cols[3])
+            out = [torch.full((cap,), -1, dtype=torch.int32, device=dev) for _ in range(3)]
+            outs.append(out)
+            g.bind_output(r, *out, cap=cap)
+        for rep_ in range(2):
+            m, agg, n_out = g.join_materialize(agg=True)
+            assert (m, agg) == (em, eagg), ((m, agg), (em, eagg))
+            assert sum(n_out) == em, (n_out, em)
+            stats = [g.stats(r) for r in range(G)]
+            assert [s["materialized"] for s in stats] == n_out and all(s["materializing"] for s in stats), (stats, n_out)
+            parts = [np.stack([c[:n].cpu().numpy() for c in outs[r]], 1) for r, n in enumerate(n_out)]
+            got = np.concatenate(parts) if parts else np.empty((0, 3), np.int32)
+            got = got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))]
+            assert got.shape == want.shape and (got == want).all()
+            # a rank only holds keys it owns (the level-0 shard of the key) unless the exact path dealt shards by size
+            if not any(s["balanced"] for s in stats):
+                for r, part in enumerate(parts):
+                    assert all(P.shard_of(int(k), G) == r for k in part[:50, 0]), r
+            assert g.join() == (em, eagg)              # the count-only join on the same group still answers (buffers shared)
+        if expect_paths:
+            assert all(s["path"] == expect_paths for s in stats), stats
+    return stats
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_materialising_join_ranks_share_one_gpu(world):
+    """the sharded materialising join at world 2 and 3 on cuda:0 (device-copy transport) — sliced path with one
+    and with two probe-side groups (the second appends to the first's output), duplicates on both sides, an empty rank."""
+    R, S = _inputs(120_000, 300_001, 31, "unique")
+    for slices in (1, 3):
+        _run_materialize([0] * world, R, S, dist_cfg=dict(slices=slices), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
+    _run_materialize([0] * world, R, S, dist_cfg=dict(slices=3, single_group=True), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
+    cuts = [0.5, 0.5, 1.0][:world] if world == 3 else [0.0, 1.0]         # a rank that holds nothing
+    _run_materialize([0] * world, R, S, cuts=cuts, dist_cfg=dict(slices=4), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
+    R, S = _inputs(60_000, 60_000, 32, "dups")                            # ~6 x 6 matches per key, negative keys
+    _run_materialize([0] * world, R, S, dist_cfg=dict(slices=2), ctx_cfg=dict(bits1=4, bits2=3), expect_paths="sliced")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_materialising_join_skew_and_small_inputs_take_the_exact_path(world):
+    """One key holds 40 % of S: a slot overflows, every rank repeats the MATERIALISING join on the exact path (output restarted at
+    position 0); single-pass sizes and an empty relation go there directly."""
+    R, S = _inputs(50_000, 200_000, 33, "heavy")
+    _run_materialize([0] * world, R, S, dist_cfg=dict(slices=3), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="exact")
+    _run_materialize([0] * world, R, S, dist_cfg=dict(exact_only=True, balance_size=True), expect_paths="exact")
+    R, S = _inputs(3_000, 9_000, 34, "unique")
+    _run_materialize([0] * world, R, S, expect_paths="exact")
+    _run_materialize([0] * world, np.empty(0, np.int32), S, expect_paths="exact")
+
+
+def test_materialising_join_capacity_is_agreed_by_every_rank():
+    """A rank whose share does not fit its columns: HJ_ECAPACITY on every rank (nothing written past a capacity), the sizes still
+    reported, and the group stays usable — the next call with room succeeds."""
+    import torch
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(80_000, 240_000, 35, "unique")
+    world = 2
+    with D.GroupJoin([0] * world) as g:
+        for r in range(world):
+            g.context(r).configure(bits1=5, bits2=4)
+        keep = _bind_group(g, P, world, R, S)
+        g.configure(slices=2)
+        small = [[torch.full((1000,), -1, dtype=torch.int32, device="cuda") for _ in range(3)] for _ in range(world)]
+        guard = [torch.full((64,), -1, dtype=torch.int32, device="cuda") for _ in range(world)]
+        for r in range(world):
+            g.bind_output(r, *small[r], cap=900)
+        with pytest.raises(P.HJError) as ei:
+            g.join_materialize(agg=False)
+        assert ei.value.code == P.ECAPACITY and "capacity" in str(ei.value), str(ei.value)
+        assert sum(g.n_out) == len(S) and g.last_matches == len(S), (g.n_out, len(S))
+        for r in range(world):
+            assert (small[r][0][900:] == -1).all() and (guard[r] == -1).all()      # nothing beyond the capacity
+        big = [[torch.empty(len(S), dtype=torch.int32, device="cuda") for _ in range(3)] for _ in range(world)]
+        for r in range(world):
+            g.bind_output(r, *big[r])
+        m, _, n_out = g.join_materialize(agg=False)
+        assert m == len(S) and sum(n_out) == len(S)
+        del keep
+
+
+def test_materialising_join_rccl_world1():
+    """The link code of the materialising join over RCCL itself, as far as one GPU goes: grouped send/recv of the rank's own share,
+    the all-reduce of the result, the all-gather of the output sizes; both paths."""
+    R, S = _inputs(150_000, 400_000, 36, "unique")
+    st = _run_materialize([0], R, S, dist_cfg=dict(slices=3, self_via_link=True), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
+    st = _run_materialize([0], R, S, dist_cfg=dict(exact_only=True, self_via_link=True), expect_paths="exact")
 
 
 def test_more_ranks_than_gpus_is_refused():

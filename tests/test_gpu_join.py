@@ -382,6 +382,18 @@ def test_bench_cli_json_cpu_baseline_gpus(P, tmp_path):
         assert line["matches"] == expect and line["gpus"] == 2 and "Total Throughput (2 GPUs)" in r.stdout
     else:
         assert r.returncode != 0 and "GPU Error" in r.stderr     # one device only: fails loudly, no fallback
+    # the transcript of the N > 1 mode on a one-GPU box: both ranks on GPU 0 over the device-copy transport (test mode, says so).
+    # The materialising run comes first, as in the reference (hjcp.cu:937-940, 986-991); every GPU keeps its share of the output
+    r = subprocess.run(base + ["--json", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HJ_BENCH_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = r.stdout
+    assert "TEST MODE" in out and out.index("With materialization") < out.index("Without materialization")
+    assert out.count("Total Throughput (2 GPUs)") == 2 and out.count("%d results" % expect) == 2
+    shares = [int(x) for x in out.split("Output (sharded, one share per GPU):")[1].split("tuples")[0].split()]
+    assert len(shares) == 2 and sum(shares) == expect and min(shares) > 0
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["matches"] == line["materialized"] == expect and line["gpus"] == 2
 
 
 def test_two_contexts_on_two_host_threads(P):
