@@ -207,14 +207,6 @@ __global__ void k_offsets(const uint32_t *__restrict__ hist, const uint64_t *__r
 // below; the exact (histogram-backed) kernel k_scatter_wc follows it.
 constexpr int WC_THREADS = 1024;
 constexpr int WC_LINE = 32;   // tuples per 128-byte line
-// Experiment switches of the LDS-side analysis (`make exp EXP=...`, profiles/r5_lds_conflicts.txt); the shipped library is built
-// with HJ_EXP = 0.  Attribution builds REMOVE one class of LDS instruction (the output is garbage, the control flow and every other
-// address are unchanged): 1 phase-A kept-tuple stores, 2 phase-B stores, 4 phase-C LDS reads, 8 phase-C global stores.  Variants
-// (output correct): 16 phase-A stores predicated instead of pointed at trash slots, 64 the same for phase B, 32 phase-C reads
-// with the two 16-byte halves swapped for every other pair of lines (no two lines of a hardware lane group on the same banks).
-#ifndef HJ_EXP
-#define HJ_EXP 0
-#endif
 constexpr int WC_HSTRIDE = MAX_PARTS + 64; // arrival counters per parity + 64 per-lane trash counters (branch-free ranking)
 
 // ------------------------------------------------------------------------------------------------
@@ -368,9 +360,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = keep[u * 4 + e];
-                if (HJ_EXP & 1) continue;
-                if (HJ_EXP & 16) { if (k != WF_NONE) buf[k] = make_int2(elem(kk[u], e), elem(pp[u], e)); }
-                else buf[k != WF_NONE ? k : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                buf[k != WF_NONE ? k : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
             }
         // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
         // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
@@ -430,9 +420,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t capd = VAR ? (lt >> 16) * WC_LINE : capS, based = VAR ? (lt & 0xFFFFu) * WC_LINE : d * capS;
                 const bool now = valid && (leaves ? q < capd : full == 0);
                 any_bypass |= valid && leaves && q >= capd;
-                if (HJ_EXP & 2) {}
-                else if (HJ_EXP & 64) { if (now) buf[based + q] = make_int2(elem(kk[u], e), elem(pp[u], e)); }
-                else buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
                 keep[j] = (valid && !leaves && full != 0) ? based + (q - full) : WF_NONE;
             }
         if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
@@ -478,24 +466,10 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     const uint32_t df = VAR ? L_.own[ls] : ls >> kshift;
                     const uint32_t jf = VAR ? ls - (L_.lt[df] & 0xFFFFu) : (ls & (K - 1));
                     const uint64_t gpos = ((uint64_t)line[df] + jf) * WC_LINE + c4;
-                    int4 x, y;
-                    if (HJ_EXP & 4) { x = make_int4((int)ls, (int)jf, 0, 1); y = x; }
-                    else if (HJ_EXP & 32) {
-                        // ds_read_b128 is served in groups of 16 lanes {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: lines t and t+3, t+1 and t+2
-                        // of the eight a wave moves per step meet in one group at the same 16-byte offsets (every line starts on bank 0): a
-                        // 2-way conflict on each read.  Lanes 16-31 and 48-63 fetch their halves in the other order: the sixteen 16-byte
-                        // chunks a group reads are then all different
-                        const uint32_t sw = (ln >> 4) & 1u;
-                        const int4 a_ = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2 * sw);
-                        const int4 b_ = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2 - 2 * sw);
-                        x = sw ? b_ : a_; y = sw ? a_ : b_;
-                    } else {
-                        x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
-                        y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
-                    }
+                    const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);     // k0 p0 k1 p1
+                    const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2); // k2 p2 k3 p3
                     const int4 kq = make_int4(x.x, x.z, y.x, y.z), pq = make_int4(x.y, x.w, y.y, y.w);
                     const uint32_t first_valid = (EXACT && jf == 0) ? L_.lo[df] : 0u;
-                    if ((HJ_EXP & 8) && !(x.x == 0x7fffff01 && y.w == 0x7fffff02)) {} else
                     if (first_valid == 0) {
                         *reinterpret_cast<int4 *>(out_keys + gpos) = kq;
                         *reinterpret_cast<int4 *>(out_pays + gpos) = pq;
