@@ -518,6 +518,7 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     R.n_alloc = sp.sizeB;
     R.pb1 = b1; R.pb2 = b2;
     R.partitioned = true; R.fast_tried = true; R.sampled = true;
+    R.flag_unread = true;
     c->join_planned = false;
     *done = true;
     return 0;
@@ -532,18 +533,22 @@ int ensure_part(hj_ctx *c, Buf &b, size_t bytes) {
     return ensure(c, b, bytes + bytes / 10);
 }
 
-int partition_rel(hj_ctx *c, int r) {
+int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     Rel &R = c->rel[r];
+    if (defer) defer->used = false;
     if (!R.bound) return fail(c, HJ_EINVAL, "relation %d not loaded", r);
     // Positions inside the partition kernels are 32-bit LINE numbers (2^37 tuples): what bounds a relation is the card's memory,
     // checked here before anything is (re)allocated — pass-1 and final buffers of both columns, ~1.14 x 16 bytes per tuple on top
     // of the input (the reference's CLI accepts up to ULONG_MAX/4 tuples, main.cu:491-514).
     if (R.n > ((uint64_t)1 << 34)) return fail(c, HJ_EINVAL, "relation too large (n <= 2^34 tuples: pass-2 parents are addressed in 32-bit units)");
+    if (c->force_sampled & (1 << r)) R.prefer_exact = true; // experiment knob: this relation takes the sampled path whatever its distribution
     choose_bits(c);
+    bool histogram_free = false; // the relation will take the plain or the sampled histogram-free passes (neither reads R.root)
     {
         const uint32_t P1g = 1u << c->bits1, P2g = 1u << c->bits2;
         FastPlan fg{};
         const bool fastg = c->bits2 && c->fast_path && !c->cfg.exact_only && !R.prefer_exact && plan_fast(c, R.n, P1g, P2g, fg);
+        histogram_free = fastg || (R.prefer_exact && R.sp.valid && !R.sampled_failed && !R.force_exact && c->bits2 && c->fast_path && !c->cfg.exact_only);
         const uint64_t wantA = c->bits2 ? (std::max<uint64_t>(R.n, fastg ? fg.sizeA : 0) + PAD) * 4 : 0, wantB = (std::max<uint64_t>(R.n, fastg ? fg.sizeB : 0) + PAD) * 4;
         uint64_t grow = 0, give_back = 0;
         for (const Buf *b : {&R.a_k, &R.a_p}) if (wantA > b->cap) { grow += wantA + wantA / 10; give_back += b->cap; }
@@ -557,7 +562,13 @@ int partition_rel(hj_ctx *c, int r) {
     hipStream_t st = c->stream;
     RET(ensure(c, R.root, 2 * 8));
     uint32_t *const flag = reinterpret_cast<uint32_t *>((uint64_t *)c->scalars.p + 8 + r); // travels with the result block
-    { Timed t(c, "k_set_root"); HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, flag)); }
+    // root offsets for the exact passes + the flag reset — not needed in front of histogram-free passes whose flag is known to be 0
+    // (steady-state steps of hj_join: two launches fewer per step)
+    if (!(assume_clean && histogram_free && !R.flag_unread && !R.flag_maybe_set)) {
+        Timed t(c, "k_set_root");
+        HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, flag));
+        R.flag_unread = false; R.flag_maybe_set = false; // reset in stream order
+    }
     uint32_t b1 = c->bits1, b2 = c->bits2;
     // A relation known to be skewed (its histogram-free attempt overflowed) is split as evenly as possible between
     // the two exact passes: fewer than 512 digits per pass leave LDS lines to deal to the heavy digits (k_scatter_wc).
@@ -617,15 +628,19 @@ int partition_rel(hj_ctx *c, int r) {
             fa.shift = b2; fa.P = P1; fa.cap = f.cap1;
             fa.out_keys = (int32_t *)R.a_k.p; fa.out_pays = (int32_t *)R.a_p.p;
             fa.obeg = (uint64_t *)R.s1beg.p; fa.oend = (uint64_t *)R.s1end.p; fa.ovf = ovf;
-            { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(st, fa)); }
             FastArgs fb{};
             fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
             fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = f.nspans;
             fb.shift = 0; fb.P = P2; fb.cap = f.cap2;
             fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
             fb.obeg = beg; fb.oend = end; fb.ovf = ovf;
-            { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(st, fb)); }
+            if (defer) { defer->fa = fa; defer->fb = fb; defer->used = true; } // the caller launches (merged with the other relation's)
+            else {
+                { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(st, fa)); }
+                { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(st, fb)); }
+            }
             R.fast_tried = true;
+            R.flag_unread = true;
         } else {
             RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
             RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
@@ -657,6 +672,7 @@ int resolve_layout(hj_ctx *c, Rel &R) {
     uint32_t ovf = 0;
     HIPCHK(c, hipMemcpyAsync(&ovf, (uint64_t *)c->scalars.p + 8 + (&R - c->rel), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.flag_unread = false; R.flag_maybe_set = ovf != 0;
     if (ovf) {
         if (R.sampled) R.sampled_failed = true;
         R.prefer_exact = true;
@@ -746,7 +762,16 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
     uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
-    if (nparts <= 16384 && !Pb.sampled && !general) { // small partition counts: plan + scan + expand in one launch (launch latency, not work, is what counts there)
+    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0; // experiment knobs are read per call: same-context A/B (tools/launch_ab.py)
+    const bool atomic_plan = c->plan_atomic;
+    if (nparts <= 1024 && !Pb.sampled && !general) { // one workgroup's worth of partitions: plan + scan + expand in one single-workgroup launch
+        Timed t(c, "k_join_plan");
+        HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, zero_cursor, sc + 0));
+    } else if (atomic_plan && !Pb.sampled && !general) { // any partition count in ONE launch: item slots reserved on the counter pass 2 zeroed
+        if (!c->items_zeroed) HIPCHK(c, hipMemsetAsync(sc + 0, 0, 8, st));
+        Timed t(c, "k_join_plan");
+        HIPCHK(c, launch_join_plan_atomic(st, a, nparts, (JoinItem *)c->items.p, sc + 1, zero_cursor, sc + 0));
+    } else if (nparts <= 16384 && !Pb.sampled && !general) {
         Timed t(c, "k_join_plan");
         HIPCHK(c, launch_join_plan_fused(st, a, nparts, (JoinItem *)c->items.p, sc + 1, zero_cursor, sc + 0));
     } else {
@@ -756,6 +781,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     { Timed t(c, "k_join_expand"); HIPCHK(c, launch_join_expand(st, a, nparts, (const uint32_t *)c->items_cnt.p,
                                                                 (const uint64_t *)c->jchunk_prefix.p, (JoinItem *)c->items.p)); }
     }
+    c->items_zeroed = false; // the counter holds this plan's item count now
     a.wave_counts = (uint64_t *)c->wave_counts.p;
     a.wave_agg = (uint64_t *)c->wave_agg.p;
     return 0;
@@ -791,6 +817,7 @@ int fetch_scalars(hj_ctx *c) {
     for (int r = 0; r < 2; r++) {
         Rel &R = c->rel[r];
         if (!R.fast_tried || R.flag_known_good) continue;
+        R.flag_unread = false; R.flag_maybe_set = (uint32_t)c->h_scalars[8 + r] != 0;
         if ((uint32_t)c->h_scalars[8 + r]) { // slots overflowed: ranges invalid
             if (getenv("HJ_DEBUG")) fprintf(stderr, "[hj] rel %d overflow flag 0x%x (sampled %d) nwg2 %u nspans %u\n", r, (uint32_t)c->h_scalars[8 + r], (int)R.sampled, R.sp.nwg2, R.sp.nspans);
             if (R.sampled) R.sampled_failed = true; // even the sampled capacities: the exact passes are what is left
@@ -862,7 +889,7 @@ void drop_graph(hj_ctx *c) {
 
 void hj_invalidate_all(hj_ctx *c) {
     invalidate(c);
-    for (int r = 0; r < 2; r++) { c->rel[r].fast_tried = false; c->rel[r].flag_known_good = false; c->rel[r].bound = false; }
+    for (int r = 0; r < 2; r++) { c->rel[r].fast_tried = false; c->rel[r].flag_known_good = false; c->rel[r].bound = false; c->rel[r].flag_unread = true; }
 }
 
 } // namespace hjx
@@ -895,7 +922,10 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
     if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
     if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
+    if (const char *ml = getenv("HJ_MERGE_LOG2")) c->merge_log2 = (uint32_t)std::max(0, std::min(40, atoi(ml)));
+    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0;
     if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
+    if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // bit 0: R, bit 1: S
     (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
     *out = c;
     return HJ_OK;
@@ -1108,7 +1138,31 @@ namespace {
 // |R|+|S| (log2) that forks.  Not with kernel events on (the instrumented steps time serial kernels).  Works the same under
 // stream capture (fork / join by events).
 int partition_both(hj_ctx *c) {
+    if (const char *ml = getenv("HJ_MERGE_LOG2")) c->merge_log2 = (uint32_t)std::max(0, std::min(40, atoi(ml)));
+    if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
     const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->fork_log2) && c->events == 0;
+    // Small and medium inputs: ONE launch per pass for both relations (k_part1_fast2 / k_part2_fast2), one stream, no event fork and
+    // join, no k_set_root in front of a relation whose flag is known to be 0, the join's item counter zeroed by pass 2: a steady-state
+    // step is pass 1, pass 2, plan, build+probe, sum, result copy.  Not with kernel events on (the instrumented steps time one
+    // relation's kernel alone on the chip), not for relations of very different sizes (their passes are arranged by priority below).
+    if (c->merge_log2 && c->events == 0 && c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->merge_log2) && c->rel[0].n && c->rel[1].n &&
+        std::max(c->rel[0].n, c->rel[1].n) < 4 * std::min(c->rel[0].n, c->rel[1].n)) {
+        FastPair pr[2];
+        for (int r = 0; r < 2; r++) RET(partition_rel(c, r, &pr[r], true));
+        if (pr[0].used && pr[1].used) {
+            pr[0].fb.zero_items = (uint64_t *)c->scalars.p + 0;
+            { Timed t(c, "k_part1_fast2"); HIPCHK(c, launch_part1_fast2(c->stream, pr[0].fa, pr[1].fa)); }
+            { Timed t(c, "k_part2_fast2"); HIPCHK(c, launch_part2_fast2(c->stream, pr[0].fb, pr[1].fb)); }
+            c->items_zeroed = true;
+        } else {
+            for (int r = 0; r < 2; r++)
+                if (pr[r].used) {
+                    { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(c->stream, pr[r].fa)); }
+                    { Timed t(c, "k_part2_fast"); HIPCHK(c, launch_part2_fast(c->stream, pr[r].fb)); }
+                }
+        }
+        return 0;
+    }
     if (!fork) {
         RET(partition_rel(c, HJ_REL_R));
         return partition_rel(c, HJ_REL_S);
@@ -1190,6 +1244,7 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
     for (int r = 0; r < 2; r++) {
         Rel &R = c->rel[r];
         if (!R.fast_tried) continue;
+        R.flag_unread = false; R.flag_maybe_set = (uint32_t)c->h_scalars[8 + r] != 0;
         if ((uint32_t)c->h_scalars[8 + r]) { // the data under the binding changed: skewed now
             if (R.sampled) R.sampled_failed = true;
             R.prefer_exact = true; c->redo_mask |= 1u << r;

@@ -48,6 +48,10 @@ struct Rel {
     bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
     bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
     bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
+    // what the host knows about the relation's overflow flag ON THE DEVICE: kernels that may raise it were queued and nobody has read
+    // it since (unread) / it was read raised and not reset since (maybe_set).  Neither: the flag is 0 and the histogram-free passes
+    // of a steady-state step need no k_set_root in front of them (partition_both)
+    bool flag_unread = true, flag_maybe_set = true;
     // the sampled path (a relation known to be skewed, on the probe side): histogram-free passes with per-digit capacities
     bool sampled = false;         // the current partitions came from it: ranges, not one range per partition
     bool sampled_failed = false;  // it overflowed on this binding: exact passes from now on
@@ -94,7 +98,11 @@ struct hj_ctx {
     uint32_t redo_mask = 0;         // relations whose overflow flag came back raised with the last result block
     uint32_t target_spans = 0;      // experiment knob (HJ_TARGET_SPANS)
     uint32_t fork_log2 = 40;        // inputs up to 2^fork_log2 tuples (= always): S's partition passes on a second stream beside R's (HJ_FORK_LOG2)
+    uint32_t merge_log2 = 29;       // |R|+|S| up to 2^merge_log2: both relations' histogram-free passes in ONE launch per pass (HJ_MERGE_LOG2; 0 = never)
+    bool plan_atomic = true;        // plain items: plan + expand in one launch with atomic slot reservation (HJ_PLAN_ATOMIC=0: plan + scan + expand)
+    bool items_zeroed = false;      // the join's item counter (scalars[0]) was zeroed by the last pass-2 launch: k_join_plan_atomic may reserve on it
     int ncu = 256;                  // CUs of the device
+    int force_sampled = 0;          // HJ_FORCE_SAMPLED (experiments): bit r = relation r takes the sampled path without having overflowed
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
@@ -159,7 +167,12 @@ int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_pay
 void hj_invalidate_all(hj_ctx *c);
 void drop_graph(hj_ctx *c);
 // (hj_stream.hip: the host-memory paths drive the same partition / plan / join steps)
-int partition_rel(hj_ctx *c, int r);
+// defer != nullptr: a relation that takes the plain histogram-free passes is prepared (buffers, state) but NOT launched — the two
+// launches come back in *defer (used = true) and the caller enqueues them, e.g. merged with the other relation's.
+// assume_clean: the caller vouches for stream order with the last read of the flags (partition_both): no k_set_root when the host
+// knows the relation's device flag to be 0
+struct FastPair { hj::FastArgs fa, fb; bool used = false; };
+int partition_rel(hj_ctx *c, int r, FastPair *defer = nullptr, bool assume_clean = false);
 int resolve_layout(hj_ctx *c, hj_ctx::Rel &R);
 int plan_join(hj_ctx *c, hj::JoinArgs &a_out, bool &tag16, bool gen_ok = true, bool keep_cursor = false);
 

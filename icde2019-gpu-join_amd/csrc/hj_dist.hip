@@ -803,7 +803,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
         R.part_off = nullptr;
         R.n_alloc = gr.sizeB;
         R.pb1 = b1; R.pb2 = b2;
-        R.partitioned = true; R.fast_tried = true; R.flag_known_good = false;
+        R.partitioned = true; R.fast_tried = true; R.flag_known_good = false; R.flag_unread = true;
         R.n_bound = (uint64_t)(gr.s1 - gr.s0) * G * q.region; // upper bound of what this rank can hold here (sizes the work-item list; R.n stays nominal)
         return 0;
     };

@@ -56,8 +56,46 @@ bool host_has_streaming_stores() { return false; }
 void wc_fence() {}
 #endif
 
+// Partition ids of a block of keys.  The hash (murmur finaliser + multiplicative range reduction) is what both passes of the split
+// spent their time on — the split is compute-bound, not memory-bound: keys only and keys + payloads run at the same rate — so it is
+// computed ONCE, in the histogram pass, eight keys at a time (AVX2 where the host has it), and kept as one or two bytes per tuple
+// for the scatter pass.
+template <typename ID>
+void shard_block_scalar(const int32_t *K, uint64_t cnt, uint32_t parts, ID *ids) {
+    for (uint64_t j = 0; j < cnt; j++) ids[j] = (ID)host_shard_of(K[j], parts);
+}
+#if defined(__x86_64__)
+template <typename ID>
+__attribute__((target("avx2"))) void shard_block_avx2(const int32_t *K, uint64_t cnt, uint32_t parts, ID *ids) {
+    const __m256i c1 = _mm256_set1_epi32((int)0x85ebca6bu), c2 = _mm256_set1_epi32((int)0xc2b2ae35u), pn = _mm256_set1_epi32((int)parts);
+    uint64_t j = 0;
+    for (; j + 8 <= cnt; j += 8) {
+        __m256i h = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(K + j));
+        h = _mm256_xor_si256(h, _mm256_srli_epi32(h, 16)); h = _mm256_mullo_epi32(h, c1);
+        h = _mm256_xor_si256(h, _mm256_srli_epi32(h, 13)); h = _mm256_mullo_epi32(h, c2);
+        h = _mm256_xor_si256(h, _mm256_srli_epi32(h, 16));
+        // (h * parts) >> 32 per lane: 32 x 32 -> 64-bit products of the even and of the odd lanes
+        const __m256i ev = _mm256_srli_epi64(_mm256_mul_epu32(h, pn), 32);
+        const __m256i od = _mm256_mul_epu32(_mm256_srli_epi64(h, 32), pn); // the high halves are the results of the odd lanes
+        const __m256i r = _mm256_blend_epi32(ev, od, 0xAA);
+        alignas(32) uint32_t t[8];
+        _mm256_store_si256(reinterpret_cast<__m256i *>(t), r);
+        for (int e = 0; e < 8; e++) ids[j + e] = (ID)t[e];
+    }
+    for (; j < cnt; j++) ids[j] = (ID)host_shard_of(K[j], parts);
+}
+#endif
+template <typename ID>
+void shard_block(const int32_t *K, uint64_t cnt, uint32_t parts, ID *ids) {
+#if defined(__x86_64__)
+    if (host_has_streaming_stores()) { shard_block_avx2<ID>(K, cnt, parts, ids); return; } // (the same run-time AVX2 check)
+#endif
+    shard_block_scalar<ID>(K, cnt, parts, ids);
+}
+
 // false: the write-combining buffers could not be allocated (nothing was written)
-bool wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t hi, uint32_t parts,
+template <typename ID>
+bool wc_scatter_chunk(const int32_t *K, const int32_t *Pv, const ID *ids, uint64_t lo, uint64_t hi, uint32_t parts,
                                                       const uint64_t *start, int32_t *oK, int32_t *oP, bool stream) {
     // line[p]: 64-byte-aligned output position of the line being filled; fill[p]: next slot; first[p]: first valid slot
     std::vector<uint64_t> line(parts);
@@ -70,7 +108,7 @@ bool wc_scatter_chunk(const int32_t *K, const int32_t *Pv, uint64_t lo, uint64_t
     }
     for (uint64_t i = lo; i < hi; i++) {
         const int32_t key = K[i];
-        const uint32_t p = host_shard_of(key, parts);
+        const uint32_t p = ids[i];
         uint32_t s = fill[p];
         bufK[p * HWC + s] = key;
         if (oP) bufP[p * HWC + s] = Pv ? Pv[i] : 1;
@@ -134,9 +172,13 @@ std::vector<int> host_node_cpus(int node) {
 
 // false: a host thread could not be started (pids limit of the container) or a write-combining buffer could not be allocated:
 // nothing usable was written (the callers report HJ_ENOMEM)
-bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
-                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
+template <typename ID>
+static bool level0_split_t(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
+                           int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
     if (threads < 1) threads = 1;
+    ID *ids = (ID *)malloc((size_t)(n ? n : 1) * sizeof(ID)); // partition id of every tuple: written by the histogram pass, read by the scatter
+    if (!ids) return false;
+    struct Free { void *p; ~Free() { free(p); } } free_ids{ids};
     std::vector<uint64_t> hist((size_t)threads * parts, 0);
     auto chunk = [&](uint32_t t, uint64_t &lo, uint64_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
     // run f(t) for t = 0..threads-1 on that many host threads; thread 0's share runs on the caller
@@ -161,7 +203,19 @@ bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
     if (!parallel([&](uint32_t t) {
             uint64_t lo, hi; chunk(t, lo, hi);
             uint64_t *h = hist.data() + (size_t)t * parts;
-            for (uint64_t i = lo; i < hi; i++) h[host_shard_of(K[i], parts)]++;
+            // four interleaved sets of counters: consecutive tuples of one partition do not wait for each other's increment
+            std::vector<uint32_t> sub((size_t)4 * parts, 0);
+            uint32_t *s0 = sub.data(), *s1 = s0 + parts, *s2 = s1 + parts, *s3 = s2 + parts;
+            constexpr uint64_t BLK = 4096;
+            for (uint64_t b = lo; b < hi; b += BLK) {
+                const uint64_t cnt = std::min<uint64_t>(BLK, hi - b);
+                shard_block<ID>(K + b, cnt, parts, ids + b);
+                uint64_t j = 0;
+                for (; j + 4 <= cnt; j += 4) { s0[ids[b + j]]++; s1[ids[b + j + 1]]++; s2[ids[b + j + 2]]++; s3[ids[b + j + 3]]++; }
+                for (; j < cnt; j++) s0[ids[b + j]]++;
+                if ((b - lo) / BLK % 65536 == 65535) { for (uint32_t p = 0; p < parts; p++) { h[p] += (uint64_t)s0[p] + s1[p] + s2[p] + s3[p]; s0[p] = s1[p] = s2[p] = s3[p] = 0; } } // (32-bit counters)
+            }
+            for (uint32_t p = 0; p < parts; p++) h[p] += (uint64_t)s0[p] + s1[p] + s2[p] + s3[p];
         })) return false;
     off.assign(parts + 1, 0);
     uint64_t sum = 0;
@@ -177,9 +231,15 @@ bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
     std::atomic<bool> scattered{true};
     const bool started = parallel([&](uint32_t t) {
         uint64_t lo, hi; chunk(t, lo, hi);
-        if (!wc_scatter_chunk(K, Pv, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream)) scattered = false;
+        if (!wc_scatter_chunk<ID>(K, Pv, ids, lo, hi, parts, hist.data() + (size_t)t * parts, oK, oP, stream)) scattered = false;
     });
     return started && scattered;
+}
+
+bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
+                       int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
+    return parts <= 256 ? level0_split_t<uint8_t>(K, Pv, n, parts, threads, oK, oP, off, pin_cpus)
+                        : level0_split_t<uint16_t>(K, Pv, n, parts, threads, oK, oP, off, pin_cpus);
 }
 
 

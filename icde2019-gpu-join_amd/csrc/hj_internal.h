@@ -61,6 +61,7 @@ struct FastArgs {
     uint32_t *ovf;               // overflow flag (also read: a set flag makes the kernel return at once)
     uint32_t mode;               // pass 1: 0 = radix digit, 1 = multi-GPU shard of the key (hash; P = number of GPUs)
     uint32_t seg_pass1, span0;   // launch_part2_fast as a pass 1 over received segments: workgroup b is span span0 + b of nspans
+    uint64_t *zero_items;        // pass 2, optional: the join's item counter, zeroed by workgroup 0 (k_join_plan_atomic reserves on it)
 };
 
 // one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
@@ -113,6 +114,8 @@ hipError_t launch_offsets(hipStream_t st, const PassArgs &pa, uint64_t n, uint64
 hipError_t launch_scatter(hipStream_t st, int mode, const PassArgs &pa);
 hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
+hipError_t launch_part1_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb); // both relations of a join in one launch per pass
+hipError_t launch_part2_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 // the sampled path of skewed relations (hj_part.hip: k_part1_var, k_part2_var)
 struct VarArgs {
@@ -133,6 +136,10 @@ hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, co
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor);
 hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
                                   uint64_t *n_items);
+// plan + expand in ONE launch for any partition count: item slots reserved with one atomic per workgroup on *n_items, which the
+// caller (or the pass-2 kernel before it, FastArgs.zero_items) has zeroed; the items come out in no particular order
+hipError_t launch_join_plan_atomic(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
+                                   uint64_t *n_items);
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items);

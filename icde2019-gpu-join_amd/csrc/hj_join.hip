@@ -244,6 +244,46 @@ __global__ __launch_bounds__(1024) void k_join_plan_fused(const uint64_t *__rest
     if (threadIdx.x == 0) *n_items = carry;
 }
 
+// The same in one launch for ANY partition count: 1024 partitions per workgroup, item slots reserved with ONE atomic per workgroup
+// on *n_items (zeroed before the launch: by the pass-2 kernel, FastArgs.zero_items, or by the host).  The items of a partition stay
+// together, partitions of a workgroup stay in order, workgroups land in the order their atomics arrive: no consumer depends on the
+// order of the item list.  2^15 partitions (2^27 x 2^27): one launch of 32 workgroups instead of plan + scan (2) + expand;
+// 2^18 partitions: 256 atomics on one word (~3 us at the ~88 returning atomics per us one address sustains).
+__global__ __launch_bounds__(1024) void k_join_plan_atomic(const uint64_t *__restrict__ bbeg, const uint64_t *__restrict__ bend,
+                                                           const uint64_t *__restrict__ pbeg, const uint64_t *__restrict__ pend,
+                                                           uint32_t nparts, uint32_t chunk, JoinItem *__restrict__ items,
+                                                           const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ pflag,
+                                                           uint64_t *__restrict__ zero2, uint64_t *__restrict__ zero_cursor,
+                                                           unsigned long long *__restrict__ n_items) {
+    __shared__ uint32_t scratch[17];
+    __shared__ unsigned long long base_s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { zero2[0] = 0; zero2[1] = 0; *zero_cursor = 0; }
+    if ((bflag && *bflag) || (pflag && *pflag)) return; // ranges not valid: no items (n_items stays 0)
+    const uint32_t p = blockIdx.x * 1024 + threadIdx.x;
+    uint64_t b0 = 0, nb = 0, q0 = 0, q1 = 0;
+    if (p < nparts) { b0 = bbeg[p]; nb = bend[p] - b0; q0 = pbeg[p]; q1 = pend[p]; }
+    const uint32_t c = (nb && q1 > q0) ? (uint32_t)((q1 - q0 + chunk - 1) / chunk) : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &total);
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(n_items, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const uint64_t at = base_s + ex;
+    for (uint32_t j = 0; j < c; j++) {
+        JoinItem it;
+        it.b0 = b0; it.nb = (uint32_t)nb; it.p = p;
+        it.q0 = q0 + (uint64_t)j * chunk;
+        it.q1 = it.q0 + chunk < q1 ? it.q0 + chunk : q1;
+        items[at + j] = it;
+    }
+}
+
+hipError_t launch_join_plan_atomic(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
+                                   uint64_t *n_items) {
+    hipLaunchKernelGGL(k_join_plan_atomic, dim3((nparts + 1023) / 1024), dim3(1024), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items,
+                       a.bflag, a.pflag, zero2, zero_cursor, reinterpret_cast<unsigned long long *>(n_items));
+    return hipGetLastError();
+}
+
 hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
                                   uint64_t *n_items) {
     hipLaunchKernelGGL(k_join_plan_fused, dim3(1), dim3(1024), 0, st, a.bbeg, a.bend, a.pbeg, a.pend, nparts, a.chunk, items, a.bflag, a.pflag,
@@ -482,6 +522,10 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
     const size_t tbl = ((size_t)a.nh * 4 + (size_t)a.cap * 8 + (TAG16 ? 0 : (size_t)a.cap * 2) + 15) & ~(size_t)15;
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + tbl); // [2][JOIN_WAVES] wave totals (round parity) | [16],[17] base lo/hi
 
+    // general items: two 16-byte groups per lane (4096-tuple sub-chunks) — the third group's 9 registers are what the table and
+    // stream cursors of both roles need to stay out of scratch at three workgroups per CU
+    constexpr int IT = GEN ? 2 : MR_IT;
+    constexpr uint32_t SUB = GEN ? 2 * JOIN_THREADS * 4 : MR_SUB;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
     const uint32_t nr = (LISTS || GEN) ? item_nranges(it) : 1u;
     const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
@@ -519,11 +563,11 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
             else { q0 = it.q0; q1 = it.q1; }
             q0 = uniform64(q0); q1 = uniform64(q1);
         } else { q0 = it.q0; q1 = it.q1; }
-        for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)MR_SUB) {
+        for (uint64_t s0 = q0 & ~(uint64_t)3; s0 < q1; s0 += (uint64_t)SUB) {
             // the sub-chunk's probe tuples: issued first, so that they fly while the table is built
             // the first 2048 tuples are requested before the table is built (they fly during the build); the rest behind it — the
             // build keeps four 16-byte loads of its own in flight and the register file is what limits the workgroups per CU
-            int4 kk[MR_IT], pp[MR_IT];
+            int4 kk[IT], pp[IT];
             auto tuple_index = [&](int t, int e) -> uint64_t { // group t < 2: 4 tuples per lane; group 2: 2 tuples per lane
                 return t < 2 ? s0 + (uint64_t)t * JOIN_THREADS * 4 + (uint64_t)tid * 4 + e : s0 + (uint64_t)2 * JOIN_THREADS * 4 + (uint64_t)tid * 2 + e;
             };
@@ -540,7 +584,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
             fetch(0);
             if (built) {
 #pragma unroll
-                for (int t = 1; t < MR_IT; t++) fetch(t);
+                for (int t = 1; t < IT; t++) fetch(t);
             }
             if (!built) {
                 for (uint32_t i = tid; i < a.nh; i += JOIN_THREADS) head[i] = 0xFFFFFFFFu;
@@ -586,7 +630,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                 // reduction and a barrier per sub-chunk) need not run.  Whether they are unique costs about one such round to find
                 // out (every entry looks down the rest of its chain for its own key), so it is asked only where the table serves
                 // many sub-chunks: list items, general items, chunks of a long streamed side (config 4: 13 sub-chunks per table).
-                if (LISTS || GEN || it.q1 - it.q0 > 2 * (uint64_t)MR_SUB) {
+                if (LISTS || GEN || it.q1 - it.q0 > 2 * (uint64_t)SUB) {
                     const uint32_t nfill = GEN ? filled : nbc0;
                     bool dup = false;
                     for (uint32_t sl = tid; sl < nfill; sl += JOIN_THREADS) {
@@ -601,15 +645,17 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                     if (dup) red[18] = 1; // (read behind the first barrier of the rounds)
                 } else if (tid == 0) red[18] = 1; // not asked: as if
 #pragma unroll
-                for (int t = 1; t < MR_IT; t++) fetch(t);
+                for (int t = 1; t < IT; t++) fetch(t);
             }
             // chain position of tuple j (END: exhausted): 16 bits each, two per register; mm bit j: tuple j sits ON a match that is
             // not written yet.  (Packed: the register file, not LDS, is what limits this kernel to three workgroups per CU.)
-            uint32_t sp2[MR_IT * 2] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mm = 0;
+            uint32_t sp2[IT * 2], mm = 0;
+#pragma unroll
+            for (int z = 0; z < IT * 2; z++) sp2[z] = 0xFFFFFFFFu;
             auto getp = [&](int j) -> uint32_t { return (j & 1) ? sp2[j >> 1] >> 16 : sp2[j >> 1] & 0xFFFFu; };
             auto setp = [&](int j, uint32_t v) { sp2[j >> 1] = (j & 1) ? ((sp2[j >> 1] & 0xFFFFu) | (v << 16)) : ((sp2[j >> 1] & 0xFFFF0000u) | v); };
 #pragma unroll
-            for (int t = 0; t < MR_IT; t++)
+            for (int t = 0; t < IT; t++)
 #pragma unroll
                 for (int e = 0; e < MR_NE(t); e++) {
                     const uint64_t idx = tuple_index(t, e);
@@ -619,7 +665,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
             for (;; par ^= 1u) { // rounds
                 // every tuple advances to its next match; the chains of a load group in lockstep
 #pragma unroll
-                for (int t = 0; t < MR_IT; t++) {
+                for (int t = 0; t < IT; t++) {
                     for (;;) {
                         bool walking = false;
 #pragma unroll
@@ -659,7 +705,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                 __syncthreads();
                 uint64_t o = ((uint64_t)red[16] | ((uint64_t)red[17] << 32)) + wbase;
 #pragma unroll
-                for (int t = 0; t < MR_IT; t++)
+                for (int t = 0; t < IT; t++)
 #pragma unroll
                     for (int e = 0; e < MR_NE(t); e++) {
                         const int j = t * 4 + e;

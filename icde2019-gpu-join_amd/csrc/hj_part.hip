@@ -620,12 +620,11 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const int32_t *__rest
 // contiguous region of fixed size, which is what travels to GPU g.  FEW: at most 4 digits — ranks are taken with the
 // wave-aggregated atomic (nearly every lane would otherwise queue on one of a few LDS words).
 template <int U, int MODE, bool FEW>
-__global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void part1_fast_body(const FastArgs &a, const uint32_t s, unsigned char *smem) {
     WfLds L_;
     wf_carve(L_, smem);
     if (__hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // an earlier workgroup gave up already
-    const uint32_t tid = threadIdx.x, s = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint64_t lo = (uint64_t)s * a.span < a.n ? (uint64_t)s * a.span : a.n; // a span past the end (short slice of a multi-GPU split): empty
     const uint64_t hi = lo + a.span < a.n ? lo + a.span : a.n;
     FastGeom g{s, a.nspans, a.cap};
@@ -635,6 +634,21 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
     __syncthreads();
     if (MODE == 0 && a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, false, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 0, false, FEW, false, MODE>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+template <int U, int MODE, bool FEW>
+__global__ __launch_bounds__(WC_THREADS) void k_part1_fast(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    part1_fast_body<U, MODE, FEW>(a, blockIdx.x, smem);
+}
+// Both relations of a join in ONE launch per pass (hj_api.hip partition_both, small and medium inputs): workgroups [0, a.nspans) are
+// relation a's spans, the rest relation b's.  A step is then three data-moving launches on one stream instead of five on two
+// (the reference's shape: launch after launch on one stream, jp.cu:1582-1613), and the second relation's workgroups fill the CUs
+// the first one's tail leaves idle without an event fork and join.
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part1_fast2(FastArgs a, FastArgs b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x < a.nspans) part1_fast_body<U, 0, false>(a, blockIdx.x, smem);
+    else part1_fast_body<U, 0, false>(b, blockIdx.x - a.nspans, smem);
 }
 
 // ---- the sampled path of skewed relations: histogram-free passes with per-digit slot capacities and LDS lines dealt by
@@ -795,12 +809,13 @@ hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n,
 
 // pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
 template <int U>
-__global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void part2_fast_body(const FastArgs &a, const uint32_t parent, unsigned char *smem) {
+    // (the join's planning kernel reserves item slots on a counter: zeroed here, by the kernel that always runs just before it)
+    if (a.zero_items && parent == 0 && threadIdx.x == 0) *a.zero_items = 0;
     if (*a.ovf) return; // pass 1 gave up: the exact passes take over
     WfLds L_;
     wf_carve(L_, smem);
-    const uint32_t tid = threadIdx.x, parent = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
     // pass 2: child c of parent d -> slot d*P + c.  seg_pass1 (multi-GPU, hj_dist.hip): the workgroup is span span0 + parent of
     // a pass 1 whose input arrives as segments (the slots received from every peer): digit d -> slot (d, span0 + parent)
     const FastGeom g = a.seg_pass1 ? FastGeom{a.span0 + parent, a.nspans, a.cap} : FastGeom{parent * a.P, 1u, a.cap};
@@ -824,6 +839,17 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
     __syncthreads();
     if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+}
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    part2_fast_body<U>(a, blockIdx.x, smem);
+}
+template <int U>
+__global__ __launch_bounds__(WC_THREADS) void k_part2_fast2(FastArgs a, FastArgs b) { // both relations: see k_part1_fast2
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x < a.nparents) part2_fast_body<U>(a, blockIdx.x, smem);
+    else part2_fast_body<U>(b, blockIdx.x - a.nparents, smem);
 }
 
 // tuples per shard (MODE 1 digit, no remap): per-workgroup LDS histogram, one global atomic per shard per workgroup
@@ -1104,6 +1130,24 @@ hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa) {
     hipError_t e = fast_attr(fn, set);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(fa.nparents), dim3(WC_THREADS), fast_lds_bytes(), st, fa);
+    return hipGetLastError();
+}
+
+hipError_t launch_part1_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb) {
+    static bool set[64] = {};
+    auto fn = k_part1_fast2<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(fa.nspans + fb.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_part2_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb) {
+    static bool set[64] = {};
+    auto fn = k_part2_fast2<2>;
+    hipError_t e = fast_attr(fn, set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(fa.nparents + fb.nparents), dim3(WC_THREADS), fast_lds_bytes(), st, fa, fb);
     return hipGetLastError();
 }
 

@@ -279,8 +279,8 @@ int hj_join_stream_probe_materialize(hj_ctx *c, const int32_t *h_keys, const int
 // the host splits them into level-0 partitions (16-way on 16 threads in the reference, hjcp.cu:1256-1266,
 // pp.cuh:38-39), and every level-0 partition pair is an independent join (hjcp.cu:1503-1618): uploaded
 // over PCIe into double-buffered staging while the previous pair is partitioned and joined on the GPU.
-// The reference's residency knapsack (groupOptimal2, pp.cu:307-468) is not needed: one pair is resident
-// at a time and level0_parts is chosen so that it fits.
+// Pairs that fit the device-memory budget together form a residency group (first-fit decreasing: the role of the reference's
+// knapsack, groupOptimal2, pp.cu:307-468); with one group R is uploaded while the host still splits S.
 int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64_t nR, const int32_t *h_S,
                       const int32_t *h_Ps, uint64_t nS, uint32_t level0_parts, uint32_t host_threads, uint64_t *matches,
                       uint64_t *agg) {
@@ -326,75 +326,119 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     c->numa_pinned_cpus = (int)pin.size();
     // host split; the partitioned copies are pinned so that the uploads are asynchronous.  The staging buffers belong
     // to the context and only ever grow: a caller that joins in a loop pins host memory once.
+    // Payload columns that are not given (= ones, what the reference synthesises, hjcp.cu:1994-1999) are neither split nor
+    // uploaded: the device fills its staging payload columns with ones once per call — half the split's stores and half the
+    // PCIe bytes of round 4's version.
     int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
     const uint64_t nn[2] = {nR, nS};
     const int32_t *srcK[2] = {h_R, h_S}, *srcP[2] = {h_Pr, h_Ps};
     std::vector<uint64_t> off[2];
     int rc = 0;
-    const auto t_split0 = std::chrono::steady_clock::now();
     for (int r = 0; r < 2 && !rc; r++) {
-        if (c->host_cap[r] < nn[r] + 16) {
+        if (c->host_cap[r] < nn[r] + 16 || (srcP[r] && !c->host_p[r])) {
             if (c->host_k[r]) (void)hipHostFree(c->host_k[r]);
             if (c->host_p[r]) (void)hipHostFree(c->host_p[r]);
             c->host_k[r] = c->host_p[r] = nullptr; c->host_cap[r] = 0;
             if (hipHostMalloc((void **)&c->host_k[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void **)&c->host_p[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess)
+                (srcP[r] && hipHostMalloc((void **)&c->host_p[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess))
                 rc = fail(c, HJ_ENOMEM, "pinned host buffers for the level-0 split");
             else c->host_cap[r] = nn[r] + 16;
         }
-        if (!rc) {
-            pk[r] = c->host_k[r]; pp[r] = c->host_p[r];
-            if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r], pin.empty() ? nullptr : &pin))
-                rc = fail(c, HJ_ENOMEM, "could not start %u host threads for the level-0 split", host_threads);
+        pk[r] = c->host_k[r]; pp[r] = srcP[r] ? c->host_p[r] : nullptr;
+    }
+    // Device-memory budget of a residency group: staging (double buffered) + both relations' partition buffers ~ 35 bytes per tuple,
+    // half of what the card can give this context — the free memory PLUS what the context already holds in buffers this call reuses
+    // (round 4 looked at the free memory alone: the second identical call saw less and could cut more groups).
+    // HJ_COPROCESS_GROUP_TUPLES overrides (tests force small groups).  On a 288-GB card everything up to ~2^31 tuples is one group.
+    uint64_t budget = 0;
+    if (const char *e = getenv("HJ_COPROCESS_GROUP_TUPLES")) budget = strtoull(e, nullptr, 10);
+    if (!budget) {
+        size_t free_b = 0, total_b = 0, held = 0;
+        for (int i = 0; i < 2; i++) held += c->cop_k[i].cap + c->cop_p[i].cap + c->seg_k[i].cap + c->seg_p[i].cap +
+                                            c->rel[i].a_k.cap + c->rel[i].a_p.cap + c->rel[i].b_k.cap + c->rel[i].b_p.cap;
+        budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? ((uint64_t)free_b + held) / 2 / 35 : ((uint64_t)1 << 28);
+    }
+    if (!rc && !c->copy) { if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) rc = fail(c, HJ_EHIP, "copy stream"); }
+    for (int i = 0; i < 2 && !rc; i++)
+        if (!c->seg_ready[i] && hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
+    const bool one_group = nR + nS <= budget; // known before anything is split: R's upload may then start while S is being split
+    auto split = [&](int r) -> int {
+        if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r], pin.empty() ? nullptr : &pin))
+            return fail(c, HJ_ENOMEM, "the level-0 split of %llu tuples could not allocate its write-combining lines / partition-id column or start its %u host threads",
+                        (unsigned long long)nn[r], host_threads);
+        return 0;
+    };
+    // staging columns of one residency group: R's partitions of the group in cop_k/p[b], S's in seg_k/p[b], each a contiguous run
+    auto ensure_staging = [&](uint64_t maxR, uint64_t maxS) -> int {
+        for (int i = 0; i < 2; i++) {
+            RET(ensure(c, c->cop_k[i], (size_t)(maxR + PAD) * 4)); RET(ensure(c, c->cop_p[i], (size_t)(maxR + PAD) * 4));
+            RET(ensure(c, c->seg_k[i], (size_t)(maxS + PAD) * 4)); RET(ensure(c, c->seg_p[i], (size_t)(maxS + PAD) * 4));
+            // payloads that are not given: ones, filled on the device (the buffers keep them for every group of the call)
+            if (!srcP[0]) HIPCHK(c, launch_fill(c->stream, (int32_t *)c->cop_p[i].p, maxR, HJ_PAYLOAD_ONES, 0));
+            if (!srcP[1]) HIPCHK(c, launch_fill(c->stream, (int32_t *)c->seg_p[i].p, maxS, HJ_PAYLOAD_ONES, 0));
         }
+        return 0;
+    };
+    const auto t_split0 = std::chrono::steady_clock::now();
+    double split_s = 0;
+    if (!rc) rc = split(0);
+    split_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split0).count();
+    // ---- the pipeline (the reference overlaps staging, H2D and the GPU work per batch, hjcp.cu:1477-1618): with one residency group
+    // R crosses PCIe while the host is still splitting S ----
+    bool r_uploaded = false;
+    if (!rc && one_group && nR) {
+        rc = ensure_staging(nR, nS);
+        if (!rc && hipMemcpyAsync(c->cop_k[0].p, pk[0], nR * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess) rc = fail(c, HJ_EHIP, "H2D");
+        if (!rc && pp[0] && hipMemcpyAsync(c->cop_p[0].p, pp[0], nR * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess) rc = fail(c, HJ_EHIP, "H2D");
+        r_uploaded = !rc;
     }
-    {
-        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split0).count();
-        // bytes read + written by the scatter (keys + payloads), like partition-primitives.cu:218
-        c->host_split_gbs = dt > 0 ? 16.0 * (double)(nR + nS) / dt / 1e9 : 0;
-    }
-    // Residency groups (the reference schedules which level-0 partitions are resident together with a knapsack over PARTS_RESIDENT
-    // slots, groupOptimal2, pp.cu:307-468 / hjcp.cu:1357-1363).  Here a group is a run of CONSECUTIVE level-0 pairs — contiguous in the
-    // split arrays, so one upload per column and ONE join per group — as long as the group's tuples fit the budget: staging (double
-    // buffered) + both relations' partition buffers ~ 35 bytes per tuple, half of the free device memory (HJ_COPROCESS_GROUP_TUPLES
-    // overrides: tests force small groups).  On a 288-GB card everything up to ~2^31 tuples is one group.
-    std::vector<uint32_t> gstart;
+    const auto t_split1 = std::chrono::steady_clock::now();
+    if (!rc) rc = split(1);
+    split_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split1).count();
+    // bytes read + written by the scatter (keys, + payloads where given), like partition-primitives.cu:218
+    c->host_split_gbs = split_s > 0 ? ((srcP[0] ? 16.0 : 8.0) * (double)nR + (srcP[1] ? 16.0 : 8.0) * (double)nS) / split_s / 1e9 : 0;
+    // Residency groups (the reference decides which level-0 partitions are resident together with a knapsack over PARTS_RESIDENT
+    // slots, groupOptimal2, pp.cu:307-468 / hjcp.cu:1357-1363): first-fit decreasing over the pairs' sizes — the big pairs open the
+    // groups, the small ones fill them up — so a skewed split needs no more groups than its bytes ask for.  Every group is uploaded
+    // pair by pair into contiguous staging columns and joined by ONE hj_join.
+    std::vector<std::vector<uint32_t>> groups;
     if (!rc) {
-        uint64_t budget = 0;
-        if (const char *e = getenv("HJ_COPROCESS_GROUP_TUPLES")) budget = strtoull(e, nullptr, 10);
-        if (!budget) {
-            size_t free_b = 0, total_b = 0;
-            budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? (uint64_t)free_b / 2 / 35 : ((uint64_t)1 << 28);
+        std::vector<uint32_t> by(level0_parts);
+        for (uint32_t p = 0; p < level0_parts; p++) by[p] = p;
+        auto size_of = [&](uint32_t p) { return (off[0][p + 1] - off[0][p]) + (off[1][p + 1] - off[1][p]); };
+        if (!one_group) std::stable_sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return size_of(x) > size_of(y); });
+        std::vector<uint64_t> load;
+        for (uint32_t p : by) {
+            size_t g = 0;
+            while (g < groups.size() && load[g] + size_of(p) > budget) g++;
+            if (g == groups.size()) { groups.emplace_back(); load.push_back(0); }
+            groups[g].push_back(p); load[g] += size_of(p);
         }
-        uint64_t cur = 0;
-        for (uint32_t p = 0; p < level0_parts; p++) {
-            const uint64_t t = (off[0][p + 1] - off[0][p]) + (off[1][p + 1] - off[1][p]);
-            if (p == 0 || cur + t > budget) { gstart.push_back(p); cur = 0; }
-            cur += t;
-        }
-        gstart.push_back(level0_parts);
     }
-    const uint32_t ngroups = gstart.empty() ? 0u : (uint32_t)gstart.size() - 1;
+    const uint32_t ngroups = (uint32_t)groups.size();
     c->coprocess_groups = ngroups;
     uint64_t maxp[2] = {0, 0};
-    if (!rc)
-        for (int r = 0; r < 2; r++)
-            for (uint32_t g = 0; g < ngroups; g++) maxp[r] = std::max(maxp[r], off[r][gstart[g + 1]] - off[r][gstart[g]]);
-    if (!rc && !c->copy) { if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) rc = fail(c, HJ_EHIP, "copy stream"); }
-    for (int i = 0; i < 2 && !rc; i++) {
-        if (!c->seg_ready[i] && hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
-        if (!rc) rc = ensure(c, c->cop_k[i], (size_t)(maxp[0] + PAD) * 4);
-        if (!rc) rc = ensure(c, c->cop_p[i], (size_t)(maxp[0] + PAD) * 4);
-        if (!rc) rc = ensure(c, c->seg_k[i], (size_t)(maxp[1] + PAD) * 4);
-        if (!rc) rc = ensure(c, c->seg_p[i], (size_t)(maxp[1] + PAD) * 4);
+    std::vector<uint64_t> gsz[2];
+    for (int r = 0; r < 2 && !rc; r++) {
+        gsz[r].assign(ngroups, 0);
+        for (uint32_t g = 0; g < ngroups; g++) {
+            for (uint32_t p : groups[g]) gsz[r][g] += off[r][p + 1] - off[r][p];
+            maxp[r] = std::max(maxp[r], gsz[r][g]);
+        }
     }
+    if (!rc && !r_uploaded) rc = ensure_staging(maxp[0], maxp[1]);
     auto upload = [&](uint32_t g) -> int {
         const int b = (int)(g & 1);
-        const uint64_t r0 = off[0][gstart[g]], rn = off[0][gstart[g + 1]] - r0, s0 = off[1][gstart[g]], sn = off[1][gstart[g + 1]] - s0;
-        if (rn) { HIPCHK(c, hipMemcpyAsync(c->cop_k[b].p, pk[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy));
-                  HIPCHK(c, hipMemcpyAsync(c->cop_p[b].p, pp[0] + r0, rn * 4, hipMemcpyHostToDevice, c->copy)); }
-        if (sn) { HIPCHK(c, hipMemcpyAsync(c->seg_k[b].p, pk[1] + s0, sn * 4, hipMemcpyHostToDevice, c->copy));
-                  HIPCHK(c, hipMemcpyAsync(c->seg_p[b].p, pp[1] + s0, sn * 4, hipMemcpyHostToDevice, c->copy)); }
+        uint64_t at[2] = {0, 0};
+        for (uint32_t p : groups[g])
+            for (int r = 0; r < 2; r++) {
+                const uint64_t o = off[r][p], cnt = off[r][p + 1] - o;
+                if (!cnt || (r == 0 && g == 0 && r_uploaded)) { at[r] += cnt; continue; }
+                Buf &dk = r ? c->seg_k[b] : c->cop_k[b], &dp = r ? c->seg_p[b] : c->cop_p[b];
+                HIPCHK(c, hipMemcpyAsync((int32_t *)dk.p + at[r], pk[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
+                if (pp[r]) HIPCHK(c, hipMemcpyAsync((int32_t *)dp.p + at[r], pp[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
+                at[r] += cnt;
+            }
         HIPCHK(c, hipEventRecord(c->seg_ready[b], c->copy));
         return 0;
     };
@@ -405,11 +449,10 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         if (g + 1 < ngroups && (rc = upload(g + 1))) break; // the other pair of buffers was joined + synchronised last round
         hipError_t e = hipStreamWaitEvent(c->stream, c->seg_ready[b], 0);
         if (e != hipSuccess) { rc = fail(c, HJ_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
-        const uint64_t rn = off[0][gstart[g + 1]] - off[0][gstart[g]], sn = off[1][gstart[g + 1]] - off[1][gstart[g]];
-        if ((rc = hj_bind_device(c, HJ_REL_R, (const int32_t *)c->cop_k[b].p, (const int32_t *)c->cop_p[b].p, rn))) break;
-        if ((rc = hj_bind_device(c, HJ_REL_S, (const int32_t *)c->seg_k[b].p, (const int32_t *)c->seg_p[b].p, sn))) break;
+        if ((rc = hj_bind_device(c, HJ_REL_R, (const int32_t *)c->cop_k[b].p, (const int32_t *)c->cop_p[b].p, gsz[0][g]))) break;
+        if ((rc = hj_bind_device(c, HJ_REL_S, (const int32_t *)c->seg_k[b].p, (const int32_t *)c->seg_p[b].p, gsz[1][g]))) break;
         uint64_t m = 0, a = 0;
-        if ((rc = hj_join(c, &m, &a))) break; // [sync]; the next pair is already on its way
+        if ((rc = hj_join(c, &m, &a))) break; // [sync]; the next group is already on its way
         tot_m += m; tot_a += a;
     }
     (void)hipStreamSynchronize(c->copy);
