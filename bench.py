@@ -567,6 +567,52 @@ def strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier):
             "workload": "2^%d ⋈ 2^%d unique uniform int32 in total, 1/%d of each relation per GPU, count-only" % (a.log2n, a.log2n, world)}
 
 
+def alt_transport_leg(a, pkg, torch, world, n, domain, expect):
+    """N > 1, rank 0 only, after every other rank has released its GPU: the SAME workload driven by ONE process (hj_dist: one host
+    thread per GPU) over both transports of one group — RCCL's send/recv kernels, then the copy engines (hipMemcpyPeerAsync over
+    xGMI; hj_dist_set_transport keeps contexts, inputs and buffers) — so that the first multi-GPU session answers DESIGN §7's two open
+    questions in one run: what RCCL's kernels cost beside 155-KiB-LDS pass workgroups, and what a link sustains at these message
+    sizes.  Recorded under dist.alt_transport; the headline stays the one-process-per-GPU RCCL run above."""
+    from importlib import import_module
+    D = import_module(pkg.__name__ + ".dist")
+    out = {"driver": "hj_dist (ONE process, one host thread per GPU; inputs regenerated per GPU with the headline's generator and seeds)"}
+    slices_list = [a.slices] + ([8] if os.environ.get("HJ_BENCH_SLICE_SWEEP") and a.slices != 8 else [])
+    with D.GroupJoin(list(range(world)), transport="rccl") as g:
+        keep = []
+        for r in range(world):
+            dev = torch.device("cuda", r)
+            cols = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
+            hj = g.context(r)
+            hj.gen_unique(cols[0], n, r * n, domain, 1)
+            hj.gen_unique(cols[2], n, r * n, domain, 2)
+            hj.fill_payload(cols[1], n, "ones")
+            hj.fill_payload(cols[3], n, "ones")
+            hj.sync()
+            keep.append(cols)
+            g.bind(r, pkg.REL_R, cols[0], cols[1])
+            g.bind(r, pkg.REL_S, cols[2], cols[3])
+        for transport in ("rccl", "copy"):
+            for sl in slices_list:
+                g.set_transport(transport)
+                g.configure(slices=sl, exact_only=a.exact_only, single_group=a.single_group)
+                for _ in range(max(1, a.warmup)):
+                    assert g.join()[0] == expect
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    got = g.join()[0]
+                dt = (time.perf_counter() - t0) / a.steps
+                assert got == expect
+                st = g.stats(0)
+                per_peer = st["link_bytes"] / max(1, world - 1)
+                key = g.transport + ("" if sl == a.slices else "_slices%d" % sl)
+                out[key] = {"ms_per_step": round(dt * 1e3, 3), "value": round(2.0 * n * world / dt / 1e9, 3), "unit": "billion tuples/s",
+                            "path": st["path"], "slices": st["slices"], "exchange_ms": round(st["exchange_ms"], 3),
+                            "link_GBs_per_direction": round(per_peer / (st["exchange_ms"] * 1e-3) / 1e9, 2) if st["exchange_ms"] > 0 else None,
+                            "rank0_stage_ms": {k: st[k] for k in ("split_ms", "pass1_ms", "pass2_join_ms", "early_pass2_join_ms", "first_split_ms", "last_pass1_ms")}}
+        del keep
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; default: WORLD_SIZE under a launcher, else 1")
@@ -594,12 +640,23 @@ def main():
                          "locally instead of crossing a link) and model the link time beside the measured local stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-materialize", action="store_true")
+    ap.add_argument("--alt-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-alt-transport", action="store_true", help="N > 1: skip the one-process leg that times the same workload over RCCL and over the copy engines")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg (2^log2n tuples per relation in TOTAL, 1/N per GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM ceilings and the phase split (profiling runs)")
     a = ap.parse_args()
     if a.gpus is None:   # `torchrun ... bench.py` without --gpus: the launcher's world size is the GPU count
         a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
+    if a.alt_child:   # the one-process two-transport leg of an N > 1 run (started by rank 0 of that run, see below)
+        import torch
+        pkg = graft.load_package()
+        n = 1 << a.log2n
+        total_n = n * a.gpus
+        domain = min(total_n, 1 << 32)
+        expect = total_n * max(1, total_n // domain)
+        print(json.dumps({"alt_transport": alt_transport_leg(a, pkg, torch, a.gpus, n, domain, expect)}))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, RCCL over
         # xGMI) before anything here touches the GPU, forward rank 0's JSON line and the launcher's exit code.
@@ -632,6 +689,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     cdev = torch.device("cpu") if backend == "gloo" else dev   # where tensors of small collectives live
+    # a CPU-side group for the end of the run: while rank 0 drives every GPU from one process (alt_transport_leg) the other ranks
+    # must wait WITHOUT a collective kernel spinning on their GPU
+    quiet = dist.new_group(backend="gloo") if (use_dist and world > 1 and backend != "gloo") else None
     pkg = graft.load_package()
     n = 1 << a.log2n
     total_n = n * world
@@ -935,6 +995,37 @@ def main():
                              % (hj_cfg_bits[0], hj_cfg_bits[1], ms_per_step)}
         hj.configure()
 
+    # ---- N > 1: both transports on the same workload, one process driving every GPU (rank 0), the others quiet ----
+    alt = None
+    final_cfg = hj.config()
+    if use_dist and c_impl and world > 1 and quiet is not None and not a.no_alt_transport:
+        if dj is not None:
+            dj.close()
+        hj.close()
+        del Rk, Rp, Sk, Sp
+        torch.cuda.empty_cache()
+        dist.barrier(group=quiet)           # every rank has released its GPU
+        if rank == 0:
+            # in a CHILD process with a deadline: the headline is already measured, and a communicator that does not come up (or a
+            # crash) in this extra leg must cost a note in the line, not the line
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                   "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--alt-child", "--gpus", str(world), "--log2n", str(a.log2n), "--steps", str(a.steps),
+                   "--warmup", str(a.warmup), "--slices", str(a.slices)] + (["--exact-only"] if a.exact_only else []) + (["--single-group"] if a.single_group else [])
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=float(os.environ.get("HJ_BENCH_ALT_TIMEOUT_S", "600")))
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"alt_transport"' in l]
+                alt = json.loads(lines[-1])["alt_transport"] if (p.returncode == 0 and lines) else {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-600:])}
+            except subprocess.TimeoutExpired:
+                alt = {"error": "the one-process leg did not finish within its deadline"}
+            except Exception as e:   # noqa: BLE001
+                alt = {"error": repr(e)}
+        dist.barrier(group=quiet)
+        hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)   # (the CPU baseline below generates its sample on the GPU)
+    if dist_info is not None:
+        dist_info["alt_transport"] = alt
+
     cpu = None
     if rank == 0 and not a.no_cpu_baseline and not (a.phantom > 1):
         # rank 0 at every N (the other ranks wait at the final barrier): the same bounded sample of the per-GPU workload
@@ -943,7 +1034,7 @@ def main():
         cpu["joinCpu"] = join_cpu_baseline(hj, torch, dev, cpu["cores"])
 
     if rank == 0:
-        cfg = hj.config()
+        cfg = final_cfg
         cfg["bits1"], cfg["bits2"] = hj_cfg_bits
         line = {
             "metric": ("billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)

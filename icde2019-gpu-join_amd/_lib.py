@@ -111,6 +111,7 @@ SIGNATURES = {
     "hj_write_relation": (C.c_int, [C.c_char_p, vp, C.c_uint64]),
     "hj_dist_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]),
     "hj_dist_create_transport": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_char_p]),
+    "hj_dist_set_transport": (C.c_int, [vp, C.c_char_p]),
     "hj_dist_destroy": (C.c_int, [vp]),
     "hj_dist_error": (C.c_char_p, [vp]),
     "hj_dist_world": (C.c_int, [vp]),

@@ -367,6 +367,8 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     };
     // pass 1
     // spans like the exact passes' (four per CU): the pieces are uneven under skew, many of them balance better than few
+    if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
+    if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
     const uint32_t target = c->target_spans ? c->target_spans : TARGET_SPANS;
     uint64_t span = (R.n + target - 1) / target;
     span = ((span + TILE - 1) / TILE) * TILE;
@@ -481,7 +483,7 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     Rel &R = c->rel[r];
     Rel::Sampled &sp = R.sp;
     *done = false;
-    if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2) {
+    if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2 || getenv("HJ_REPLAN")) {
         sp.valid = false;
         const int rc = plan_sampled(c, R, b1, b2);
         if (rc < 0) return rc;
@@ -541,7 +543,9 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     // checked here before anything is (re)allocated — pass-1 and final buffers of both columns, ~1.14 x 16 bytes per tuple on top
     // of the input (the reference's CLI accepts up to ULONG_MAX/4 tuples, main.cu:491-514).
     if (R.n > ((uint64_t)1 << 34)) return fail(c, HJ_EINVAL, "relation too large (n <= 2^34 tuples: pass-2 parents are addressed in 32-bit units)");
+    if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // (experiment knobs are read per call: same-context A/B)
     if (c->force_sampled & (1 << r)) R.prefer_exact = true; // experiment knob: this relation takes the sampled path whatever its distribution
+    else if (c->force_sampled & (4 << r)) { R.prefer_exact = false; R.sampled_failed = false; } // bits 2, 3: forget what was learned (back to the plain passes)
     choose_bits(c);
     bool histogram_free = false; // the relation will take the plain or the sampled histogram-free passes (neither reads R.root)
     {

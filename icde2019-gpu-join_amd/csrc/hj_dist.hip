@@ -1130,6 +1130,7 @@ struct hj_dist {
     int world = 0;
     std::vector<hj_dist_rank *> ranks;
     std::unique_ptr<CopyGroup> copy;
+    std::vector<int> dev;                    // HIP device of every rank
     std::string err, transport;
     struct Bound { const int32_t *k = nullptr, *p = nullptr; uint64_t n = 0; } bound[64][2];
     MatOut outb[64];
@@ -1137,71 +1138,94 @@ struct hj_dist {
 
 extern "C" {
 
+// The links of a group: made at creation and again by hj_dist_set_transport (the ranks, their contexts and every buffer stay).
+// want: "" / "auto" ($HJ_DIST_TRANSPORT, else RCCL for distinct devices and device copies for shared ones), "rccl", "device-copy".
+static int make_links(hj_dist *d, std::string want) {
+    const int nranks = d->world;
+    const std::vector<int> &dev = d->dev;
+    bool distinct = true;
+    for (int r = 0; r < nranks; r++) for (int q = 0; q < r; q++) distinct &= dev[q] != dev[r];
+    if (want.empty() || want == "auto") { const char *e = getenv("HJ_DIST_TRANSPORT"); want = e ? e : ""; }
+    if (want == "copy") want = "device-copy";
+    if (!want.empty() && want != "auto" && want != "rccl" && want != "device-copy") { d->err = "unknown transport '" + want + "' (rccl, device-copy = copy, auto)"; return HJ_EINVAL; }
+    if (want == "rccl" && !distinct) { d->err = "RCCL refuses ranks that share a device: device-copy is the transport of such a group"; return HJ_EINVAL; }
+    const bool use_rccl = want == "rccl" || ((want.empty() || want == "auto") && distinct);
+    std::vector<ncclComm_t> comms(nranks, nullptr);
+    std::unique_ptr<CopyGroup> copy;
+    if (use_rccl) {
+        if (!rccl().ok || rccl().CommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { d->err = "ncclCommInitAll failed"; return HJ_EHIP; }
+    } else {
+        copy.reset(new CopyGroup(nranks));
+        copy->dev = dev;
+        copy->timeout_s = (!d->ranks.empty() && d->ranks[0]->cfg.timeout_ms) ? d->ranks[0]->cfg.timeout_ms * 1e-3 : env_timeout_s();
+        // distinct devices: every rank reads its peers' regions directly (xGMI peer access)
+        for (int r = 0; r < nranks && distinct; r++) {
+            if (hipSetDevice(dev[r]) != hipSuccess) return HJ_EHIP;
+            for (int q = 0; q < nranks; q++) {
+                if (q == r) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev[r], dev[q]) != hipSuccess || !can) { d->err = "no peer access between the devices of ranks " + std::to_string(r) + " and " + std::to_string(q); return HJ_EHIP; }
+                const hipError_t e = hipDeviceEnablePeerAccess(dev[q], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return HJ_EHIP;
+                (void)hipGetLastError();
+            }
+        }
+        for (int r = 0; r < nranks; r++)
+            if (hipSetDevice(dev[r]) != hipSuccess || hipEventCreateWithFlags(&copy->ready[r], hipEventDisableTiming) != hipSuccess) {
+                for (auto e : copy->ready) if (e) (void)hipEventDestroy(e);
+                return HJ_EHIP;
+            }
+    }
+    // the old links go (a healthy group: drained first), the new ones come
+    for (int r = 0; r < nranks; r++) {
+        hj_dist_rank *k = d->ranks[r];
+        if (k->link) { (void)hipSetDevice(dev[r]); if (!k->link->failed(nullptr) && k->comm) (void)hipStreamSynchronize(k->comm); k->link.reset(); }
+    }
+    if (d->copy) for (auto e : d->copy->ready) if (e) (void)hipEventDestroy(e);
+    d->copy = std::move(copy);
+    for (int r = 0; r < nranks; r++) {
+        hj_dist_rank *k = d->ranks[r];
+        if (use_rccl) { RcclLink *l = new RcclLink(); l->comm = comms[r]; l->rank = r; l->world = nranks; k->link.reset(l); }
+        else { CopyLink *l = new CopyLink(); l->g = d->copy.get(); l->rank = r; k->link.reset(l); }
+        memset(k->agreed, 0, sizeof k->agreed);
+    }
+    d->transport = use_rccl ? "rccl" : "device-copy";
+    return HJ_OK;
+}
+
 int hj_dist_create_transport(hj_dist **out, int nranks, const int *devices, const char *transport) {
     if (!out) return HJ_EINVAL;
     *out = nullptr;
     if (nranks < 1 || nranks > 64) return HJ_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HJ_EHIP; // no GPU: fail loudly
-    std::vector<int> dev(nranks);
-    bool distinct = true;
-    for (int r = 0; r < nranks; r++) {
-        dev[r] = devices ? devices[r] : r;
-        if (dev[r] < 0 || dev[r] >= ndev) return HJ_EINVAL; // fewer GPUs visible than ranks asked for
-        for (int q = 0; q < r; q++) distinct &= dev[q] != dev[r];
-    }
-    std::string want = transport ? transport : "";
-    if (want.empty() || want == "auto") { const char *e = getenv("HJ_DIST_TRANSPORT"); want = e ? e : ""; }
-    if (want == "copy") want = "device-copy";
-    if (!want.empty() && want != "auto" && want != "rccl" && want != "device-copy") return HJ_EINVAL;
-    if (want == "rccl" && !distinct) return HJ_EINVAL; // RCCL refuses duplicate GPUs
-    const bool use_rccl = want == "rccl" || ((want.empty() || want == "auto") && distinct);
     hj_dist *d = new hj_dist();
     d->world = nranks;
-    std::vector<ncclComm_t> comms(nranks, nullptr);
-    if (use_rccl) {
-        if (!rccl().ok || rccl().CommInitAll(comms.data(), nranks, dev.data()) != ncclSuccess) { delete d; return HJ_EHIP; }
-        d->transport = "rccl";
-    } else {
-        d->copy.reset(new CopyGroup(nranks));
-        d->copy->dev = dev;
-        d->copy->timeout_s = env_timeout_s();
-        d->transport = "device-copy";
-        // distinct devices: every rank reads its peers' regions directly (xGMI peer access)
-        for (int r = 0; r < nranks && distinct; r++) {
-            if (hipSetDevice(dev[r]) != hipSuccess) { delete d; return HJ_EHIP; }
-            for (int q = 0; q < nranks; q++) {
-                if (q == r) continue;
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, dev[r], dev[q]) != hipSuccess || !can) { delete d; return HJ_EHIP; }
-                const hipError_t e = hipDeviceEnablePeerAccess(dev[q], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { delete d; return HJ_EHIP; }
-                (void)hipGetLastError();
-            }
-        }
+    d->dev.resize(nranks);
+    for (int r = 0; r < nranks; r++) {
+        d->dev[r] = devices ? devices[r] : r;
+        if (d->dev[r] < 0 || d->dev[r] >= ndev) { delete d; return HJ_EINVAL; } // fewer GPUs visible than ranks asked for
     }
     int rc = 0;
-    size_t wrapped = 0; // communicators handed to a rank (its RcclLink owns and destroys them)
     for (int r = 0; r < nranks && !rc; r++) {
         hj_dist_rank *k = new hj_dist_rank();
         d->ranks.push_back(k);
         k->rank = r; k->world = nranks; k->own_ctx = true;
-        rc = hj_create(&k->c, dev[r]);
-        if (rc) break;
-        if (use_rccl) { RcclLink *l = new RcclLink(); l->comm = comms[r]; l->rank = r; l->world = nranks; k->link.reset(l); wrapped = (size_t)r + 1; }
-        else {
-            CopyLink *l = new CopyLink(); l->g = d->copy.get(); l->rank = r; k->link.reset(l);
-            if (hipSetDevice(dev[r]) != hipSuccess || hipEventCreateWithFlags(&d->copy->ready[r], hipEventDisableTiming) != hipSuccess) rc = HJ_EHIP;
-        }
+        rc = hj_create(&k->c, d->dev[r]);
         if (!rc) rc = rank_init(k);
     }
-    if (rc) {
-        for (size_t r = wrapped; use_rccl && r < comms.size(); r++) if (comms[r]) (void)rccl().CommDestroy(comms[r]); // not owned by any rank yet
-        hj_dist_destroy(d);
-        return rc;
-    }
+    if (!rc) rc = make_links(d, transport ? transport : "");
+    if (rc) { hj_dist_destroy(d); return rc; }
     *out = d;
     return HJ_OK;
+}
+
+// Another transport for the SAME group (contexts, bound columns, every buffer stay): what a multi-GPU node uses to time one workload
+// over RCCL's kernels and over the copy engines back to back (bench.py dist.alt_transport).  On failure the group keeps its links.
+int hj_dist_set_transport(hj_dist *d, const char *transport) {
+    if (!d) return HJ_EINVAL;
+    for (auto *k : d->ranks) { std::string why; if (k->link && k->link->failed(&why)) { d->err = "the group was aborted (" + why + "): create a new one"; return HJ_EHIP; } }
+    return make_links(d, transport ? transport : "");
 }
 
 int hj_dist_create(hj_dist **out, int nranks, const int *devices) { return hj_dist_create_transport(out, nranks, devices, nullptr); }

@@ -279,6 +279,10 @@ class GroupJoin:
     def transport(self):
         return self._L.hj_dist_transport(self._h).decode()
 
+    def set_transport(self, transport):
+        """hj_dist_set_transport: the same group (contexts, bindings, buffers) over "rccl" or "copy"."""
+        self._ck(self._L.hj_dist_set_transport(self._h, transport.encode() if transport else None))
+
     def context(self, rank):
         """The rank's HashJoin context (borrowed: owned by the group) — configure radix bits, generate inputs with it."""
         hj = _HashJoin.__new__(_HashJoin)

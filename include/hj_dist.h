@@ -92,6 +92,10 @@ int hj_dist_create(hj_dist **out, int nranks, const int *devices);
  * 155-KiB-LDS pass workgroups that run beside the exchange; peer access is enabled between distinct devices), or NULL / "" / "auto"
  * = $HJ_DIST_TRANSPORT, else rccl for distinct devices and device-copy for shared ones (what hj_dist_create does). */
 int hj_dist_create_transport(hj_dist **out, int nranks, const int *devices, const char *transport);
+/* The same group over another transport (contexts, bound columns and every buffer stay): a multi-GPU node times one workload over
+ * RCCL's kernels and over the copy engines back to back with it.  HJ_EINVAL for a name the devices do not allow (the group keeps
+ * the links it had). */
+int hj_dist_set_transport(hj_dist *d, const char *transport);
 int hj_dist_destroy(hj_dist *d);
 const char *hj_dist_error(const hj_dist *d);
 int hj_dist_world(const hj_dist *d);

@@ -381,6 +381,42 @@ def test_materialising_join_rccl_world1():
     st = _run_materialize([0], R, S, dist_cfg=dict(exact_only=True, self_via_link=True), expect_paths="exact")
 
 
+def test_transport_switch_over_inside_one_group():
+    """hj_dist_set_transport: ONE group, its contexts, bindings and buffers kept, joined over RCCL, then over the
+    device-copy transport, then over RCCL again — what bench.py --gpus N does on a multi-GPU node to time both transports on the
+    same workload.  World 1 is what one GPU allows for RCCL; at world 2 and 3 on one GPU the device-copy links are rebuilt in place
+    and a transport the devices do not allow is refused without harming the group."""
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(150_000, 350_000, 41, "unique")
+    with D.GroupJoin([0], transport="rccl") as g:
+        g.context(0).configure(bits1=5, bits2=4)
+        keep = _bind_group(g, P, 1, R, S)
+        g.configure(slices=2, self_via_link=True)
+        seen = []
+        for t in ("rccl", "copy", "rccl", "device-copy"):
+            g.set_transport(t)
+            seen.append(g.transport)
+            assert g.join()[0] == len(S)
+            st = g.stats(0)
+            assert st["path"] == "sliced" and st["exchange_ms"] > 0
+        assert seen == ["rccl", "device-copy", "rccl", "device-copy"]
+        del keep
+    for world in (2, 3):
+        with D.GroupJoin([0] * world) as g:
+            for r in range(world):
+                g.context(r).configure(bits1=5, bits2=4)
+            keep = _bind_group(g, P, world, R, S)
+            g.configure(slices=3)
+            assert g.join()[0] == len(S)
+            with pytest.raises(P.HJError):
+                g.set_transport("rccl")                     # ranks share a device: refused, the group keeps its links
+            assert g.transport == "device-copy" and g.join()[0] == len(S)
+            g.set_transport("copy")                         # rebuilt in place
+            assert g.join()[0] == len(S) and sum(g.stats(r)["received"][1] for r in range(world)) == len(S)
+            del keep
+
+
 def test_more_ranks_than_gpus_is_refused():
     P = pkg()
     D = import_module(P.__name__ + ".dist")
