@@ -829,10 +829,18 @@ def main():
 
     # ---- N > 1 (or the multi-GPU path on one GPU): the materialising sharded join and the strong-scaling point ----
     dist_mat, strong = None, None
+    # (the headline above is measured: a failure in one of the extra legs is recorded in the line, it does not take the line down —
+    # a rank that fails leaves its peers to the deadline of their next collective, after which they fail into the same handler)
     if use_dist and c_impl and not a.no_materialize:
-        dist_mat = dist_materialize_leg(a, pkg, torch, dist, hj, dj, (Rk, Rp, Sk, Sp), n, world, rank, expect, dup, cdev, barrier)
-    if use_dist and c_impl and world > 1 and not a.no_strong:
-        strong = strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier)
+        try:
+            dist_mat = dist_materialize_leg(a, pkg, torch, dist, hj, dj, (Rk, Rp, Sk, Sp), n, world, rank, expect, dup, cdev, barrier)
+        except Exception as e:   # noqa: BLE001
+            dist_mat = {"error": repr(e)}
+    if use_dist and c_impl and world > 1 and not a.no_strong and not (dist_mat or {}).get("error"):
+        try:
+            strong = strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier)
+        except Exception as e:   # noqa: BLE001
+            strong = {"error": repr(e)}
 
     # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)

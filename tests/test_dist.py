@@ -118,6 +118,35 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+@pytest.mark.gpu
+def test_bench_multi_gpu_legs_on_one_gpu():
+    """The N > 1 legs of bench.py that one GPU can run: the sharded MATERIALISING join through hj_dist_rank (world 1 over RCCL,
+    `--force-dist`: digest-checked output, stage times) and the one-process two-transport leg (`--alt-child`: the same group over
+    RCCL, then over the copy engines)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--log2n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    m = line["materialize"]
+    assert m and not m.get("error"), m
+    assert m["output_tuples_total"] == 1 << 24 and m["digest_checked"] and m["path"] == "sliced" and m["output_tuples_per_rank"] == [1 << 24]
+    assert "not the headline" in line["metric"] and line["strong_scaling"] is None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--alt-child", "--gpus", "1", "--log2n", "24", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    alt = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["alt_transport"]
+    assert alt["rccl"]["path"] == "sliced" and alt["device-copy"]["path"] == "sliced" and alt["rccl"]["value"] > 0 and alt["device-copy"]["value"] > 0
+    # a phantom line says what it is
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--phantom", "4", "--log2n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["is_measurement"] is False and "PHANTOM" in line["metric"] and line["materialize"]["model"]["gpus"] == 4
+
+
 def _gpu_count():
     try:
         import torch

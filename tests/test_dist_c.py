@@ -425,6 +425,48 @@ def test_more_ranks_than_gpus_is_refused():
 
 
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs on one node")
+def test_rccl_group_is_destroyed_and_recreated_after_a_deadline():
+    """a rank stalls over RCCL, its peer gives up at the deadline with a collective kernel possibly still on the communication
+    stream; destroying the group must not hang behind it (the link is aborted before any buffer is freed), and a fresh group on the
+    same devices works."""
+    import time
+    P = pkg()
+    D = import_module(P.__name__ + ".dist")
+    R, S = _inputs(400_000, 900_000, 51, "unique")
+    import torch
+    g = D.GroupJoin([0, 1], transport="rccl")
+    keep = []
+    for r in range(2):
+        g.context(r).configure(bits1=6, bits2=4)
+        dev = torch.device("cuda", r)
+        cols = []
+        for X in (R, S):
+            a, b = len(X) * r // 2, len(X) * (r + 1) // 2
+            k = torch.from_numpy(np.ascontiguousarray(X[a:b])).to(dev)
+            cols += [k, torch.ones_like(k)]
+        keep.append(cols)
+        g.bind(r, P.REL_R, cols[0], cols[1])
+        g.bind(r, P.REL_S, cols[2], cols[3])
+    g.configure(slices=3, timeout_ms=1500)
+    assert g.join()[0] == len(S)
+    os.environ["HJ_DIST_TEST_STALL_RANK"] = "2"
+    try:
+        with pytest.raises(P.HJError):
+            g.join()
+    finally:
+        del os.environ["HJ_DIST_TEST_STALL_RANK"]
+    t0 = time.time()
+    g.close()                                            # must come back
+    assert time.time() - t0 < 30.0
+    with D.GroupJoin([0, 1], transport="rccl") as g2:
+        for r in range(2):
+            g2.context(r).configure(bits1=6, bits2=4)
+            g2.bind(r, P.REL_R, keep[r][0], keep[r][1])
+            g2.bind(r, P.REL_S, keep[r][2], keep[r][3])
+        assert g2.join()[0] == len(S)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs on one node")
 def test_rccl_world2_through_the_c_abi():
     """Two GPUs: the same calls over real links (skipped on the one-GPU boxes of this pool)."""
     R, S = _inputs(3_000_000, 7_000_001, 10, "unique")
@@ -433,3 +475,8 @@ def test_rccl_world2_through_the_c_abi():
     R, S = _inputs(200_000, 900_000, 11, "heavy")
     stats, _ = _run([0, 1], R, S, ctx_cfg=dict(bits1=5, bits2=4))
     assert all(s["path"] == "exact" for s in stats)
+    # the materialising join over real links: both paths, every GPU keeps its share
+    R, S = _inputs(300_000, 800_001, 12, "unique")
+    _run_materialize([0, 1], R, S, dist_cfg=dict(slices=3), ctx_cfg=dict(bits1=6, bits2=4), expect_paths="sliced")
+    R, S = _inputs(60_000, 250_000, 13, "heavy")
+    _run_materialize([0, 1], R, S, ctx_cfg=dict(bits1=5, bits2=4), expect_paths="exact")

@@ -1,10 +1,12 @@
 #!/bin/bash
 # the three bench lines that carry roofline.traffic, re-run once the PMC files of THIS binary are in profiles/ (the traffic field is
-# filled only when the lib_sha256 stored in profiles/r4_pmc_*.json equals the running library's).  Every line THREE times, three
+# filled only when the lib_sha256 stored in profiles/${ROUND}_pmc_*.json equals the running library's).  Every line THREE times, three
 # processes back to back: processes on one box differ by up to 10 % (profiles/r4_column_phase.txt), so the documents quote the MEDIAN
 # process and the range (tools/copy_evidence.sh lines picks it).
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r4lines
+ROUND=${ROUND:-r5}
+export ROUND
+OUT=gpurun_out/${ROUND}lines
 mkdir -p $OUT
 sha256sum icde2019-gpu-join_amd/libhj.so
 for i in 1 2 3; do
@@ -13,15 +15,15 @@ for i in 1 2 3; do
   python bench.py --workload zipf --steps 5 --warmup 2 > $OUT/bench_zipf.$i.json 2>/dev/null; echo "rc=$?"
 done
 python3 - <<'PY'
-import json
+import json, os
 for f in ("2p30","2p27","zipf"):
     runs=[]
     for i in (1,2,3):
-        d=[json.loads(l) for l in open("gpurun_out/r4lines/bench_%s.%d.json"%(f,i)) if l.startswith("{")][0]
+        d=[json.loads(l) for l in open("gpurun_out/%slines/bench_%s.%d.json"%(os.environ["ROUND"],f,i)) if l.startswith("{")][0]
         runs.append((d["value"], i, d))
     runs.sort(key=lambda t: t[0])
     v, i, d = runs[1]
     d["three_processes"] = {"values": [r[0] for r in runs], "ms_per_step": [r[2]["ms_per_step"] for r in runs], "this_line": "the median process of three back to back on one box"}
-    open("gpurun_out/r4lines/bench_%s.json"%f,"w").write(json.dumps(d)+"\n")
+    open("gpurun_out/%slines/bench_%s.json"%(os.environ["ROUND"],f),"w").write(json.dumps(d)+"\n")
     print(f, [r[0] for r in runs], "median", v, d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], (d.get("materialize") or {}).get("value"))
 PY

@@ -1,9 +1,10 @@
 #!/bin/bash
-# round-4 evidence: bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/r4prof/ (copy what should be judged
+# the round's evidence (ROUND=r5 by default): bench lines + rocprofv3 kernel stats + PMC passes, all into gpurun_out/${ROUND}prof/ (copy what should be judged
 # into profiles/).  --pmc runs are separate from --kernel-trace --stats runs and never combined with sys/runtime tracing.
 cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
-OUT=$ROOT/gpurun_out/r4prof
+ROUND=${ROUND:-r5}
+OUT=$ROOT/gpurun_out/${ROUND}prof
 mkdir -p $OUT
 cd $ROOT
 sha256sum icde2019-gpu-join_amd/libhj.so > $OUT/libhj.sha256
@@ -27,16 +28,16 @@ cd /tmp
 # relations' kernels overlapped on two streams (the timed steps) a kernel's start-to-end time includes the other kernel's share
 # of the chip.  The variable is exported here: no env/sh hop between rocprofv3 and python3.
 export HJ_FORK_LOG2=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats30 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats30.log 2>&1; echo "stats30 rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats27 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --log2n 27 --no-cpu-baseline > $OUT/stats27.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python3 $ROOT/bench.py --workload zipf --steps 5 --warmup 2 --no-cpu-baseline > $OUT/statszipf.log 2>&1
-for d in stats30 stats27 statszipf; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats30 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-materialize > $OUT/stats30.log 2>&1; echo "stats30 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats27 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --log2n 27 --no-cpu-baseline --no-materialize > $OUT/stats27.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statszipf -- python3 $ROOT/bench.py --workload zipf --steps 5 --warmup 2 --no-cpu-baseline --no-materialize > $OUT/statszipf.log 2>&1
+for d in stats30 stats27 statszipf; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/$d.kernel_stats.csv; rm -rf $OUT/$d; grep '^{' $OUT/$d.log | tail -1 > $OUT/$d.bench_line.json; done
 unset HJ_FORK_LOG2
 cd $ROOT
-tools/pmc_collect.sh r4prof/pmc30
-tools/pmc_collect.sh r4prof/pmc30_mat --with-materialize
-tools/pmc_collect.sh r4prof/pmc27 --log2n 27
-tools/pmc_collect.sh r4prof/pmczipf --workload zipf --warmup 1
-tools/pmc_collect.sh r4prof/pmczipf_mat --with-materialize --workload zipf --warmup 1
+tools/pmc_collect.sh ${ROUND}prof/pmc30
+tools/pmc_collect.sh ${ROUND}prof/pmc30_mat --with-materialize
+tools/pmc_collect.sh ${ROUND}prof/pmc27 --log2n 27
+tools/pmc_collect.sh ${ROUND}prof/pmczipf --workload zipf --warmup 1
+tools/pmc_collect.sh ${ROUND}prof/pmczipf_mat --with-materialize --workload zipf --warmup 1
 rm -rf $OUT/pmc30/p? $OUT/pmc30_mat/p? $OUT/pmc27/p? $OUT/pmczipf/p? $OUT/pmczipf_mat/p?
 ls -la $OUT

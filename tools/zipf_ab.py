@@ -34,25 +34,32 @@ def main():
     hj.sync()
     expect = {name: nS - int((k == nR).sum().item()) for name, k in data.items()}
     b = lr - 12
-    variants = [  # (label, data, bits1, bits2, env)
-        ("zipf sampled 8+7 (default)", "zipf1.0", 0, 0, {}),
-        ("zipf sampled 9+6", "zipf1.0", 9, b - 9, {}),
-        ("zipf sampled 7+8", "zipf1.0", 7, b - 7, {}),
-        ("zipf sampled 8+7 spans 512", "zipf1.0", 0, 0, {"HJ_TARGET_SPANS": "512"}),
-        ("zipf sampled 8+7 guide 1", "zipf1.0", 0, 0, {"HJ_VAR_GUIDE": "1"}),
-        ("uniform FK plain 9+6", "uniformFK", 0, 0, {"HJ_FORCE_SAMPLED": "8"}),
-        ("uniform FK plain 8+7", "uniformFK", 8, b - 8, {"HJ_FORCE_SAMPLED": "8"}),
-        ("uniform FK sampled 9+6", "uniformFK", 9, b - 9, {"HJ_FORCE_SAMPLED": "2"}),
-        ("uniform FK sampled 8+7", "uniformFK", 8, b - 8, {"HJ_FORCE_SAMPLED": "2"}),
-    ]
+    if lr <= 27:
+        variants = [  # (label, data, hj_configure arguments, env)
+            ("zipf sampled 8+7 (default)", "zipf1.0", {}, {}),
+            ("zipf sampled 9+6", "zipf1.0", dict(bits1=9, bits2=b - 9), {}),
+            ("zipf sampled 7+8", "zipf1.0", dict(bits1=7, bits2=b - 7), {}),
+            ("zipf exact passes", "zipf1.0", dict(exact_only=True), {}),
+            ("uniform FK plain 9+6", "uniformFK", {}, {"HJ_FORCE_SAMPLED": "8"}),
+            ("uniform FK plain 8+7", "uniformFK", dict(bits1=8, bits2=b - 8), {"HJ_FORCE_SAMPLED": "8"}),
+            ("uniform FK sampled 9+6", "uniformFK", dict(bits1=9, bits2=b - 9), {"HJ_FORCE_SAMPLED": "2"}),
+            ("uniform FK sampled 8+7", "uniformFK", dict(bits1=8, bits2=b - 8), {"HJ_FORCE_SAMPLED": "2"}),
+        ]
+    else:  # 16 - 18 radix bits: the sampled path (512-way passes under skew) against the exact passes
+        variants = [
+            ("zipf sampled (default bits)", "zipf1.0", {}, {}),
+            ("zipf exact passes", "zipf1.0", dict(exact_only=True), {}),
+            ("uniform FK plain", "uniformFK", {}, {"HJ_FORCE_SAMPLED": "8"}),
+            ("uniform FK sampled", "uniformFK", {}, {"HJ_FORCE_SAMPLED": "2"}),
+        ]
     os.environ["HJ_REPLAN"] = "1"
     acc = {v[0]: [] for v in variants}
     for r in range(rounds):
-        for label, dname, b1, b2, env in variants:
+        for label, dname, cfg, env in variants:
             for kn in KNOBS:
                 os.environ.pop(kn, None)
             os.environ.update(env)
-            hj.configure(bits1=b1, bits2=b2)
+            hj.configure(**cfg)
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, data[dname], Sp)
             for _ in range(2):                       # first contact (overflow -> sample -> tables) and one steady step
@@ -65,10 +72,17 @@ def main():
             kt = hj.timings()
             hj.enable_timings(0)
             # S's launches: the longer of the two per kernel name when R and S share one (plain passes)
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                assert hj.join()[0] == expect[dname]
+            torch.cuda.synchronize()
+            step_ms = (time.perf_counter() - t0) / 3 * 1e3
             row = {k: round(v["total_ms"] / 3, 4) for k, v in kt.items() if v["launches"] and (k.startswith("k_part") or k.startswith("k_join") or k.startswith("k_hist") or k.startswith("k_scatter"))}
-            acc[label].append({"layout_S": layout, "ms_per_step_by_kernel": row})
-    for label, _, b1, b2, env in variants:
-        print(json.dumps({"variant": label, "bits": [b1, b2], "env": env, "rounds": acc[label]}))
+            acc[label].append({"layout_S": layout, "step_ms": round(step_ms, 3), "ms_per_step_by_kernel": row})
+    for label, _, cfg, env in variants:
+        print(json.dumps({"sizes": [lr, ls], "variant": label, "configure": cfg, "env": env, "rounds": acc[label]}))
 
 
 if __name__ == "__main__":
