@@ -333,10 +333,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     // lines of the 512 dealt to `cnt` digits with shares sh[]: a digit wants its expected arrivals per round + 30 %
     auto deal = [&](const double *sh, uint32_t cnt, std::vector<uint32_t> &lt, std::vector<uint32_t> &own, std::vector<uint32_t> &lines) {
         // every digit starts from what the uniform kernels give it (512/cnt lines) or what it needs, whichever is more; when
-        // that is more than the lines there are the lightest digits give theirs back first (down to one), then everybody scales.
-        // 512 digits (a 512-way pass, 17 / 18 radix bits): the buffer's 32 extra lines — trash slots in the other modes — are there to
-        // deal as well (wc_fast HOT): LINES = 544
-        const uint32_t LINES = cnt == 512u ? (uint32_t)WC_LINES_ALL : 512u;
+        // that is more than 512 lines the lightest digits give theirs back first (down to one), then everybody scales
         const uint32_t kdef = std::max<uint32_t>(1u, 512u / cnt);
         std::vector<uint32_t> need(cnt);
         uint32_t total = 0;
@@ -346,20 +343,20 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             lines[d] = std::max(need[d], kdef);
             total += lines[d];
         }
-        if (total > LINES) {
+        if (total > 512) {
             std::vector<uint32_t> by(cnt);
             for (uint32_t d = 0; d < cnt; d++) by[d] = d;
             std::stable_sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return sh[x] < sh[y]; });
-            for (uint32_t round = 0; round < kdef && total > LINES; round++)
-                for (uint32_t i = 0; i < cnt && total > LINES; i++) {
+            for (uint32_t round = 0; round < kdef && total > 512; round++)
+                for (uint32_t i = 0; i < cnt && total > 512; i++) {
                     const uint32_t d = by[i];
                     if (lines[d] > need[d] && lines[d] > 1) { lines[d]--; total--; }
                 }
         }
-        if (total > LINES) { // the needs alone exceed the lines: one each, the rest in proportion to the wish beyond one
+        if (total > 512) { // the needs alone exceed the lines: one each, the rest in proportion to the wish beyond one
             uint32_t tn = 0;
             for (uint32_t d = 0; d < cnt; d++) tn += need[d];
-            for (uint32_t d = 0; d < cnt; d++) lines[d] = 1 + (uint32_t)((uint64_t)(need[d] - 1) * (LINES - cnt) / (tn - cnt));
+            for (uint32_t d = 0; d < cnt; d++) lines[d] = 1 + (uint32_t)((uint64_t)(need[d] - 1) * (512 - cnt) / (tn - cnt));
         }
         uint32_t first = 0;
         for (uint32_t d = 0; d < cnt; d++) {
@@ -377,7 +374,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     span = ((span + TILE - 1) / TILE) * TILE;
     uint64_t nspans = (R.n + span - 1) / span;
     while (nspans > 1024) { span += TILE; nspans = (R.n + span - 1) / span; }
-    std::vector<uint32_t> lt1(P1), own1(WC_LINES_ALL, 0xFFFFu), lines1, vbase1(P1), vcap1(P1);
+    std::vector<uint32_t> lt1(P1), own1(512, 0xFFFFu), lines1, vbase1(P1), vcap1(P1);
     deal(fd.data(), P1, lt1, own1, lines1);
     uint64_t posA = 0;
     double maxfd = 0;
@@ -394,7 +391,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
         if (posA >= ((uint64_t)1 << 32) - ((uint64_t)1 << 20)) return 1; // does not fit 32-bit positions: not plannable
     }
     // pass 2
-    std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * WC_LINES_ALL, 0xFFFFu), heavy2(P1, 0), wg, rpart, pr0(NP), pnr(NP);
+    std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * 512, 0xFFFFu), heavy2(P1, 0), wg, rpart, pr0(NP), pnr(NP);
     uint64_t posB = 0;
     bool any_heavy = false, any_light = false;
     // parents in the order their workgroups should start: the slow ones (one dominant child: wave-aggregated ranking) and the
@@ -433,7 +430,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
         std::vector<double> sh(P2);
         double mx = 0;
         for (uint32_t q = 0; q < P2; q++) { sh[q] = f[d * P2 + q] / fd[d]; mx = std::max(mx, sh[q]); }
-        std::vector<uint32_t> lt(P2), own(WC_LINES_ALL, 0xFFFFu), lines;
+        std::vector<uint32_t> lt(P2), own(512, 0xFFFFu), lines;
         deal(sh.data(), P2, lt, own, lines);
         heavy2[d] = mx > 0.25;
         (heavy2[d] ? any_heavy : any_light) = true;
@@ -446,7 +443,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             cbase2[d * P2 + q] = (uint32_t)W; cap2[d * P2 + q] = (uint32_t)cap; lt2[d * P2 + q] = lt[q];
             W += cap;
         }
-        for (uint32_t i = 0; i < (uint32_t)WC_LINES_ALL; i++) own2[(size_t)d * WC_LINES_ALL + i] = own[i];
+        for (uint32_t i = 0; i < 512; i++) own2[(size_t)d * 512 + i] = own[i];
         if (getenv("HJ_DEBUG") && J > 1) {
             uint32_t qm = 0;
             for (uint32_t q = 0; q < P2; q++) if (sh[q] > sh[qm]) qm = q;
@@ -587,10 +584,11 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     R.n_bound = 0;
     R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
     // known to be skewed: the sampled path — on either side of the join since round 4 (a build partition that is a list of ranges
-    // is built into the LDS table piece by piece: general items, plan_join).  Up to 18 radix bits since round 5: a 512-way pass gives its
-    // hot digits the write-combining buffer's 32 extra lines (wc_fast HOT) instead of letting their tuples leave one by one — round 4
-    // stopped at 17 bits because a 512-way pass under skew was no faster than the exact passes (profiles/r4_sampled_16_17_bits.txt)
-    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 18 && c->fast_path && !c->cfg.exact_only &&
+    // is built into the LDS table piece by piece: general items, plan_join).  Up to 17 radix bits: at 16 (2^28 x 2^31 Zipf) it takes
+    // 18.9 ms where the exact passes take 24.6, at 17 bits 23.6 against 26.9; at 18 bits both passes are 512-way, a heavy digit has
+    // ONE LDS line and most of its tuples bypass it: no faster than the exact passes, the materialising join slower (profiles/
+    // r4_sampled_16_17_bits.txt)
+    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 17 && c->fast_path && !c->cfg.exact_only &&
         R.n >= ((uint64_t)1 << 20)) {
         bool done = false;
         RET(partition_sampled(c, r, b1, b2, flag, &done));

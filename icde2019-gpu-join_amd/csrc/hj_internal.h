@@ -22,7 +22,6 @@ constexpr int SCAN_CHUNK = 1 << SCAN_CHUNK_LOG; // = SCAN_THREADS * SCAN_PER
 constexpr int JOIN_THREADS = 512;
 constexpr int JOIN_WAVES = JOIN_THREADS / 64;
 
-constexpr int WC_LINES_ALL = MAX_PARTS + 32;    // LDS lines of the write-combining buffer: 512 + the 32 that are trash slots or, in a 512-way pass under skew, hot digits' lines
 constexpr int MAX_SEGS = 8192;                  // segments of one exact pass (parents x segments per parent)
 
 // One exact (histogram + scan + scatter) radix pass.  The input is a list of segments [sbeg[i], send[i]) of the
@@ -121,7 +120,7 @@ uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 // the sampled path of skewed relations (hj_part.hip: k_part1_var, k_part2_var)
 struct VarArgs {
     const uint32_t *vbase, *vcap; // pass 1: per digit [P]; pass 2: per (parent, child) [nparents*P]
-    const uint32_t *lt, *own;     // lines dealt: (lines << 16 | first line) per digit [P] (pass 2: per parent row), owner digit per LDS line [WF_LINES_HOST = 544]
+    const uint32_t *lt, *own;     // lines dealt: (lines << 16 | first line) per digit [P] (pass 2: per parent row), owner digit per LDS line [512]
     const uint32_t *heavy;        // pass 1: [1]; pass 2: per parent — one digit holds more than a quarter of the input
     const uint4 *wg;              // pass 2: per workgroup {parent d, first pass-1 span, spans, output position of its sub-slots}
 };

@@ -276,12 +276,7 @@ __device__ __forceinline__ uint32_t slot_lines(const FastGeom &g, uint32_t d) { 
 // says each will receive per round (L_.lt[d] = lines << 16 | first line, L_.own[line] = digit), instead of K each.
 // MODE 1 (exact pass only): the digit is the multi-GPU shard of the key (digit_of<1>: hash, optional position table), P
 // need not be a power of two (K = the largest power of two <= 512/P lines per digit).
-// HOT (round 5; a 512-way pass of a relation known to be skewed — 17 and 18 radix bits): VAR over ALL 544 lines of the buffer.  With
-// 512 digits every digit needs a line and the 512 are gone: the hot digits' tuples used to leave one by one (9.0 ms per 2^31 tuples
-// against 6.4, profiles/r5_zipf_pass_ab.txt).  The 32 lines that serve the other modes as per-thread trash slots are dealt to the hot
-// digits instead (Zipf 1.0: the ten hottest digits want 13, 6, 4, 3, 2, 2, 1, 1, 1, 1 lines beyond their own) and the placements
-// that must not happen are predicated instead of pointed at trash (measured neutral: profiles/r5_lds_conflicts.txt, variants 16 / 64).
-template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0, bool HOT = false>
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
@@ -365,8 +360,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t k = keep[u * 4 + e];
-                if (HOT) { if (k != WF_NONE) buf[k] = make_int2(elem(kk[u], e), elem(pp[u], e)); } // (the trash slots are hot digits' lines)
-                else buf[k != WF_NONE ? k : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                buf[k != WF_NONE ? k : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
             }
         // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
         // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
@@ -426,8 +420,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t capd = VAR ? (lt >> 16) * WC_LINE : capS, based = VAR ? (lt & 0xFFFFu) * WC_LINE : d * capS;
                 const bool now = valid && (leaves ? q < capd : full == 0);
                 any_bypass |= valid && leaves && q >= capd;
-                if (HOT) { if (now) buf[based + q] = make_int2(elem(kk[u], e), elem(pp[u], e)); }
-                else buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
                 keep[j] = (valid && !leaves && full != 0) ? based + (q - full) : WF_NONE;
             }
         if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
@@ -487,24 +480,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     }
                 }
             }
-            if (HOT && ln < 16u) { // the wave's two lines of the extra 32 (lines 512 + 2 wv, + 1): 8 lanes each
-                const uint32_t ex = (uint32_t)MAX_PARTS + wv * 2 + (ln >> 3);
-                const uint32_t dx = L_.own[ex];
-                if (dx < P) {
-                    const uint32_t ltx = L_.lt[dx], wx = h[dx];
-                    uint32_t fulln = ((wx >> 16) + (wx & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
-                    const uint32_t capx = (ltx >> 16) * WC_LINE;
-                    fulln = (fulln < capx ? fulln : capx) >> 5;
-                    const uint32_t jx = ex - (ltx & 0xFFFFu);
-                    if (jx < fulln) {
-                        const uint64_t gpos = ((uint64_t)line[dx] + jx) * WC_LINE + c4;
-                        const int4 x = *reinterpret_cast<const int4 *>(buf + ex * WC_LINE + c4);
-                        const int4 y = *reinterpret_cast<const int4 *>(buf + ex * WC_LINE + c4 + 2);
-                        *reinterpret_cast<int4 *>(out_keys + gpos) = make_int4(x.x, x.z, y.x, y.z);
-                        *reinterpret_cast<int4 *>(out_pays + gpos) = make_int4(x.y, x.w, y.y, y.w);
-                    }
-                }
-            }
         }
         __syncthreads();
         if (stop) return; // workgroup-uniform: every thread read the same LDS word between the same barriers
@@ -554,11 +529,11 @@ __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.sb = L_.pc4 + WF_MAXSEG + 4;
     L_.lo = L_.pc4;
     L_.lt = L_.sb + WF_MAXSEG;       // lines dealt by need: an area of their own (the segment tables of pass 2 are in use then)
-    L_.own = L_.lt + MAX_PARTS;      // [WF_LINES]: owner digit of every line (HOT: the 32 extra lines too)
+    L_.own = L_.lt + MAX_PARTS;
 }
 size_t fast_lds_bytes_impl() {
     return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
-           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 + (size_t)WF_LINES * 4;
+           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2;
 }
 
 // The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
@@ -745,11 +720,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     g.vbase = v.vbase; g.vcap = v.vcap; g.voff = 0; g.vs = s;
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
     if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[tid]; }
-    if (tid < (uint32_t)WF_LINES) L_.own[tid] = v.own[tid];
+    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
-    // 512 digits: the 32 extra lines are dealt to the hot digits (HOT); fewer digits: the 512 lines are dealt by need (VAR)
-    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 0, 0, false, HEAVY, true, 0, true>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    // 512 digits: every digit has exactly one of the 512 lines, there is nothing to deal — the fixed-geometry rounds (no per-digit
+    // line table in the inner loops) with the sampled slot capacities (a 512-way pass under skew: 9.8 -> see r4_sampled_16_17_bits.txt)
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 0, false, HEAVY, true, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
 }
 
@@ -778,13 +754,13 @@ __global__ __launch_bounds__(WC_THREADS) void k_part2_var(FastArgs a, VarArgs v)
     __syncthreads();
     for (uint32_t i = tid; i < 2 * WC_HSTRIDE; i += WC_THREADS) L_.hh[i] = 0;
     if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[(uint64_t)d * a.P + tid]; }
-    if (tid < (uint32_t)WF_LINES) L_.own[tid] = v.own[(uint64_t)d * WF_LINES + tid];
+    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[(uint64_t)d * MAX_PARTS + tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     __syncthreads();
     // workgroup-uniform: parents dominated by one child rank with the wave-aggregated atomic (as k_scatter_wc does per span)
-    if (a.P == (uint32_t)MAX_PARTS) { // 512 children: the extra lines go to the hot ones (see k_part1_var)
-        if (v.heavy[d]) wc_fast<U, 0, 1, false, true, true, 0, true>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-        else wc_fast<U, 0, 1, false, false, true, 0, true>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (a.P == (uint32_t)MAX_PARTS) { // one line per child: the fixed-geometry rounds (see k_part1_var)
+        if (v.heavy[d]) wc_fast<U, 1, 1, false, true, false, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+        else wc_fast<U, 1, 1, false, false, false, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
         return;
     }
     if (v.heavy[d]) wc_fast<U, 0, 1, false, true, true, 0>(L_, a.keys, a.pays, 0, 0, 0, w.z, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);

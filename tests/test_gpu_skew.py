@@ -139,9 +139,8 @@ def test_skewed_exact_passes_deal_lines_by_need(P, cfg):
                                        # 16 / 17 radix bits: the sample histogram no longer fits one workgroup's LDS (sliced sampling pass)
                                        (dict(bits1=9, bits2=7), 1 << 20, 1 << 24), (dict(bits1=9, bits2=8), 1 << 20, 3 << 22),
                                        (dict(bits1=8, bits2=8), 1 << 21, 1 << 24),
-                                       # 512-way passes under skew (round 5): the hot digits get the buffer's 32 extra lines (wc_fast HOT),
-                                       # in pass 1, in pass 2, and in both at 18 radix bits — where the sampled path used to stop
-                                       (dict(bits1=9, bits2=9), 1 << 20, 1 << 24), (dict(bits1=6, bits2=9), 1 << 20, 3 << 22)])
+                                       # a 512-way SECOND pass under skew (one line per child, the hot child's overflow leaves tuple by tuple)
+                                       (dict(bits1=6, bits2=9), 1 << 20, 3 << 22)])
 def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
     """A skewed relation on the probe side: the first join finds its slots overflowing, samples the key distribution once and
     from then on partitions it with the histogram-free passes at per-digit capacities (layout 'sampled': a partition is a list
