@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
-"""Regenerate the result tables of README.md, BASELINE.md and DESIGN.md from profiles/r4_bench_*.json, so that the documents quote
-the committed evidence and nothing else.  A generated block sits between
+"""Regenerate the result tables of README.md, BASELINE.md and DESIGN.md from profiles/<round>_bench_*.json (ROUND, default r5), so that
+the documents quote the committed evidence and nothing else.  A generated block sits between
 
     <!-- BEGIN generated:NAME (tools/update_docs.py) -->   and   <!-- END generated:NAME -->
 
-Numbers in brackets are the same command's line inside the evidence call (tools/gpu_profiles.sh: another process, usually another
-box, of the same binary); the leading number is from tools/gpu_bench_lines.sh, run with the PMC files of the binary in place.
-Usage: python tools/update_docs.py [--check]"""
+The leading number of a row is the MEDIAN process of three back to back on one box (tools/gpu_bench_lines.sh, min-max in square
+brackets); numbers in round brackets are the same command's line inside the evidence call (tools/gpu_profiles.sh: another process,
+usually another box, of the same binary).  Usage: python tools/update_docs.py [--check]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("ROUND", "r5")
 
 
 def load(name):
-    return [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r4_bench_%s.json" % name)) if l.startswith("{")]
+    return [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (ROUND, name))) if l.startswith("{")]
 
 
 def sha():
-    return open(os.path.join(ROOT, "profiles", "r4_libhj.sha256")).read().split()[0]
+    return open(os.path.join(ROOT, "profiles", "%s_libhj.sha256" % ROUND)).read().split()[0]
 
 
 def both(name):
@@ -32,12 +33,34 @@ def kms(d, k):  # per-launch ms of a kernel (the instrumented steps)
     return v["ms_per_step"] / v["launches_per_step"]
 
 
-def tp(d):  # "[three processes on one box: a-b] " when the line is the median of three
+def tp(d):
     t = d.get("three_processes")
-    return ("[median of three processes on one box: %.1f–%.1f] " % (min(t["values"]), max(t["values"]))) if t else ""
+    return ("[%.1f–%.1f] " % (min(t["values"]), max(t["values"]))) if t else ""
 
 
-def readme_rows():
+def roof(d):
+    r = d["roofline"]
+    s = "`%s` %.2f ms per launch = %.2f of 8 TB/s" % (r["kernel"], r["avg_launch_ms"], r["frac"])
+    if r.get("frac_of_mix_ceiling"):
+        s += " = %.2f of the same-run mix ceiling (%.2f TB/s)" % (r["frac_of_mix_ceiling"], r["mix_ceiling_GBs"] / 1e3)
+    if r.get("traffic"):
+        s += "; HBM traffic %.3f × algorithmic" % (r["traffic"] / r["algorithmic_bytes_per_launch"])
+    return s
+
+
+def mat(d):
+    m = d.get("materialize") or {}
+    if not m or m.get("error"):
+        return "—"
+    s = "**%.1f** (%.2f ms)" % (m["value"], m["ms_per_step"])
+    if m.get("k_join_materialize_frac_of_8TBs"):
+        s += ", `k_join_mat_reg` %.2f ms = %.2f of 8 TB/s" % (m["k_join_materialize_ms"], m["k_join_materialize_frac_of_8TBs"])
+        if m.get("frac_of_mix_ceiling"):
+            s += " = %.2f of its mix ceiling (%.0f %% writes)" % (m["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"])
+    return s
+
+
+def results_rows():
     b30, e30 = both("2p30")
     b27, e27 = both("2p27")
     bz, ez = both("zipf")
@@ -45,149 +68,58 @@ def readme_rows():
     st, co = load("stream")[0], load("coprocess")[0]
     zp, zb = load("zipf_24_27_pk_builds")[0], load("zipf_24_27_zipf_builds")[0]
     base = load("baselines")
-    out = ["| workload | Gtuples/s | ms/step | notes |", "|---|---|---|---|"]
-    r, re_, p, pe, m, me = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"]
-    out.append(("| 2^30 ⋈ 2^30 unique uniform int32, count-only (headline) | **%.1f** " + tp(b30) + "(%.1f; r3 driver 140.9; r2 driver 124.3) | %.2f (%.2f) | "
-               "`k_part1_fast` %.2f (%.2f) ms, `k_part2_fast` %.2f (%.2f) ms per launch, `k_join` %.2f (%.2f) ms; dominant `%s` %.2f (%.2f) of 8 TB/s = "
-               "%.2f (%.2f) of the same-run copy ceiling; probe %.2f (%.2f) of 8 TB/s; HBM traffic %.3f × algorithmic |")
-               % (b30["value"], e30["value"], b30["ms_per_step"], e30["ms_per_step"], kms(b30, "k_part1_fast"), kms(e30, "k_part1_fast"),
-                  kms(b30, "k_part2_fast"), kms(e30, "k_part2_fast"), kms(b30, "k_join_count"), kms(e30, "k_join_count"), r["kernel"], r["frac"], re_["frac"],
-                  r["frac_of_stream_copy"], re_["frac_of_stream_copy"], p["frac_of_8TBs"], pe["frac_of_8TBs"], r["traffic"] / r["algorithmic_bytes_per_launch"]))
-    out.append("| same, **materialising 2^30 `(key,payR,payS)` tuples in ONE probe** | **%.1f** (%.1f; r3 driver 121.2; round 2, two probes: 93.6) | %.2f (%.2f) | "
-               "`k_join_mat_reg` %.2f (%.2f) ms = %.2f (%.2f) of 8 TB/s = %.2f (%.2f) of the same-run read/write-mix ceiling (%.0f %% of its bytes are writes) |"
-               % (m["value"], me["value"], m["ms_per_step"], me["ms_per_step"], m["k_join_materialize_ms"], me["k_join_materialize_ms"],
-                  m["k_join_materialize_frac_of_8TBs"], me["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"]))
-    out.append("| 2^30, exact (histogram) passes only | %.1f | %.2f | |" % (bx["value"], bx["ms_per_step"]))
-    r, re_, p, pe, m, me = b27["roofline"], e27["roofline"], b27["probe_phase"], e27["probe_phase"], b27["materialize"], e27["materialize"]
-    out.append(("| 2^27 ⋈ 2^27 (configs[1]), default 9+6 bits | **%.1f** " + tp(b27) + "(%.1f; round 2: 113.9) | %.2f (%.2f) | dominant `%s` %.2f (%.2f) of 8 TB/s = %.2f (%.2f) of the "
-               "copy ceiling, probe %.2f (%.2f) (stated target 0.68 NOT met: a 0.45-ms launch carries ~60 µs of fixed cost, DESIGN §10.1); materialising %.1f (%.1f) |")
-               % (b27["value"], e27["value"], b27["ms_per_step"], e27["ms_per_step"], r["kernel"], r["frac"], re_["frac"], r["frac_of_stream_copy"], re_["frac_of_stream_copy"],
-                  p["frac_of_8TBs"], pe["frac_of_8TBs"], m["value"], me["value"]))
-    s, se = b27["config2_as_stated"], e27["config2_as_stated"]
-    out.append("| 2^27 ⋈ 2^27 **as configs[1] states it: ONE 9-bit pass** | %.1f (%.1f) | %.1f (%.1f) | 2^18-tuple partitions rebuild the LDS table ~60 × each: why the default is two passes |"
-               % (s["value"], se["value"], s["ms_per_step"], se["ms_per_step"]))
-    r, re_, p, pe, m, me = bz["roofline"], ez["roofline"], bz["probe_phase"], ez["probe_phase"], bz["materialize"], ez["materialize"]
-    out.append(("| **PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0 (configs[3])**, count | **%.1f** " + tp(bz) + "(%.1f; round 3: 128 on its fastest box; round 2: 94.1) | %.2f (%.2f) | "
-               "S: `k_part1_var` %.2f (%.2f) + `k_part2_var` %.2f (%.2f) ms — sampled capacities, no histogram (dominant `%s` %.2f (%.2f) of 8 TB/s, traffic %.3f ×); "
-               "join %.2f (%.2f) ms = %.2f (%.2f); the larger relation's passes on a high-priority stream (DESIGN §3.5); everything exact: %.1f |")
-               % (bz["value"], ez["value"], bz["ms_per_step"], ez["ms_per_step"], kms(bz, "k_part1_var"), kms(ez, "k_part1_var"), kms(bz, "k_part2_var"), kms(ez, "k_part2_var"),
-                  r["kernel"], r["frac"], re_["frac"], r["traffic"] / r["algorithmic_bytes_per_launch"], kms(bz, "k_join_count"), kms(ez, "k_join_count"),
-                  p["frac_of_8TBs"], pe["frac_of_8TBs"], bzx["value"]))
-    out.append("| same, **materialising 2^31 − 2 tuples (24 GiB) in one probe**, digest-checked | **%.1f** (%.1f) | %.2f (%.2f) | `k_join_mat_reg` with list items %.2f (%.2f) ms = "
-               "%.2f (%.2f) of 8 TB/s = %.2f (%.2f) of the mix ceiling (%.0f %% writes); 0 scratch (round 3: 24–28 B/lane, untimed) |"
-               % (m["value"], me["value"], m["ms_per_step"], me["ms_per_step"], m["k_join_materialize_ms"], me["k_join_materialize_ms"], m["k_join_materialize_frac_of_8TBs"],
-                  me["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"]))
-    f, fe = bz["first_call_split_ms"], ez["first_call_split_ms"]
-    out.append("| first call on a fresh, skewed binding (config 4) | | %.0f ms (%.0f ms), of which device allocation %.0f (%.0f) | the library's own share is 20–45 ms (failed optimistic attempt "
-               "%.0f, sample + plan %.0f, the answering step %.1f); the rest is allocation, once per buffer: 20–50 ms on a clean box, 0.8–2.8 s when the driver has pages to scrub (`profiles/r4_first_call.txt`) |"
-               % (bz["first_call_ms"], ez["first_call_ms"], f["allocation_ms"], fe["allocation_ms"], f["failed_optimistic_attempt_ms"], f["sample_and_plan_ms"], f["rest_ms (the step that answered)"]))
-    out.append("| PK–FK 2^24 ⋈ 2^27 Zipf, **the Zipf side designated to build** | %.1f (round 3: 0.1) | %.2f (round 3: 1503) | general work items: sampled build side, tables from range lists, "
-               "the smaller partition builds; the PK side building: %.2f ms; materialising %.2f / %.2f ms |"
-               % (zb["value"], zb["ms_per_step"], zp["ms_per_step"], zb["materialize"]["ms_per_step"], zp["materialize"]["ms_per_step"]))
-    out.append("| PK–FK **2^32 ⋈ 2^31** (beyond 32-bit positions) | property test | | count = 2^31, multiset-preserving partitions of the 2^32-tuple relation, slotted and exact (`test_beyond_2p32_tuples`) |")
-    out.append("| S (2^30) streamed from pinned host memory against R (2^27) | %.1f | %.1f | %.1f GB/s H2D, transfer-bound; materialising 2^28 tuples back to the host in one probe per segment: %.1f ms, %.1f GB/s D2H |"
+    m8 = load("phantom8")[0]
+    out = ["| workload (BASELINE config) | Gtuples/s: median of three processes [min–max] (evidence call) | ms/step | dominant pass kernel; probe | materialising variant | CPU baseline |",
+           "|---|---|---|---|---|---|"]
+    p, c = b30["probe_phase"], b30["cpu_baseline"]
+    out.append("| **3: 2^30 ⋈ 2^30 unique uniform int32, count-only (headline)** | **%.1f** %s(%.1f; driver r4 141.8, r3 140.9, r2 124.3) | %.2f (%.2f) | %s; `k_join` %.2f ms = %.2f of 8 TB/s (target %.2f) | %s | "
+               "%.3f (radix port, %d threads, %s); `joinCpu` port %.3f at 2^22 |"
+               % (b30["value"], tp(b30), e30["value"], b30["ms_per_step"], e30["ms_per_step"], roof(b30), p["avg_launch_ms"], p["frac_of_8TBs"], p["target_frac"], mat(b30),
+                  c["value"], c["cores"], "full size" if "full size" in c["sample"] else "bounded sample", c["joinCpu"]["value"]))
+    out.append("| 3, exact (histogram) passes only | %.1f | %.2f | `k_scatter_wc` + `k_hist` | | |" % (bx["value"], bx["ms_per_step"]))
+    p, c = b27["probe_phase"], b27["cpu_baseline"]
+    out.append("| **2: 2^27 ⋈ 2^27, default 9+6 bits** | **%.1f** %s(%.1f; r4 127.7) | %.2f (%.2f) | %s; `k_join` %.3f ms = %.2f (target %.3f from the fixed-cost model: %s) | %s | %.3f |"
+               % (b27["value"], tp(b27), e27["value"], b27["ms_per_step"], e27["ms_per_step"], roof(b27), p["avg_launch_ms"], p["frac_of_8TBs"], p["target_frac"],
+                  "met" if p["meets_target"] else "NOT met", mat(b27), c["value"]))
+    s = b27.get("config2_as_stated") or {}
+    if s:
+        out.append("| 2 AS STATED in configs[1]: ONE 9-bit pass | %.1f | %.2f | 2^18-tuple partitions rebuild the LDS table ~60 × each: why the default is two passes | | |" % (s["value"], s["ms_per_step"]))
+    p, c = bz["probe_phase"], bz["cpu_baseline"]
+    out.append("| **4: PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0, count-only** | **%.1f** %s(%.1f; r4 126.0) | %.2f (%.2f) | S: `k_part1_var` %.2f + `k_part2_var` %.2f ms (sampled capacities, no histogram); %s; `k_join` %.2f ms = %.2f | %s | %.3f (bounded PK–FK Zipf sample, %d threads) |"
+               % (bz["value"], tp(bz), ez["value"], bz["ms_per_step"], ez["ms_per_step"], kms(bz, "k_part1_var"), kms(bz, "k_part2_var"), roof(bz), p["avg_launch_ms"], p["frac_of_8TBs"], mat(bz),
+                  c["value"], c["cores"]))
+    out.append("| 4, exact passes only | %.1f | %.2f | `k_scatter_wc` + `k_hist` | | |" % (bzx["value"], bzx["ms_per_step"]))
+    f = bz["first_call_split_ms"]
+    out.append("| 4, first call on a fresh binding | | %.0f ms | of which device allocation %.0f, failed optimistic attempt %.0f, sample + plan %.0f | | |"
+               % (bz["first_call_ms"], f["allocation_ms"], f["failed_optimistic_attempt_ms"], f["sample_and_plan_ms"]))
+    out.append("| PK–FK 2^24 ⋈ 2^27 Zipf: PK side builds / the Zipf side designated to build (general items) | %.1f / %.1f | %.2f / %.2f | §3.6 | %s / %s | |"
+               % (zp["value"], zb["value"], zp["ms_per_step"], zb["ms_per_step"], mat(zp), mat(zb)))
+    out.append("| S (2^30) streamed from pinned host memory against R (2^27) | %.1f | %.1f | %.1f GB/s H2D: transfer-bound | 2^28 tuples back to the host, one probe per segment: %.1f ms, %.1f GB/s D2H | |"
                % (st["value"], st["ms_per_step"], st["h2d_GBs"], st["materialize"]["ms"], st["materialize"]["d2h_GBs"]))
-    out.append("| R, S (2^27 each) in host memory, CPU–GPU co-processing | %.2f | %.0f | host write-combining split %.0f GB/s on a 16-CPU quota of a shared 2-node host (1.4–2.1 Gtuples/s over the round's boxes: "
-               "the hosts differ); workers bound to the GPU's node |" % (co["value"], co["ms_per_step"], co["host_split_GBs"]))
+    out.append("| R, S (2^27 each) in host memory, CPU–GPU co-processing | %.2f (r4 1.42) | %.0f (r4 189) | host split %.0f GB/s on the box's CPU quota, R uploaded under S's split, payload columns filled on the device | | |"
+               % (co["value"], co["ms_per_step"], co["host_split_GBs"]))
     b = [d for d in base if "2^30" in d["metric"]][0]["results"]
-    out.append("| non-partitioned baselines at 2^30: perfect array / global chained table | %.1f / %.1f | | the curves the reference compares against (partitioned, same process: %.1f) |"
+    out.append("| non-partitioned baselines at 2^30: perfect array / global chained table | %.1f / %.1f | | the curves the reference compares against (partitioned, same process: %.1f) | | |"
                % (b["perfect array"]["Gtuples_per_s"], b["global chained table"]["Gtuples_per_s"], b["partitioned (radix + LDS tables)"]["Gtuples_per_s"]))
-    c, ce = b30["cpu_baseline"], e30["cpu_baseline"]
-    out.append("| CPU baseline, same 2^30 ⋈ 2^30, %d host threads (the box's cgroup CPU quota; oracle port, full size) | %.3f (%.3f) | | reported, not a target; reference `joinCpu` port %.3f (%.3f) at 2^22 |"
-               % (c["cores"], c["value"], ce["value"], c["joinCpu"]["value"], ce["joinCpu"]["value"]))
+    mm = m8["dist"]["model"]
+    mt = (m8.get("materialize") or {}).get("model") or {}
+    out.append("| 5: 2^33 ⋈ 2^33 over 8 GPUs | measured by the driver (`bench.py --gpus 8`: headline over RCCL + materialising join + strong-scaling point + both transports); "
+               "modelled from one-GPU stage times (NOT a measurement): %.1f per GPU count-only%s | %.1f modelled | link-bound: %.1f ms of links, %.1f ms of local work of which %.1f exposed | | |"
+               % (mm["modelled_Gtuples_per_s_per_gpu"], (", %.1f materialising" % mt["modelled_Gtuples_per_s_per_gpu"]) if mt else "", mm["modelled_step_ms"], mm["link_ms"], mm["local_ms_total"], mm["exposed_local_ms"]))
     return out
 
 
-def model_rows(wide):
-    out = []
-    if wide:
-        out += ["| G | bytes per link direction | link ms | local ms total | exposed local ms (first split + last pass 1 + last group's pass 2 and join) | exposed / link | modelled step | per-GPU Gtuples/s |",
-                "|---|---|---|---|---|---|---|---|"]
-    else:
-        out += ["| G | link ms | local work ms | exposed local ms | exposed / link | modelled step ms | per-GPU Gtuples/s |", "|---|---|---|---|---|---|---|"]
+def model_rows(_wide=True):
+    out = ["| G | bytes per link direction | link ms | local ms total | exposed local ms (first split + last pass 1 + last group's pass 2 and join) | modelled step: count-only | modelled step: materialising | per-GPU Gtuples/s (count / materialising) |",
+           "|---|---|---|---|---|---|---|---|"]
     for g, lab in (("2", "2"), ("4", "4"), ("8", "8"), ("8_single_group", "8, probe side joined in one group (`--single-group`)")):
-        m = load("phantom" + g)[0]["dist"]["model"]
-        if wide:
-            out.append("| %s | %.2f GB | %.1f | %.1f | %.1f | %.3f | %.1f ms | %.1f |" % (lab, m["bytes_per_link_direction"] / 1e9, m["link_ms"], m["local_ms_total"], m["exposed_local_ms"],
-                                                                                         m["exposed_over_link"], m["modelled_step_ms"], m["modelled_Gtuples_per_s_per_gpu"]))
-        else:
-            out.append("| %s | %.1f | %.1f | %.1f | %.2f | %.1f | %.1f |" % (lab, m["link_ms"], m["local_ms_total"], m["exposed_local_ms"], m["exposed_over_link"], m["modelled_step_ms"],
-                                                                            m["modelled_Gtuples_per_s_per_gpu"]))
-    return out
-
-
-def baseline_rows():
-    b30, e30 = both("2p30")
-    b27, e27 = both("2p27")
-    bz, ez = both("zipf")
-    m8 = load("phantom8")[0]["dist"]["model"]
-    out = ["| config | GPUs | Gtuples/s | dominant pass kernel GB/s (algorithmic) | probe GB/s (algorithmic) | % of 8 TB/s (pass / probe) | CPU baseline Gtuples/s (cores) |", "|---|---|---|---|---|---|---|"]
-    r, re_, p, pe, m, me, c, ce = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"], b30["cpu_baseline"], e30["cpu_baseline"]
-    out.append(("| 3: 2^30 ⋈ 2^30 uniform, count-only | 1 | **%.1f**, %.2f ms " + tp(b30) + "(evidence call %.1f, %.2f ms; driver r3 140.9, r2 124.3; round 1: 105–107) | %.0f (`%s`, %.2f ms; evidence call %.0f; PMC traffic %.2f GB for %.2f); "
-               "same-run stream-copy ceiling %.0f | %.0f (%.2f ms) | %.1f %% / %.1f %% (evidence call %.1f %% / %.1f %%) | %.2f (%.2f) (%d threads = the box's cgroup CPU quota, same workload at full size, oracle port); "
-               "reference `joinCpu` port %.2f at 2^22 |")
-               % (b30["value"], b30["ms_per_step"], e30["value"], e30["ms_per_step"], r["achieved"], r["kernel"], r["avg_launch_ms"], re_["achieved"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9,
-                  r["stream_copy_ceiling"], p["achieved_GBs"], p["avg_launch_ms"], 100 * r["frac"], 100 * p["frac_of_8TBs"], 100 * re_["frac"], 100 * pe["frac_of_8TBs"], c["value"], ce["value"], c["cores"], c["joinCpu"]["value"]))
-    out.append("| 3: same, materialising 2^30 output tuples in ONE probe | 1 | **%.1f** (evidence call %.1f; driver r3 121.2; round 2, two probes: 93.6) | same | `k_join_mat_reg` %.0f (%.0f) (8 B/tuple + 12 B/match) | "
-               "— / %.1f %% (%.1f %%) (%.2f (%.2f) of the same-run read/write-mix ceiling) | — |"
-               % (m["value"], me["value"], m["k_join_materialize_GBs"], me["k_join_materialize_GBs"], 100 * m["k_join_materialize_frac_of_8TBs"], 100 * me["k_join_materialize_frac_of_8TBs"],
-                  m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"]))
-    r, re_, p, pe, c = b27["roofline"], e27["roofline"], b27["probe_phase"], e27["probe_phase"], b27["cpu_baseline"]
-    out.append("| 2: 2^27 ⋈ 2^27 uniform, count-only, DEFAULT 9+6 bits (two passes) | 1 | %.1f, %.2f ms (evidence call %.1f; round 2: 113.9) | %.0f (`%s`; evidence call %.0f) | %.0f | "
-               "%.1f %% / %.1f %% (stated probe target 68 %%: not met) | %.2f |"
-               % (b27["value"], b27["ms_per_step"], e27["value"], r["achieved"], r["kernel"], re_["achieved"], p["achieved_GBs"], 100 * r["frac"], 100 * p["frac_of_8TBs"], c["value"]))
-    s, se = b27["config2_as_stated"], e27["config2_as_stated"]
-    out.append("| 2 AS STATED in configs[1]: ONE 9-bit pass | 1 | **%.1f** (%.1f ms per step; evidence call %.1f / %.1f) | | | | why the default is two passes: 2^18-tuple partitions rebuild the LDS table ~60 × each |"
-               % (s["value"], s["ms_per_step"], se["value"], se["ms_per_step"]))
-    r, re_, p, m, me, c, ce = bz["roofline"], ez["roofline"], bz["probe_phase"], bz["materialize"], ez["materialize"], bz["cpu_baseline"], ez["cpu_baseline"]
-    out.append("| 4: PK–FK 2^27 ⋈ 2^31 Zipf θ=1.0, count-only | 1 | **%.1f**, %.2f ms (evidence call %.1f, %.2f ms; round 2: 94.1; round 1: 65–70) | S: sampled capacities, no histogram: %.0f (`%s`, %.2f ms per 2^31 tuples; "
-               "PMC traffic %.2f GB for %.2f) | `k_join` %.2f ms = %.0f | %.1f %% / %.1f %% | %.2f (%.2f) (bounded PK–FK Zipf sample, %d threads) |"
-               % (bz["value"], bz["ms_per_step"], ez["value"], ez["ms_per_step"], r["achieved"], r["kernel"], r["avg_launch_ms"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9,
-                  p["avg_launch_ms"], p["achieved_GBs"], 100 * r["frac"], 100 * p["frac_of_8TBs"], c["value"], ce["value"], c["cores"]))
-    out.append("| 4: same, materialising 2^31 − 2 output tuples (24 GiB) in ONE probe, digest-checked | 1 | **%.1f** (%.2f ms per step; evidence call %.1f) | same | `k_join_mat_reg`, list items: %.2f ms = %.0f (evidence call %.2f ms = %.0f) | "
-               "— / %.1f %% (%.2f of the %.0f %%-writes mix ceiling) | — |"
-               % (m["value"], m["ms_per_step"], me["value"], m["k_join_materialize_ms"], m["k_join_materialize_GBs"], me["k_join_materialize_ms"], me["k_join_materialize_GBs"],
-                  100 * m["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"]))
-    out.append("| 5: 2^33 ⋈ 2^33 over 8 GPUs | 8 | measured by the driver (`bench.py --gpus 8`: `hj_dist`, C++ over RCCL; the line carries an xGMI roofline); modelled from one-GPU stage times: "
-               "%.1f per GPU (%.1f ms/step, link-bound) | | | | |" % (m8["modelled_Gtuples_per_s_per_gpu"], m8["modelled_step_ms"]))
-    return out
-
-
-def design_rows():
-    b30, e30 = both("2p30")
-    b27, e27 = both("2p27")
-    bz, ez = both("zipf")
-    bx, bzx = load("2p30_exact")[0], load("zipf_exact")[0]
-    zp, zb = load("zipf_24_27_pk_builds")[0], load("zipf_24_27_zipf_builds")[0]
-    m8 = load("phantom8")[0]["dist"]["model"]
-    out = ["| config | Gtuples/s | ms/step | dominant pass kernel: ms, of 8 TB/s, of same-run copy ceiling | probe of 8 TB/s | CPU baseline Gtuples/s |", "|---|---|---|---|---|---|"]
-    r, re_, p, pe, m, me, c = b30["roofline"], e30["roofline"], b30["probe_phase"], e30["probe_phase"], b30["materialize"], e30["materialize"], b30["cpu_baseline"]
-    out.append(("| 3: 2^30 ⋈ 2^30 uniform, count-only | **%.1f** " + tp(b30) + "(evidence call %.1f; r3 driver 140.9; r2 driver 124.3; r1 105–107) | %.2f (%.2f) | `%s` %.2f ms, %.2f, %.2f (copy %.2f TB/s) (evidence call %.2f ms, %.2f, %.2f); "
-               "traffic %.2f GB for %.2f | %.2f (%.2f) | %.2f (radix port, %d threads, full size); `joinCpu` port %.2f at 2^22 |")
-               % (b30["value"], e30["value"], b30["ms_per_step"], e30["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"], r["frac_of_stream_copy"], r["stream_copy_ceiling"] / 1e3,
-                  re_["avg_launch_ms"], re_["frac"], re_["frac_of_stream_copy"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9, p["frac_of_8TBs"], pe["frac_of_8TBs"], c["value"], c["cores"], c["joinCpu"]["value"]))
-    out.append("| 3: same, materialising 2^30 tuples in one probe | **%.1f** (evidence call %.1f; r3 driver 121.2; r2 93.6–96.4) | %.2f (%.2f) | — | `k_join_mat_reg` %.2f (%.2f) = %.2f (%.2f) of the read/write-mix ceiling | — |"
-               % (m["value"], me["value"], m["ms_per_step"], me["ms_per_step"], m["k_join_materialize_frac_of_8TBs"], me["k_join_materialize_frac_of_8TBs"], m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"]))
-    out.append("| 3: exact passes only | %.1f | %.2f | `k_scatter_wc` | | |" % (bx["value"], bx["ms_per_step"]))
-    r, re_, p, m, me, c = b27["roofline"], e27["roofline"], b27["probe_phase"], b27["materialize"], e27["materialize"], b27["cpu_baseline"]
-    out.append("| 2: 2^27 ⋈ 2^27 uniform (9+6) | %.1f (evidence call %.1f; r2 113.9) | %.2f (%.2f) | `%s` %.3f ms, %.2f, %.2f (evidence call %.3f, %.2f, %.2f) | %.2f (stated 0.68: not met) | %.2f |"
-               % (b27["value"], e27["value"], b27["ms_per_step"], e27["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"], r["frac_of_stream_copy"], re_["avg_launch_ms"], re_["frac"], re_["frac_of_stream_copy"],
-                  p["frac_of_8TBs"], c["value"]))
-    out.append("| 2: same, materialising | %.1f (%.1f) | %.2f | | `k_join_mat_reg` %.2f (%.2f) | |" % (m["value"], me["value"], m["ms_per_step"], m["k_join_materialize_frac_of_8TBs"], me["k_join_materialize_frac_of_8TBs"]))
-    s, se = b27["config2_as_stated"], e27["config2_as_stated"]
-    out.append("| 2 AS STATED: one 9-bit pass | %.1f (%.1f) | %.2f | 2^18-tuple partitions: the LDS table is rebuilt ~60 × per partition | | |" % (s["value"], se["value"], s["ms_per_step"]))
-    r, re_, p, pe, m, me, c = bz["roofline"], ez["roofline"], bz["probe_phase"], ez["probe_phase"], bz["materialize"], ez["materialize"], bz["cpu_baseline"]
-    out.append("| 4: PK–FK 2^27 ⋈ 2^31 Zipf θ=1.0 | **%.1f** (evidence call %.1f; r3 128 on its fastest box; r2 94.1; r1 65–70) | %.2f (%.2f) | `%s` %.2f (%.2f) ms per 2^31-tuple launch = %.2f (%.2f); traffic %.2f GB for %.2f | "
-               "%.2f (%.2f) | %.2f (bounded PK–FK Zipf sample) |"
-               % (bz["value"], ez["value"], bz["ms_per_step"], ez["ms_per_step"], r["kernel"], r["avg_launch_ms"], re_["avg_launch_ms"], r["frac"], re_["frac"], r["traffic"] / 1e9, r["algorithmic_bytes_per_launch"] / 1e9,
-                  p["frac_of_8TBs"], pe["frac_of_8TBs"], c["value"]))
-    out.append("| 4: same, materialising 2^31 − 2 tuples in one probe (24 GiB out, digest-checked) | **%.1f** (%.1f) | %.2f (%.2f) | — | `k_join_mat_reg` (list items) %.2f (%.2f) ms = %.2f (%.2f) = %.2f (%.2f) of the mix ceiling (%.0f %% writes) | — |"
-               % (m["value"], me["value"], m["ms_per_step"], me["ms_per_step"], m["k_join_materialize_ms"], me["k_join_materialize_ms"], m["k_join_materialize_frac_of_8TBs"], me["k_join_materialize_frac_of_8TBs"],
-                  m["frac_of_mix_ceiling"], me["frac_of_mix_ceiling"], 100 * m["write_share_of_bytes"]))
-    out.append("| 4: exact passes only | %.1f | | `k_scatter_wc` + `k_hist` | | |" % bzx["value"])
-    out.append("| PK–FK 2^24 ⋈ 2^27 Zipf, PK side builds / Zipf side designated to build | %.1f / %.1f (round 3: 0.1) | %.2f / %.2f (1503) | §3.6 | | |" % (zp["value"], zb["value"], zp["ms_per_step"], zb["ms_per_step"]))
-    out.append("| 5: 2^33 ⋈ 2^33 over 8 GPUs | measured by the driver (`bench.py --gpus 8` → `hj_dist` over RCCL); model §7: %.1f ms/step = %.1f Gtuples/s per GPU | | | | |"
-               % (m8["modelled_step_ms"], m8["modelled_Gtuples_per_s_per_gpu"]))
+        d = load("phantom" + g)[0]
+        m = d["dist"]["model"]
+        mt = (d.get("materialize") or {}).get("model") or {}
+        out.append("| %s | %.2f GB | %.1f | %.1f | %.1f | %.1f ms | %s | %.1f / %s |"
+                   % (lab, m["bytes_per_link_direction"] / 1e9, m["link_ms"], m["local_ms_total"], m["exposed_local_ms"], m["modelled_step_ms"],
+                      ("%.1f ms (local %.1f, exposed %.1f)" % (mt["modelled_step_ms"], mt["local_ms_total"], mt["exposed_local_ms"])) if mt else "—",
+                      m["modelled_Gtuples_per_s_per_gpu"], ("%.1f" % mt["modelled_Gtuples_per_s_per_gpu"]) if mt else "—"))
     return out
 
 
@@ -195,56 +127,25 @@ def step_rows():
     b30, e30 = both("2p30")
     k, ke = b30["kernels"], e30["kernels"]
     m, me = b30["materialize"], e30["materialize"]
-    r = b30["roofline"]
     tot = k["k_part1_fast"]["ms_per_step"] + k["k_part2_fast"]["ms_per_step"] + k["k_join_count"]["ms_per_step"]
     tote = ke["k_part1_fast"]["ms_per_step"] + ke["k_part2_fast"]["ms_per_step"] + ke["k_join_count"]["ms_per_step"]
-    return ["Per step at 2^30⋈2^30 (`profiles/r4_bench_2p30.json`; the evidence call's process in brackets): 2 × `k_part1_fast` + 2 × `k_part2_fast` + `k_join_count` =",
+    return ["Per step at 2^30⋈2^30 (`profiles/%s_bench_2p30.json`; the evidence call's process in brackets): 2 × `k_part1_fast` + 2 × `k_part2_fast` + `k_join_count` =" % ROUND,
             "%.2f + %.2f + %.2f = %.1f ms (%.2f + %.2f + %.2f = %.1f ms) of kernels measured one at a time; the timed step runs S's two passes on a second"
             % (k["k_part1_fast"]["ms_per_step"], k["k_part2_fast"]["ms_per_step"], k["k_join_count"]["ms_per_step"], tot, ke["k_part1_fast"]["ms_per_step"], ke["k_part2_fast"]["ms_per_step"], ke["k_join_count"]["ms_per_step"], tote),
-            "stream beside R's (§3.5) and takes **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (14.8–16.2 ms over boxes and processes this round; the"
+            "stream beside R's (§3.5) and takes **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (the driver's runs: r4 15.14 ms = 141.8, r3 15.24 = 140.9, r2 17.27; round 1: 20.0–20.4)."
             % (b30["ms_per_step"], b30["value"], e30["ms_per_step"], e30["value"]),
-            "driver's round-3 run: 15.24 ms = 140.9; round 2: 17.27; round 1: 20.0–20.4). Materialising step: **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)**"
-            % (m["ms_per_step"], m["value"], me["ms_per_step"], me["value"]),
-            "(round 2, two probes: 22.3–23.3 ms = 92–96)."]
+            "Materialising step: **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (round 2, two probes: 22.3–23.3 ms = 92–96)."
+            % (m["ms_per_step"], m["value"], me["ms_per_step"], me["value"])]
 
 
 BLOCKS = {
-    ("README.md", "results"): readme_rows,
-    ("README.md", "model"): lambda: model_rows(False),
-    ("BASELINE.md", "results"): baseline_rows,
-    ("DESIGN.md", "results"): design_rows,
-    ("DESIGN.md", "model"): lambda: model_rows(True),
+    ("README.md", "results"): results_rows,
+    ("README.md", "model"): model_rows,
+    ("BASELINE.md", "results"): results_rows,
+    ("DESIGN.md", "results"): results_rows,
+    ("DESIGN.md", "model"): model_rows,
     ("DESIGN.md", "step"): step_rows,
 }
-
-
-def sync_profiles_readme(check):
-    """profiles/README.md: the binary's hash, the kernel-stats sentence, the GPU suite's count — from the files."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "README.md")
-    s = orig = open(path).read()
-    s = re.sub(r"final binary `libhj\.so` sha256 `[0-9a-f]{8}…`", "final binary `libhj.so` sha256 `%s…`" % sha()[:8], s)
-    rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_kernel_stats_2p30.csv")))}
-
-    def avg(sub):
-        for k, r in rows.items():
-            if sub in k:
-                return float(r["AverageNs"]) / 1e6, r["Calls"]
-    e = load("2p30_evidence_call")[0]
-    k = e["kernels"]
-    m = re.search(r"2\^30: `k_part2_fast` \d+ calls avg [0-9.]+ ms.*?\(the bench line of that call: [^)]*\)\.", s)
-    if m:
-        s = s.replace(m.group(0), "2^30: `k_part2_fast` %s calls avg %.3f ms, `k_part1_fast` %.3f ms, `k_join` %.3f ms, `k_join_mat_reg` %s calls %.3f ms (the bench line of that call: %.2f / %.2f / %.2f / %.2f)."
-                      % (avg("k_part2_fast")[1], avg("k_part2_fast")[0], avg("k_part1_fast")[0], avg("k_join<")[0], avg("k_join_mat_reg")[1], avg("k_join_mat_reg")[0],
-                         k["k_part2_fast"]["ms_per_step"] / 2, k["k_part1_fast"]["ms_per_step"] / 2, k["k_join_count"]["ms_per_step"], e["materialize"]["k_join_materialize_ms"]))
-    t = open(os.path.join(ROOT, "profiles", "r4_gpu_tests.txt")).read().strip().split("\n")[-1]
-    mm = re.search(r"(\d+) passed, (\d+) skipped.* in ([0-9.]+)s", t)
-    if mm:
-        s = re.sub(r"`pytest -m gpu` of the final binary: \d+ passed, \d+ skipped \(the two RCCL world-2 tests\), \d+ s;",
-                   "`pytest -m gpu` of the final binary: %s passed, %s skipped (the two RCCL world-2 tests), %.0f s;" % (mm.group(1), mm.group(2), float(mm.group(3))), s)
-    if s != orig and not check:
-        open(path, "w").write(s)
-    return s != orig
 
 
 def main():
@@ -267,8 +168,6 @@ def main():
             stale.append(fname)
             if not check:
                 open(path, "w").write(s)
-    if sync_profiles_readme(check):
-        stale.append("profiles/README.md")
     print(("stale: " if check else "updated: ") + (", ".join(stale) or "nothing"))
     return 1 if (check and stale) else 0
 
