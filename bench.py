@@ -177,7 +177,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     traffic = None
     try:
         pmf = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_zipf.json")))
-        key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
+        key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom + "<")]
         if key and pmf.get("lib_sha256") == lib_sha256():
             traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
     except Exception:
@@ -860,7 +860,7 @@ def main():
         try:
             src = "profiles/r5_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
             pmf = json.load(open(os.path.join(ROOT, src)))
-            key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom)]
+            key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom + "<")]
             if key and pmf.get("lib_sha256") == lib_sha256():
                 traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
         except Exception:

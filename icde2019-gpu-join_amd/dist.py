@@ -158,7 +158,26 @@ class ShardedJoin:
         mask = (1 << 64) - 1
         return [(h[2 * i] + (h[2 * i + 1] << 32)) & mask for i in range(len(vals))]
 
-    def join(self, Rk, Rp, Sk, Sp, verify=False):
+    def join_materialize(self, Rk, Rp, Sk, Sp):
+        """The sharded MATERIALISING join of this driver (what hj_dist_rank_join_materialize is behind the C ABI): after the exchange
+        every rank materialises the (key, payR, payS) tuples of the partitions it owns and keeps them; the sizes are all-gathered.
+        Returns (global matches, (key, payR, payS) host columns of this rank's share, [tuples of every rank])."""
+        return self.join(Rk, Rp, Sk, Sp, materialize=True)
+
+    def _finish(self, materialize):
+        e = self.e
+        if not materialize:
+            m, agg = e.join_count()                               # unchanged single-GPU build+probe
+            gm, ga = self._allreduce_u64([m, agg])
+            return gm, ga
+        k, pr, ps = e.join_materialize()                          # this rank's share stays with it (SURVEY §8(e): the output stays sharded)
+        t = torch.tensor([len(k)], dtype=torch.int64, device=self.cdev)
+        allt = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(allt, t, group=self.ctl)
+        sizes = [int(x.item()) for x in allt]
+        return sum(sizes), (k, pr, ps), sizes
+
+    def join(self, Rk, Rp, Sk, Sp, verify=False, materialize=False):
         """Local slices of R and S (int32 device columns) → (global matches, global sum payR*payS mod 2^64).
 
         verify=True (first warm-up step of bench.py): the order-independent (key,payload) digest of everything
@@ -178,8 +197,7 @@ class ShardedJoin:
             e.partition(self.pkg.REL_R)
             e.partition(self.pkg.REL_S)
             self.last_received = (nR, nS)
-            m, agg = e.join_count()
-            return tuple(self._allreduce_u64([m, agg]))
+            return self._finish(materialize)
         plan = None
         if self.balance == "size":
             # which GPU owns which virtual shard must be the same for R and S: count both first (keys only, no data
@@ -212,9 +230,7 @@ class ShardedJoin:
                                    % (n_sent, d_sent, n_got, d_got))
         e.partition(self.pkg.REL_S)
         self.last_received = (totR, totS)
-        m, agg = e.join_count()                                   # unchanged single-GPU build+probe
-        gm, ga = self._allreduce_u64([m, agg])
-        return gm, ga
+        return self._finish(materialize)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

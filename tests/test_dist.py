@@ -49,6 +49,16 @@ def test_sharded_join_gloo_world3_size_aware():
     assert sum(a + b for a, b in res["received"]) == 20_000 + 50_001
 
 
+def test_sharded_materialising_join_gloo_world2_and_3():
+    """The materialising N>1 path at world 2 and 3 over gloo (CPU; the torch.distributed driver with the oracle as the local engine):
+    the union of the ranks' shares is the oracle's multiset (sum of the shares' order-independent checksums, sizes), every rank
+    holds only keys of its own shard; hash and size-aware shard placement."""
+    for world, env, port in ((2, {}, 29661), (3, {"HJ_DIST_CHUNK": "3000"}, 29663), (2, {"HJ_DIST_SKEW": "1", "HJ_DIST_BALANCE": "size"}, 29665)):
+        res = _run(world, dict(env, HJ_DIST_MATERIALIZE="1"), port)
+        assert res["got"] == res["expect"], res
+        assert len(res["sizes"]) == world and min(res["sizes"]) > 0
+
+
 def test_assign_by_size_is_deterministic_and_balanced():
     from importlib import import_module
     SJ = import_module(pkg().__name__ + ".dist").ShardedJoin
