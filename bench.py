@@ -691,7 +691,10 @@ def main():
     cdev = torch.device("cpu") if backend == "gloo" else dev   # where tensors of small collectives live
     # a CPU-side group for the end of the run: while rank 0 drives every GPU from one process (alt_transport_leg) the other ranks
     # must wait WITHOUT a collective kernel spinning on their GPU
-    quiet = dist.new_group(backend="gloo") if (use_dist and world > 1 and backend != "gloo") else None
+    quiet = None
+    if use_dist and world > 1 and backend != "gloo":
+        import datetime
+        quiet = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=40))   # (longer than the child's deadline)
     pkg = graft.load_package()
     n = 1 << a.log2n
     total_n = n * world
