@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -236,6 +237,145 @@ static bool level0_split_t(const int32_t *K, const int32_t *Pv, uint64_t n, uint
     return started && scattered;
 }
 
+// ---- the same split in ONE pass over the input (the co-processing path, round 5) ----
+// The histogram pass exists to make every partition one contiguous run; an upload does not need that.  Here every worker scatters its
+// chunk of the input into BLOCKS of tuples that it takes from a private arena as its partitions fill up — the reference's own layout
+// idea, fixed-size buckets handed out by bump allocation (join-primitives.cu:138-192), on the host and without atomics: one arena per
+// worker.  A partition is then a list of blocks (every block but a worker's last one per partition is full); nothing can overflow
+// whatever the key distribution, the input is read once (4 bytes per tuple instead of 4 + 4 + 1), and every flushed line is 64-byte
+// aligned (blocks are), so all of them leave with streaming stores.
+// one worker of the one-pass split: its chunk of the input goes, partition by partition, into blocks taken from [arena, arena_end) —
+// the worker's own part of the staging columns.  Everything by value: the workers share nothing but the input.
+static bool split_blocks_worker(const int32_t *K, const int32_t *Pv, const uint64_t lo, const uint64_t hi, uint64_t arena, const uint64_t arena_end,
+                                const uint32_t parts, const uint32_t block, int32_t *oK, int32_t *oP, const bool stream, std::vector<HostBlock> *out,
+                                std::atomic<uint64_t> *upto) {
+    uint64_t cur[4096]; // start of the partition's current block (tuples)
+    uint32_t cnt[4096]; // tuples in it (flushed + buffered); block = "needs one"
+    uint16_t ids[4096];
+    for (uint32_t p = 0; p < parts; p++) { cur[p] = 0; cnt[p] = block; }
+    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = (oP && Pv) ? (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4) : nullptr;
+    if (!bufK || (oP && Pv && !bufP)) { free(bufK); free(bufP); return false; }
+    std::vector<HostBlock> blocks;
+    std::vector<uint8_t> opened(parts, 0);
+    bool good = true;
+    uint64_t low = arena; // the lowest block still open: everything below it is complete
+    for (uint64_t b = lo; b < hi && good; b += 4096) {
+        const uint64_t m = std::min<uint64_t>(4096, hi - b);
+        shard_block<uint16_t>(K + b, m, parts, ids);
+        for (uint64_t j = 0; j < m; j++) {
+            const uint32_t p = ids[j];
+            uint32_t c = cnt[p];
+            if (c == block) { // the partition needs a (new) block
+                const bool was_low = opened[p] && cur[p] == low;
+                if (opened[p]) blocks.push_back(HostBlock{p, cur[p], c});
+                if (arena + block > arena_end) { good = false; break; } // cannot happen: the arena holds every case
+                cur[p] = arena; arena += block; c = 0; opened[p] = 1;
+                if (was_low) { // the lowest open block has just been closed: publish the new complete prefix of the arena
+                    low = cur[p];
+                    for (uint32_t q = 0; q < parts; q++) if (opened[q] && cur[q] < low) low = cur[q];
+                    if (upto) { wc_fence(); upto->store(low, std::memory_order_release); }
+                }
+            }
+            const uint32_t s = c & (HWC - 1);
+            bufK[p * HWC + s] = K[b + j];
+            if (bufP) bufP[p * HWC + s] = Pv[b + j];
+            cnt[p] = ++c;
+            if (s == HWC - 1) { // the line is complete: blocks are whole 64-byte lines, every line streams out
+                const uint64_t o = cur[p] + c - HWC;
+                if (stream) { wc_flush_line(oK + o, bufK + p * HWC); if (bufP) wc_flush_line(oP + o, bufP + p * HWC); }
+                else { memcpy(oK + o, bufK + p * HWC, HWC * 4); if (bufP) memcpy(oP + o, bufP + p * HWC, HWC * 4); }
+            }
+        }
+    }
+    for (uint32_t p = 0; p < parts && good; p++) {
+        if (!opened[p]) continue;
+        const uint32_t tail = cnt[p] & (HWC - 1);
+        const uint64_t o = cur[p] + cnt[p] - tail;
+        for (uint32_t j = 0; j < tail; j++) { oK[o + j] = bufK[p * HWC + j]; if (bufP) oP[o + j] = bufP[p * HWC + j]; }
+        blocks.push_back(HostBlock{p, cur[p], cnt[p]});
+    }
+    wc_fence();
+    free(bufK); free(bufP);
+    *out = std::move(blocks);
+    return good;
+}
+
+uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t threads) {
+    // partly filled blocks (one per partition and worker at most) cost capacity, small blocks cost uploads: an eighth of the mean
+    // (worker, partition) share, a power of two between 2^12 and 2^20 tuples
+    const uint64_t share = n / ((uint64_t)std::max(1u, threads) * std::max(1u, parts) * 8);
+    uint32_t b = 4096;
+    while (b < (1u << 20) && (uint64_t)b * 2 <= share) b *= 2;
+    return b;
+}
+
+// a worker needs at most ceil(chunk / block) + parts blocks (every partition may end on a partly filled one)
+static uint64_t split_arena_tuples(uint64_t chunk, uint32_t parts, uint32_t block) { return ((chunk + block - 1) / block + parts) * (uint64_t)block; }
+
+uint64_t host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads) {
+    if (threads < 1) threads = 1;
+    const uint32_t block = host_split_block_size(n, parts, threads);
+    uint64_t cap = 0;
+    for (uint32_t t = 0; t < threads; t++) cap += split_arena_tuples(n * (t + 1) / threads - n * t / threads, parts, block);
+    return cap;
+}
+
+bool host_level0_split_blocks(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads, int32_t *oK, int32_t *oP,
+                              std::vector<HostBlock> &blocks, std::vector<uint64_t> &part_size, const std::vector<int> *pin_cpus,
+                              const std::function<void(const HostSplitProgress &)> *while_running) {
+    if (threads < 1) threads = 1;
+    if (parts > 4096) return false;
+    const uint32_t block = host_split_block_size(n, parts, threads);
+    const bool stream = host_has_streaming_stores() && (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
+    const bool pin = pin_cpus && !pin_cpus->empty();
+    std::vector<std::vector<HostBlock>> mine(threads);
+    std::vector<char> okv(threads, 1);
+    HostSplitProgress prog;
+    std::vector<uint64_t> &astart = prog.arena;
+    astart.assign(threads + 1, 0);
+    for (uint32_t t = 0; t < threads; t++) astart[t + 1] = astart[t] + split_arena_tuples(n * (t + 1) / threads - n * t / threads, parts, block);
+    prog.upto.reset(new std::atomic<uint64_t>[(size_t)threads * 8]);
+    for (uint32_t t = 0; t < threads; t++) prog.upto[(size_t)t * 8].store(astart[t], std::memory_order_relaxed);
+    std::atomic<uint32_t> finished{0};
+    {
+        std::vector<std::thread> th;
+        bool started = true;
+        auto run = [=, &mine, &okv, &astart, &prog, &finished](uint32_t t) {
+            if (pin) {
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                for (int c : *pin_cpus) CPU_SET(c, &set);
+                (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+            }
+            okv[t] = split_blocks_worker(K, Pv, n * t / threads, n * (t + 1) / threads, astart[t], astart[t + 1], parts, block, oK, oP, stream, &mine[t],
+                                         &prog.upto[(size_t)t * 8]) ? 1 : 0;
+            finished.fetch_add(1, std::memory_order_release);
+        };
+        const bool own_share = !pin && !while_running; // the calling thread is worker 0
+        try {
+            for (uint32_t t = own_share ? 1 : 0; t < threads; t++) th.emplace_back(run, t);
+        } catch (const std::system_error &) { started = false; }
+        if (started && own_share) run(0);
+        if (while_running) {
+            while (finished.load(std::memory_order_acquire) < th.size()) {
+                (*while_running)(prog);
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+        for (auto &x : th) x.join();
+        if (while_running && started) (*while_running)(prog);
+        if (!started) return false;
+    }
+    for (char c : okv) if (!c) return false;
+    blocks.clear();
+    part_size.assign(parts, 0);
+    for (uint32_t t = 0; t < threads; t++)
+        for (const HostBlock &hb : mine[t]) { blocks.push_back(hb); part_size[hb.part] += hb.count; }
+    // by partition, then by address: neighbours in the staging columns stay neighbours (the caller merges them into one upload)
+    std::sort(blocks.begin(), blocks.end(), [](const HostBlock &a, const HostBlock &b) { return a.part != b.part ? a.part < b.part : a.start < b.start; });
+    return true;
+}
+
 bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads,
                        int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus) {
     return parts <= 256 ? level0_split_t<uint8_t>(K, Pv, n, parts, threads, oK, oP, off, pin_cpus)
@@ -259,6 +399,59 @@ int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t p = 0; p <= parts; p++) offsets[p] = off[p];
     if (gbs) *gbs = dt > 0 ? (out_pays ? 16.0 : 8.0) * (double)n / dt / 1e9 : 0;
+    return HJ_OK;
+}
+
+uint64_t hj_host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads) {
+    if (parts == 0 || parts > 4096) return 0;
+    if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    return host_split_blocks_capacity(n, parts, threads);
+}
+
+int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads, int32_t *out_keys,
+                         int32_t *out_pays, uint64_t cap, uint32_t *block_part, uint64_t *block_start, uint32_t *block_count,
+                         uint64_t max_blocks, uint64_t *n_blocks, double *gbs) {
+    if ((n && (!keys || !out_keys)) || !n_blocks || parts == 0 || parts > 4096) return HJ_EINVAL;
+    if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (cap < host_split_blocks_capacity(n, parts, threads)) return HJ_ECAPACITY;
+    std::vector<HostBlock> blocks;
+    std::vector<uint64_t> psize;
+    // HJ_HOST_SPLIT_TEST_PROGRESS=1 (tests): take the complete prefixes the split publishes while it runs the way an uploader would —
+    // copy them out at once — and check afterwards that what was copied was final
+    struct Snap { uint64_t start; std::vector<int32_t> k; };
+    std::vector<Snap> snaps;
+    std::vector<uint64_t> sent, arena;
+    std::function<void(const HostSplitProgress &)> snoop = [&](const HostSplitProgress &pg) {
+        if (sent.empty()) { sent.assign(pg.arena.begin(), pg.arena.end() - 1); arena = pg.arena; }
+        for (uint32_t t = 0; t + 1 < pg.arena.size(); t++) {
+            const uint64_t d = pg.done(t);
+            if (d > sent[t]) { snaps.push_back(Snap{sent[t], std::vector<int32_t>(out_keys + sent[t], out_keys + d)}); sent[t] = d; }
+        }
+    };
+    const char *tp = getenv("HJ_HOST_SPLIT_TEST_PROGRESS");
+    const bool snooping = tp && atoi(tp) == 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!host_level0_split_blocks(keys, pays, n, parts, threads, out_keys, out_pays, blocks, psize, nullptr, snooping ? &snoop : nullptr)) return HJ_ENOMEM;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (snooping) {
+        uint64_t covered = 0, in_full_blocks = 0;
+        for (const Snap &sn : snaps) {
+            if (memcmp(sn.k.data(), out_keys + sn.start, sn.k.size() * 4) != 0) return HJ_EIO; // published before it was complete
+            covered += sn.k.size();
+        }
+        const uint32_t bs = host_split_block_size(n, parts, threads);
+        for (const HostBlock &hb : blocks) { // everything below a worker's mark is whole, FULL blocks
+            const size_t t = (size_t)(std::upper_bound(arena.begin(), arena.end(), hb.start) - arena.begin()) - 1;
+            if (!sent.empty() && hb.start < sent[t]) { if (hb.count != bs || hb.start + bs > sent[t]) return HJ_EIO; in_full_blocks += hb.count; }
+        }
+        if (covered != in_full_blocks) return HJ_EIO;
+        if (gbs) *gbs = (double)covered; // (the test reads how much was published)
+        gbs = nullptr;
+    }
+    *n_blocks = blocks.size();
+    if (blocks.size() > max_blocks || (blocks.size() && (!block_part || !block_start || !block_count))) return HJ_ECAPACITY;
+    for (size_t i = 0; i < blocks.size(); i++) { block_part[i] = blocks[i].part; block_start[i] = blocks[i].start; block_count[i] = (uint32_t)blocks[i].count; }
+    if (gbs) *gbs = dt > 0 ? (out_pays && pays ? 16.0 : 8.0) * (double)n / dt / 1e9 : 0;
     return HJ_OK;
 }
 

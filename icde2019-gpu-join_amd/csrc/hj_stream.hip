@@ -332,17 +332,26 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     int32_t *pk[2] = {nullptr, nullptr}, *pp[2] = {nullptr, nullptr};
     const uint64_t nn[2] = {nR, nS};
     const int32_t *srcK[2] = {h_R, h_S}, *srcP[2] = {h_Pr, h_Ps};
-    std::vector<uint64_t> off[2];
+    // The split is ONE pass over each input (round 5; the histogram pass of hj_host_split is gone from this path): a partition comes
+    // out as a list of blocks of the staging columns, which is all an upload needs.
+    // HJ_COPROCESS_SPLIT=2 (read per call: same-context A/B) runs the two-pass split instead.
+    std::vector<HostBlock> blk[2];
+    std::vector<uint64_t> psize[2];
+    const char *split_env = getenv("HJ_COPROCESS_SPLIT");
+    const bool two_pass = split_env && atoi(split_env) == 2, no_overlap = split_env && atoi(split_env) == 3; // 3: one pass, uploads after the split
+    std::vector<uint64_t> arena_of[2], sent_upto[2]; // one group: what went to the device while the split was running
+    uint64_t streamed[2] = {0, 0};
     int rc = 0;
     for (int r = 0; r < 2 && !rc; r++) {
-        if (c->host_cap[r] < nn[r] + 16 || (srcP[r] && !c->host_p[r])) {
+        const uint64_t need = host_split_blocks_capacity(nn[r], level0_parts, host_threads);
+        if (c->host_cap[r] < need + 16 || (srcP[r] && !c->host_p[r])) {
             if (c->host_k[r]) (void)hipHostFree(c->host_k[r]);
             if (c->host_p[r]) (void)hipHostFree(c->host_p[r]);
             c->host_k[r] = c->host_p[r] = nullptr; c->host_cap[r] = 0;
-            if (hipHostMalloc((void **)&c->host_k[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess ||
-                (srcP[r] && hipHostMalloc((void **)&c->host_p[r], (size_t)(nn[r] + 16) * 4, hipHostMallocDefault) != hipSuccess))
+            if (hipHostMalloc((void **)&c->host_k[r], (size_t)(need + 16) * 4, hipHostMallocDefault) != hipSuccess ||
+                (srcP[r] && hipHostMalloc((void **)&c->host_p[r], (size_t)(need + 16) * 4, hipHostMallocDefault) != hipSuccess))
                 rc = fail(c, HJ_ENOMEM, "pinned host buffers for the level-0 split");
-            else c->host_cap[r] = nn[r] + 16;
+            else c->host_cap[r] = need + 16;
         }
         pk[r] = c->host_k[r]; pp[r] = srcP[r] ? c->host_p[r] : nullptr;
     }
@@ -363,9 +372,43 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         if (!c->seg_ready[i] && hipEventCreateWithFlags(&c->seg_ready[i], hipEventDisableTiming) != hipSuccess) rc = fail(c, HJ_EHIP, "event");
     const bool one_group = nR + nS <= budget; // known before anything is split: R's upload may then start while S is being split
     auto split = [&](int r) -> int {
-        if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off[r], pin.empty() ? nullptr : &pin))
-            return fail(c, HJ_ENOMEM, "the level-0 split of %llu tuples could not allocate its write-combining lines / partition-id column or start its %u host threads",
+        if (two_pass) { // the round-4 split (histogram pass + scatter into contiguous partitions): one block per partition
+            std::vector<uint64_t> off;
+            if (!host_level0_split(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], off, pin.empty() ? nullptr : &pin))
+                return fail(c, HJ_ENOMEM, "the two-pass level-0 split of %llu tuples could not allocate or start its %u host threads", (unsigned long long)nn[r], host_threads);
+            blk[r].clear(); psize[r].assign(level0_parts, 0);
+            for (uint32_t p = 0; p < level0_parts; p++)
+                if (off[p + 1] > off[p]) { blk[r].push_back(HostBlock{p, off[p], off[p + 1] - off[p]}); psize[r][p] = off[p + 1] - off[p]; }
+            return 0;
+        }
+        // One residency group: which partition a tuple belongs to does not matter to the upload, so the complete part of every worker's
+        // arena crosses PCIe WHILE the split is still running (the reference overlaps staging, H2D and GPU work per batch, hjcp.cu:
+        // 1477-1618); the calling thread issues the copies and takes no share of the split.  What is left when the workers have
+        // finished — the partly filled blocks and the last few full ones — follows block by block (upload_rest).
+        std::vector<uint64_t> sent; // per worker: its arena is uploaded up to here
+        int up_rc = 0;
+        std::function<void(const HostSplitProgress &)> pump = [&](const HostSplitProgress &pg) {
+            const uint32_t W = (uint32_t)pg.arena.size() - 1;
+            if (sent.empty()) { sent.assign(pg.arena.begin(), pg.arena.end() - 1); arena_of[r] = pg.arena; }
+            const uint64_t chunk = std::max<uint64_t>(host_split_block_size(nn[r], level0_parts, W), std::min<uint64_t>((uint64_t)1 << 20, nn[r] / W / 8));
+            Buf &dk = r ? c->seg_k[0] : c->cop_k[0], &dp = r ? c->seg_p[0] : c->cop_p[0];
+            for (uint32_t t = 0; t < W && !up_rc; t++) {
+                const uint64_t d = pg.done(t);
+                if (d < sent[t] + chunk) continue;
+                const uint64_t cnt = d - sent[t];
+                if (hipMemcpyAsync((int32_t *)dk.p + streamed[r], pk[r] + sent[t], cnt * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess ||
+                    (pp[r] && hipMemcpyAsync((int32_t *)dp.p + streamed[r], pp[r] + sent[t], cnt * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess))
+                    up_rc = fail(c, HJ_EHIP, "H2D");
+                sent[t] = d; streamed[r] += cnt;
+            }
+        };
+        const bool streaming = one_group && !no_overlap && nn[r] >= ((uint64_t)1 << 16);
+        if (!host_level0_split_blocks(srcK[r], srcP[r], nn[r], level0_parts, host_threads, pk[r], pp[r], blk[r], psize[r], pin.empty() ? nullptr : &pin,
+                                      streaming ? &pump : nullptr))
+            return fail(c, HJ_ENOMEM, "the level-0 split of %llu tuples could not allocate its write-combining lines or start its %u host threads",
                         (unsigned long long)nn[r], host_threads);
+        if (up_rc) return up_rc;
+        if (streaming) { sent.push_back(~(uint64_t)0); sent_upto[r] = sent; }
         return 0;
     };
     // staging columns of one residency group: R's partitions of the group in cop_k/p[b], S's in seg_k/p[b], each a contiguous run
@@ -379,17 +422,46 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         }
         return 0;
     };
+    // blocks -> one staging column pair: the blocks (any order: a group is joined as one relation) sorted by address, neighbours
+    // merged into one copy.  Returns the tuples uploaded through *at.
+    auto upload_blocks = [&](int r, int b, std::vector<const HostBlock *> &list, uint64_t *at) -> int {
+        std::sort(list.begin(), list.end(), [](const HostBlock *x, const HostBlock *y) { return x->start < y->start; });
+        Buf &dk = r ? c->seg_k[b] : c->cop_k[b], &dp = r ? c->seg_p[b] : c->cop_p[b];
+        for (size_t i = 0; i < list.size();) {
+            const uint64_t o = list[i]->start;
+            uint64_t cnt = list[i]->count;
+            for (i++; i < list.size() && list[i]->start == o + cnt; i++) cnt += list[i]->count;
+            HIPCHK(c, hipMemcpyAsync((int32_t *)dk.p + *at, pk[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
+            if (pp[r]) HIPCHK(c, hipMemcpyAsync((int32_t *)dp.p + *at, pp[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
+            *at += cnt;
+        }
+        return 0;
+    };
+    // one group: the blocks of relation r that did not cross while its split was running (all of them when nothing was streamed)
+    auto upload_rest = [&](int r) -> int {
+        std::vector<const HostBlock *> rest;
+        for (const HostBlock &hb : blk[r]) {
+            bool gone = false;
+            if (!sent_upto[r].empty()) {
+                const size_t t = (size_t)(std::upper_bound(arena_of[r].begin(), arena_of[r].end(), hb.start) - arena_of[r].begin()) - 1;
+                gone = hb.start < sent_upto[r][t];
+            }
+            if (!gone) rest.push_back(&hb);
+        }
+        uint64_t at = streamed[r];
+        RET(upload_blocks(r, 0, rest, &at));
+        if (at != nn[r]) return fail(c, HJ_EINVAL, "internal: %llu of %llu tuples of relation %d were uploaded", (unsigned long long)at, (unsigned long long)nn[r], r);
+        return 0;
+    };
+    // ---- the pipeline: with one residency group both relations cross PCIe while the host is still splitting ----
+    bool r_uploaded = false;
+    if (!rc && one_group) rc = ensure_staging(nR, nS);
     const auto t_split0 = std::chrono::steady_clock::now();
     double split_s = 0;
     if (!rc) rc = split(0);
     split_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split0).count();
-    // ---- the pipeline (the reference overlaps staging, H2D and the GPU work per batch, hjcp.cu:1477-1618): with one residency group
-    // R crosses PCIe while the host is still splitting S ----
-    bool r_uploaded = false;
     if (!rc && one_group && nR) {
-        rc = ensure_staging(nR, nS);
-        if (!rc && hipMemcpyAsync(c->cop_k[0].p, pk[0], nR * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess) rc = fail(c, HJ_EHIP, "H2D");
-        if (!rc && pp[0] && hipMemcpyAsync(c->cop_p[0].p, pp[0], nR * 4, hipMemcpyHostToDevice, c->copy) != hipSuccess) rc = fail(c, HJ_EHIP, "H2D");
+        rc = upload_rest(0);
         r_uploaded = !rc;
     }
     const auto t_split1 = std::chrono::steady_clock::now();
@@ -405,7 +477,7 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     if (!rc) {
         std::vector<uint32_t> by(level0_parts);
         for (uint32_t p = 0; p < level0_parts; p++) by[p] = p;
-        auto size_of = [&](uint32_t p) { return (off[0][p + 1] - off[0][p]) + (off[1][p + 1] - off[1][p]); };
+        auto size_of = [&](uint32_t p) { return psize[0][p] + psize[1][p]; };
         if (!one_group) std::stable_sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return size_of(x) > size_of(y); });
         std::vector<uint64_t> load;
         for (uint32_t p : by) {
@@ -422,23 +494,31 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     for (int r = 0; r < 2 && !rc; r++) {
         gsz[r].assign(ngroups, 0);
         for (uint32_t g = 0; g < ngroups; g++) {
-            for (uint32_t p : groups[g]) gsz[r][g] += off[r][p + 1] - off[r][p];
+            for (uint32_t p : groups[g]) gsz[r][g] += psize[r][p];
             maxp[r] = std::max(maxp[r], gsz[r][g]);
         }
     }
     if (!rc && !r_uploaded) rc = ensure_staging(maxp[0], maxp[1]);
+    // the blocks of partition p are blk[r][first[r][p] .. first[r][p + 1]) (the split returns them sorted by partition)
+    std::vector<size_t> first[2];
+    for (int r = 0; r < 2 && !rc; r++) {
+        first[r].assign(level0_parts + 1, 0);
+        for (const HostBlock &hb : blk[r]) first[r][hb.part + 1]++;
+        for (uint32_t p = 0; p < level0_parts; p++) first[r][p + 1] += first[r][p];
+    }
     auto upload = [&](uint32_t g) -> int {
         const int b = (int)(g & 1);
-        uint64_t at[2] = {0, 0};
-        for (uint32_t p : groups[g])
-            for (int r = 0; r < 2; r++) {
-                const uint64_t o = off[r][p], cnt = off[r][p + 1] - o;
-                if (!cnt || (r == 0 && g == 0 && r_uploaded)) { at[r] += cnt; continue; }
-                Buf &dk = r ? c->seg_k[b] : c->cop_k[b], &dp = r ? c->seg_p[b] : c->cop_p[b];
-                HIPCHK(c, hipMemcpyAsync((int32_t *)dk.p + at[r], pk[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
-                if (pp[r]) HIPCHK(c, hipMemcpyAsync((int32_t *)dp.p + at[r], pp[r] + o, cnt * 4, hipMemcpyHostToDevice, c->copy));
-                at[r] += cnt;
-            }
+        for (int r = 0; r < 2; r++) {
+            if (r == 0 && g == 0 && r_uploaded) continue;
+            if (one_group) { RET(upload_rest(r)); continue; } // (S, or an empty R)
+            std::vector<const HostBlock *> list;
+            for (uint32_t p : groups[g])
+                for (size_t i = first[r][p]; i < first[r][p + 1]; i++) list.push_back(&blk[r][i]);
+            uint64_t at = 0;
+            RET(upload_blocks(r, b, list, &at));
+            if (at != gsz[r][g]) return fail(c, HJ_EINVAL, "internal: the blocks of residency group %u hold %llu tuples, its partitions %llu", g,
+                                             (unsigned long long)at, (unsigned long long)gsz[r][g]);
+        }
         HIPCHK(c, hipEventRecord(c->seg_ready[b], c->copy));
         return 0;
     };

@@ -369,6 +369,34 @@ def host_split(keys, pays, parts, threads=0):
     return ok, op, off, gbs.value
 
 
+def host_split_blocks(keys, pays, parts, threads=0):
+    """The one-pass host split hj_join_coprocess runs (no GPU): (out_keys, out_pays | None, block_part, block_start, block_count, GB/s).
+    The output columns are staging columns with holes: only the blocks are meaningful."""
+    keys, kp = _host_i32(keys)
+    pp = None
+    if pays is not None:
+        pays, pp = _host_i32(pays)
+    L = _lib.lib()
+    cap = L.hj_host_split_blocks_capacity(len(keys), parts, threads)
+
+    def aligned():
+        a = np.zeros(cap + 16, np.int32)
+        sh = (-a.ctypes.data) % 64 // 4
+        return a[sh:sh + cap]
+    ok = aligned()
+    op = aligned() if pays is not None else None
+    maxb = cap // 4096 + 1
+    bp, bs, bc = np.zeros(maxb, np.uint32), np.zeros(maxb, np.uint64), np.zeros(maxb, np.uint32)
+    nb, gbs = C.c_uint64(), C.c_double()
+    rc = L.hj_host_split_blocks(kp, pp, len(keys), parts, threads, ok.ctypes.data_as(C.c_void_p),
+                                op.ctypes.data_as(C.c_void_p) if op is not None else None, cap, bp.ctypes.data_as(C.c_void_p),
+                                bs.ctypes.data_as(C.c_void_p), bc.ctypes.data_as(C.c_void_p), maxb, C.byref(nb), C.byref(gbs))
+    if rc:
+        raise HJError(rc, "hj_host_split_blocks")
+    m = nb.value
+    return ok, op, bp[:m], bs[:m], bc[:m], gbs.value
+
+
 def shard_of(key, nshards):
     return _lib.lib().hj_shard_of(int(np.int32(key)), nshards)
 

@@ -175,6 +175,16 @@ int hj_join_coprocess(hj_ctx *ctx, const int32_t *h_R, const int32_t *h_Pr, uint
  * second by the whole split (the reference prints its partition throughput, pp.cu:218).  No GPU involved. */
 int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
                   int32_t *out_keys, int32_t *out_pays, uint64_t *offsets, double *gbs);
+/* The split hj_join_coprocess itself runs (round 5): ONE pass over the input, no histogram.  A partition comes out as a list of
+ * blocks of the output columns — each worker takes fixed-size blocks from its own arena as its partitions fill up, the reference's
+ * bucket-chain layout (join-primitives.cu:138-192) on the host — which is all the uploads need.  out_keys / out_pays hold cap >=
+ * hj_host_split_blocks_capacity(n, parts, threads) tuples (64-byte aligned for the streaming stores); out_pays is written only when
+ * pays is given.  Block i holds block_count[i] tuples of partition block_part[i] at out_*[block_start[i]..]; blocks come sorted by
+ * (partition, start).  *n_blocks = blocks produced; HJ_ECAPACITY if cap or max_blocks is too small.  No GPU involved. */
+uint64_t hj_host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads);
+int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
+                         int32_t *out_keys, int32_t *out_pays, uint64_t cap, uint32_t *block_part, uint64_t *block_start,
+                         uint32_t *block_count, uint64_t max_blocks, uint64_t *n_blocks, double *gbs);
 /* NUMA placement of the last hj_join_coprocess call (partition-primitives.cu:129-253 keeps partitions and threads per
  * socket): NUMA nodes of the host, the node closest to the context's GPU (-1 unknown: pinned staging is allocated there by
  * hipHostMalloc), and how many of that node's CPUs the split's workers were bound to (0: not bound — one node, HJ_NUMA=0). */

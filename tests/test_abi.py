@@ -112,6 +112,61 @@ def test_host_write_combining_split_parity():
         assert np.array_equal(off2, off) and np.all(op2 == 1) and np.array_equal(np.sort(ok2), np.sort(keys))
 
 
+def test_host_one_pass_block_split_parity():
+    """hj_host_split_blocks (what hj_join_coprocess runs: one pass, partitions as lists of blocks taken from per-worker arenas — the
+    reference's bucket chains, join-primitives.cu:138-192, on the host) against numpy: every block holds tuples of its partition only,
+    blocks do not overlap and stay inside the capacity, and the blocks together are exactly the input (key, payload) multiset."""
+    import numpy as np
+    p = pkg()
+    rng = np.random.default_rng(23)
+    for n, parts, threads in ((0, 4, 2), (1, 1, 1), (15, 16, 3), (5000, 7, 4), (300_007, 16, 8), (250_000, 64, 5), (70_000, 1000, 2),
+                              (1_200_000, 16, 3)):
+        keys = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+        keys[: n // 3] = rng.integers(0, 40, n // 3)            # a skewed third
+        pays = np.arange(n, dtype=np.int32)
+        for with_pay in (True, False):
+            ok, op, bp, bs, bc, gbs = p.host_split_blocks(keys, pays if with_pay else None, parts, threads)
+            assert int(bc.sum()) == n
+            assert np.all(bc > 0) and np.all(bp < parts)
+            order = np.lexsort((bs, bp))
+            assert np.array_equal(order, np.arange(len(bp)))        # sorted by (partition, start)
+            by_addr = np.argsort(bs)
+            ends = bs[by_addr].astype(np.int64) + bc[by_addr]
+            assert np.all(ends[:-1] <= bs[by_addr][1:].astype(np.int64)) and (len(ends) == 0 or ends[-1] <= len(ok))
+            got_k = np.concatenate([ok[int(s):int(s) + int(c)] for s, c in zip(bs, bc)]) if len(bs) else np.empty(0, np.int32)
+            owner = np.repeat(bp, bc)
+            if n:
+                assert np.array_equal(np.array([p.shard_of(int(k), parts) for k in got_k[:: max(1, n // 20000)]]), owner[:: max(1, n // 20000)])
+            if with_pay:
+                got_p = np.concatenate([op[int(s):int(s) + int(c)] for s, c in zip(bs, bc)]) if len(bs) else np.empty(0, np.int32)
+                assert np.array_equal(keys[got_p], got_k)               # payload travels with its key
+                assert np.array_equal(np.sort(got_p), np.arange(n))     # a permutation: nothing lost, nothing duplicated
+            else:
+                assert op is None and np.array_equal(np.sort(got_k), np.sort(keys))
+    # what the split publishes while it runs (the ranges hj_join_coprocess uploads beside the split): checked inside the library under
+    # HJ_HOST_SPLIT_TEST_PROGRESS=1 — every published range was final when published and consists of whole, full blocks
+    os.environ["HJ_HOST_SPLIT_TEST_PROGRESS"] = "1"
+    try:
+        published = 0
+        for n, parts, threads in ((2_000_000, 16, 4), (1_500_000, 3, 7), (900_000, 200, 2)):
+            keys = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+            keys[: n // 4] = 5                                     # one partition far ahead of the others
+            ok, op, bp, bs, bc, covered = p.host_split_blocks(keys, None, parts, threads)
+            assert int(bc.sum()) == n and 0 <= covered <= n
+            published += covered
+        assert published > 0
+    finally:
+        del os.environ["HJ_HOST_SPLIT_TEST_PROGRESS"]
+    # too small a capacity is refused, not overrun
+    L = p._lib.lib()
+    import ctypes as C
+    nb = C.c_uint64()
+    k = np.zeros(1000, np.int32)
+    o = np.zeros(1000, np.int32)
+    assert L.hj_host_split_blocks(k.ctypes.data_as(C.c_void_p), None, 1000, 4, 2, o.ctypes.data_as(C.c_void_p), None, 1000,
+                                  None, None, None, 0, C.byref(nb), None) == p.ECAPACITY
+
+
 def test_timinginfo_layout_matches_reference(tmp_path):
     """struct timingInfo (src/common.h:101-119): unsigned n; timeval start[5], end[5]; 8 doubles; 4 unsigned counters.
     Offsets on x86-64 (timeval = 16 bytes): the header a maintainer links against must agree field by field."""

@@ -772,14 +772,35 @@ def test_coprocess_residency_groups(P, monkeypatch):
     S[: nS // 3] = 77                                               # one level-0 partition far above any small budget
     Pr, Ps = np.arange(nR, dtype=np.int32), np.arange(nS, dtype=np.int32)
     expect = o.join_count(R, Pr, S, Ps, checksum=False)[:2]
-    seen = []
-    for budget in ("0", "1", "60000", "150000", "400000", "100000000"):
-        monkeypatch.setenv("HJ_COPROCESS_GROUP_TUPLES", budget)
-        with P.HashJoin(0) as hj:
-            assert hj.join_coprocess(R, Pr, S, Ps, 16, 4) == expect, budget
-            seen.append(hj.coprocess_groups())
-    assert seen[0] == 1 and seen[1] == 16 and seen[-1] == 1            # no override: the card's budget; 1 tuple: every pair alone
-    assert seen[1] >= seen[2] >= seen[3] >= seen[4] >= seen[5]
+    for split in ("1", "2"):                                        # one pass into blocks (default) / the two-pass split of round 4
+        monkeypatch.setenv("HJ_COPROCESS_SPLIT", split)
+        seen = []
+        for budget in ("0", "1", "60000", "150000", "400000", "100000000"):
+            monkeypatch.setenv("HJ_COPROCESS_GROUP_TUPLES", budget)
+            with P.HashJoin(0) as hj:
+                assert hj.join_coprocess(R, Pr, S, Ps, 16, 4) == expect, (split, budget)
+                seen.append(hj.coprocess_groups())
+        assert seen[0] == 1 and seen[1] == 16 and seen[-1] == 1        # no override: the card's budget; 1 tuple: every pair alone
+        assert seen[1] >= seen[2] >= seen[3] >= seen[4] >= seen[5]
+
+
+def test_coprocess_many_blocks_per_partition(P):
+    """The one-pass split hands a partition over as a list of blocks from every worker's arena; at 2^22 tuples a (worker, partition)
+    share is several blocks, merged into one upload where they are neighbours.  Same result as the resident join."""
+    n = 1 << 22
+    rng = np.random.default_rng(5)
+    R = rng.permutation(n).astype(np.int32)
+    S = rng.integers(0, n + n // 8, n).astype(np.int32)
+    Pr = np.arange(n, dtype=np.int32)
+    Ps = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    with P.HashJoin(0) as hj:
+        hj.load_host(P.REL_R, R, Pr)
+        hj.load_host(P.REL_S, S, Ps)
+        expect = hj.join()
+        assert expect[0] == int((S < n).sum())
+        for threads in (1, 5, 8):
+            assert hj.join_coprocess(R, Pr, S, Ps, 16, threads) == expect, threads
+        assert hj.join_coprocess(R, None, S, None, 16, 8)[0] == expect[0]
 
 
 def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
