@@ -16,7 +16,7 @@ python bench.py --workload zipf --steps 5 --warmup 2 --exact-only --no-cpu-basel
 python bench.py --workload zipf --zipf-sizes 24 27 --build-side 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_zipf_24_27_pk_builds.json 2>/dev/null
 python bench.py --workload zipf --zipf-sizes 24 27 --build-side 2 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_zipf_24_27_zipf_builds.json 2>/dev/null; echo "zipf-builds rc=$?"
 python bench.py --workload stream --steps 3 --warmup 1 > $OUT/bench_stream.json 2>/dev/null; echo "stream rc=$?"
-python bench.py --workload coprocess --log2n 27 --steps 3 --warmup 1 > $OUT/bench_coprocess.json 2>/dev/null; echo "coprocess rc=$?"
+python bench.py --workload coprocess --log2n 27 --steps 9 --warmup 2 > $OUT/bench_coprocess.json 2>/dev/null; echo "coprocess rc=$?"
 python bench.py --steps 5 --warmup 2 --force-dist --no-cpu-baseline > $OUT/bench_forcedist.json 2>/dev/null; echo "forcedist rc=$?"
 for g in 2 4 8; do python bench.py --steps 5 --warmup 2 --force-dist --phantom $g --no-cpu-baseline > $OUT/bench_phantom$g.json 2>/dev/null; done
 python bench.py --steps 5 --warmup 2 --force-dist --phantom 8 --single-group --no-cpu-baseline > $OUT/bench_phantom8_single_group.json 2>/dev/null

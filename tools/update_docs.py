@@ -96,7 +96,7 @@ def results_rows():
                % (zp["value"], zb["value"], zp["ms_per_step"], zb["ms_per_step"], mat(zp), mat(zb)))
     out.append("| S (2^30) streamed from pinned host memory against R (2^27) | %.1f | %.1f | %.1f GB/s H2D: transfer-bound | 2^28 tuples back to the host, one probe per segment: %.1f ms, %.1f GB/s D2H | |"
                % (st["value"], st["ms_per_step"], st["h2d_GBs"], st["materialize"]["ms"], st["materialize"]["d2h_GBs"]))
-    out.append("| R, S (2^27 each) in host memory, CPU–GPU co-processing | %.2f (r4 1.42) | %.0f (r4 189) | host split %.0f GB/s on the box's CPU quota, R uploaded under S's split, payload columns filled on the device | | |"
+    out.append("| R, S (2^27 each) in host memory, CPU–GPU co-processing | %.2f (r4 1.42) | %.0f (r4 189) | one-pass host split (%.0f GB/s on the box's CPU quota) with the uploads running beside it, payload columns filled on the device; same-context A/B against the two-pass split: `r5_coprocess_split_ab.txt` | | |"
                % (co["value"], co["ms_per_step"], co["host_split_GBs"]))
     b = [d for d in base if "2^30" in d["metric"]][0]["results"]
     out.append("| non-partitioned baselines at 2^30: perfect array / global chained table | %.1f / %.1f | | the curves the reference compares against (partitioned, same process: %.1f) | | |"
