@@ -129,8 +129,6 @@ hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &v
 hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, uint32_t nwg, bool any_heavy, bool any_light);
 hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
                                 uint64_t *sbeg, uint64_t *send, uint32_t *flag, uint64_t *received, uint64_t *received_self = nullptr);
-hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag);
-hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end);
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op);
 hipError_t launch_join_plan(hipStream_t st, const JoinArgs &a, uint32_t nparts, uint32_t *items_cnt, uint64_t *zero2, uint64_t *zero_cursor);
@@ -154,7 +152,6 @@ hipError_t launch_np_perfect(hipStream_t st, const int32_t *bk, uint64_t nb, con
 hipError_t launch_np_chained(hipStream_t st, const int32_t *bk, const int32_t *bp, uint64_t nb, const int32_t *pk, const int32_t *pp,
                              uint64_t np, uint32_t log_slots, int32_t *head, int32_t *next, uint64_t *out2);
 hipError_t launch_dot(hipStream_t st, const int32_t *a, const int32_t *b, const uint64_t *n_ptr, uint64_t cap, uint64_t *out);
-hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out);
 hipError_t launch_fill(hipStream_t st, int32_t *p, uint64_t n, int mode, uint64_t first);
 hipError_t launch_gen_unique(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t domain, uint64_t seed);
 hipError_t launch_gen_zipf(hipStream_t st, int32_t *keys, uint64_t n, uint64_t first, uint64_t alphabet, double theta, uint64_t seed);

@@ -783,16 +783,6 @@ hipError_t launch_dot(hipStream_t st, const int32_t *a, const int32_t *b, const 
     return hipGetLastError();
 }
 
-// sum of a device-sized uint64 array (per-wave aggregates) into *out (zeroed by the caller)
-__global__ __launch_bounds__(256) void k_reduce64(const uint64_t *__restrict__ data, const uint32_t *__restrict__ len_ptr,
-                                                  uint64_t mul, unsigned long long *__restrict__ out) {
-    const uint64_t L = len_ptr ? (uint64_t)(*len_ptr) * mul : mul;
-    uint64_t s = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (uint64_t)gridDim.x * blockDim.x) s += data[i];
-    s = wave_sum64(s);
-    if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
-}
-
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------------
@@ -905,12 +895,6 @@ hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bo
 
 hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2) {
     hipLaunchKernelGGL(k_sum2, dim3(256), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2));
-    HJ_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t launch_reduce64(hipStream_t st, const uint64_t *data, const uint32_t *len_ptr, uint64_t mul, uint64_t *out) {
-    hipLaunchKernelGGL(k_reduce64, dim3(512), dim3(256), 0, st, data, len_ptr, mul, reinterpret_cast<unsigned long long *>(out));
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -796,17 +796,6 @@ hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G
     return hipGetLastError();
 }
 
-// flag |= any of the n gathered flags (the overflow flags of every rank's level-0 split, after an all-gather)
-__global__ void k_or_flags(const uint32_t *__restrict__ gathered, uint32_t n, uint32_t *__restrict__ flag) {
-    uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v |= gathered[i];
-    if (v) *flag = 1u;
-}
-hipError_t launch_or_flags(hipStream_t st, const uint32_t *gathered, uint32_t n, uint32_t *flag) {
-    hipLaunchKernelGGL(k_or_flags, dim3(1), dim3(64), 0, st, gathered, n, flag);
-    return hipGetLastError();
-}
-
 // pass 2: one workgroup per parent = the spp input segments [sbeg, send) of that parent
 template <int U>
 __device__ __forceinline__ void part2_fast_body(const FastArgs &a, const uint32_t parent, unsigned char *smem) {
@@ -937,11 +926,10 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
     uint64_t lines = n16 / 8, pow2 = 1;
     while (pow2 * 2 <= lines) pow2 *= 2;
     const uint64_t used16 = kind == 1 ? pow2 * 8 : n16; // the scatter covers the largest power-of-two number of lines
-    static int blocks = 0, unr = 0, nt = 0;
+    static int blocks = 0, nt = 0;
     static std::once_flag once; // experiment knobs, read once (contexts on several host threads may get here together)
     std::call_once(once, [] {
         const char *e = getenv("HJ_UB_BLOCKS"); blocks = e ? atoi(e) : 16384;
-        const char *f = getenv("HJ_UB_UNROLL"); unr = f ? atoi(f) : 2;
         const char *h = getenv("HJ_UB_NT"); nt = h ? atoi(h) : 0;
     });
     dim3 g(blocks), b(256);
@@ -951,16 +939,10 @@ hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int3
         hipLaunchKernelGGL(k_ubench_oneway, g, b, 0, st, (const int4 *)ik, (const int4 *)ip, (int4 *)ok, (int4 *)op, n16, kind == 3);
         return hipGetLastError();
     }
-    if (kind == 0) { if (unr == 1) UB(0, 1); else if (unr == 2) UB(0, 2); else if (unr == 8) UB(0, 8); else UB(0, 4); }
-    else { if (unr == 1) UB(1, 1); else if (unr == 2) UB(1, 2); else if (unr == 8) UB(1, 8); else UB(1, 4); }
+    // two 16-byte loads of each column in flight per lane (1, 4 and 8 were swept in round 3: no better; the instances are gone)
+    if (kind == 0) UB(0, 2); else UB(1, 2);
 #undef UB
     return hipGetLastError();
-}
-
-// partition ranges from an offsets array (single-pass / unpartitioned layouts): beg[i] = off[i], end[i] = off[i+1]
-__global__ void k_range_from_offsets(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ beg, uint64_t *__restrict__ end) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { beg[i] = off[i]; end[i] = off[i + 1]; }
 }
 
 // gap-free copy of a partitioned relation given as ranges: partition p moves to [off[p], off[p+1]) (introspection)
@@ -1151,11 +1133,6 @@ hipError_t launch_part2_fast2(hipStream_t st, const FastArgs &fa, const FastArgs
     return hipGetLastError();
 }
 
-hipError_t launch_range_from_offsets(hipStream_t st, const uint64_t *off, uint32_t n, uint64_t *beg, uint64_t *end) {
-    hipLaunchKernelGGL(k_range_from_offsets, dim3((n + 255) / 256), dim3(256), 0, st, off, n, beg, end);
-    HJ_LAUNCH_CHECK();
-    return hipSuccess;
-}
 
 hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, const uint64_t *beg, const uint64_t *end,
                           uint32_t nparts, const uint64_t *off, int32_t *ok, int32_t *op) {

@@ -74,15 +74,16 @@ def _run(devices, R, S, cuts=None, dist_cfg=None, ctx_cfg=None, payload="rowid")
     return stats, transport
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sliced_exchange_ranks_share_one_gpu(world):
-    """World sizes 2 and 3 (not a power of two) on cuda:0: the sliced fixed-size path (two-pass radix bits forced so that
-    it applies at test sizes), 1 to 5 slices, uneven local sizes, an empty rank."""
+    """World sizes 2, 3 (not a power of two) and 8 (the level-0 split with more than four shards: its own kernel instance,
+    k_part1_fast<2, 1, false>) on cuda:0: the sliced fixed-size path (two-pass radix bits forced so that it applies at test
+    sizes), 1 to 5 slices, uneven local sizes, an empty rank."""
     R, S = _inputs(300_000, 700_001, 5, "unique")
     for slices in (1, 3, 5):
         stats, transport = _run([0] * world, R, S, dist_cfg=dict(slices=slices), ctx_cfg=dict(bits1=5, bits2=4))
         assert transport == "device-copy" and all(s["path"] == "sliced" for s in stats), stats
-    cuts = [0.5, 0.5, 1.0][:world] if world == 3 else [0.2, 1.0]       # rank 1 of 3 holds nothing; 20/80 at world 2
+    cuts = [0.2, 1.0] if world == 2 else [max(i, 1) / (world - 1) for i in range(world - 1)] + [1.0]   # 20/80; rank 1 of 3 (of 8) holds nothing
     stats, _ = _run([0] * world, R, S, cuts=cuts, dist_cfg=dict(slices=4), ctx_cfg=dict(bits1=5, bits2=4))
     assert all(s["path"] == "sliced" for s in stats)
     R, S = _inputs(200_000, 200_000, 6, "dups")
@@ -316,7 +317,7 @@ def _run_materialize(devices, R, S, cuts=None, dist_cfg=None, ctx_cfg=None, cap_
     return stats
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_materialising_join_ranks_share_one_gpu(world):
     """the sharded materialising join at world 2 and 3 on cuda:0 (device-copy transport) — sliced path with one
     and with two probe-side groups (the second appends to the first's output), duplicates on both sides, an empty rank."""
@@ -324,7 +325,7 @@ def test_materialising_join_ranks_share_one_gpu(world):
     for slices in (1, 3):
         _run_materialize([0] * world, R, S, dist_cfg=dict(slices=slices), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
     _run_materialize([0] * world, R, S, dist_cfg=dict(slices=3, single_group=True), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
-    cuts = [0.5, 0.5, 1.0][:world] if world == 3 else [0.0, 1.0]         # a rank that holds nothing
+    cuts = [0.0, 1.0] if world == 2 else [max(i, 1) / (world - 1) for i in range(world - 1)] + [1.0]   # a rank that holds nothing
     _run_materialize([0] * world, R, S, cuts=cuts, dist_cfg=dict(slices=4), ctx_cfg=dict(bits1=5, bits2=4), expect_paths="sliced")
     R, S = _inputs(60_000, 60_000, 32, "dups")                            # ~6 x 6 matches per key, negative keys
     _run_materialize([0] * world, R, S, dist_cfg=dict(slices=2), ctx_cfg=dict(bits1=4, bits2=3), expect_paths="sliced")

@@ -818,7 +818,8 @@ def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
 
 
 # ---- §8(f) rank 3: late materialisation (jp.cu:1420-1557) / rank 4: non-partitioned baselines (jp.cu:628-742) ----
-@pytest.mark.parametrize("cfg", [None, dict(bits1=5, bits2=4), dict(build_side=2)])
+# (bits 8+8: 16 radix bits -> the kernels that compare 16-bit tags, k_join<true, 2>)
+@pytest.mark.parametrize("cfg", [None, dict(bits1=5, bits2=4), dict(build_side=2), dict(bits1=8, bits2=8)])
 def test_late_materialize(P, cfg):
     rng = np.random.default_rng(31)
     nR, nS, c1, c2 = 30_000, 100_000, 3, 2
@@ -844,6 +845,35 @@ def test_late_materialize(P, cfg):
         finally:
             hj.device_free(dDr)
             hj.device_free(dDs)
+
+
+def test_hbm_ceiling_microbenchmarks_move_what_they_say(P):
+    """hj_ubench (the same-run HBM ceilings bench.py prices the pass kernels against): the copy really copies both columns, the line
+    scatter writes every 128-byte line of its power-of-two prefix exactly once, the write-only stream writes, the read-only stream
+    leaves the output alone — and each reports a rate."""
+    import torch
+    n = (1 << 20) + 4096
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, generator=g).to(dev)
+    b = torch.arange(n, dtype=torch.int32, device=dev)
+    with P.HashJoin(0) as hj:
+        c, d = torch.zeros_like(a), torch.zeros_like(b)
+        assert hj.ubench("copy", a, b, c, d, n, reps=2) > 0
+        assert torch.equal(c, a) and torch.equal(d, b)
+        c.fill_(-1)
+        d.fill_(-1)
+        assert hj.ubench("line_scatter", a, b, c, d, n, reps=2) > 0
+        m = 1 << 20                                                  # the largest power-of-two number of 128-B lines: 2^20 tuples
+        lines_in = b[:m].view(-1, 32)                                # payload = row id: a line is 32 consecutive ids
+        lines_out = d[:m].view(-1, 32)
+        assert torch.equal(lines_out[:, 1:] - lines_out[:, :1], lines_in[:, 1:] - lines_in[:, :1])   # whole lines, order kept inside
+        assert torch.equal(torch.sort(lines_out[:, 0]).values, lines_in[:, 0])                          # every line exactly once
+        assert torch.equal(a[d[:m].long()], c[:m])                   # the key column went with it
+        assert bool((d[m:] == -1).all())
+        c.fill_(-1)
+        assert hj.ubench("read", a, b, c, d, n, reps=2) > 0 and bool((c == -1).all())
+        assert hj.ubench("write", a, b, c, d, n, reps=2) > 0 and not bool((c == -1).any())
 
 
 def test_nonpartitioned_baselines(P, golden_dir):
