@@ -246,44 +246,98 @@ static bool level0_split_t(const int32_t *K, const int32_t *Pv, uint64_t n, uint
 // aligned (blocks are), so all of them leave with streaming stores.
 // one worker of the one-pass split: its chunk of the input goes, partition by partition, into blocks taken from [arena, arena_end) —
 // the worker's own part of the staging columns.  Everything by value: the workers share nothing but the input.
+//
+// The chunk is taken in batches that stay in the cache (>= 128 tuples per partition on average): partition ids of the batch (AVX2),
+// a counting sort of the batch into a local buffer (histogram on four interleaved counter sets, prefix, scatter — no data-dependent
+// branch per tuple), then every partition's RUN of the batch is appended to its current block: the partly filled line of the partition is
+// completed in a 64-byte staging line, whole lines go from the sorted buffer to the block with streaming stores, the rest waits in the
+// staging line.  (Until round 5's last version every tuple went through its partition's staging line on its own: a counter update, an
+// unpredictable "line full" branch and a 64-byte load behind sixteen 4-byte stores per line — ~10 cycles per tuple.)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void wc_stream_lines(int32_t *dst, const int32_t *src, uint64_t lines) { // dst 64-byte aligned, src anywhere
+    for (uint64_t i = 0; i < lines; i++) {
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i * 16), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i * 16)));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i * 16 + 8), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i * 16 + 8)));
+    }
+}
+#else
+static void wc_stream_lines(int32_t *dst, const int32_t *src, uint64_t lines) { memcpy(dst, src, lines * HWC * 4); }
+#endif
+
 static bool split_blocks_worker(const int32_t *K, const int32_t *Pv, const uint64_t lo, const uint64_t hi, uint64_t arena, const uint64_t arena_end,
                                 const uint32_t parts, const uint32_t block, int32_t *oK, int32_t *oP, const bool stream, std::vector<HostBlock> *out,
                                 std::atomic<uint64_t> *upto) {
-    uint64_t cur[4096]; // start of the partition's current block (tuples)
-    uint32_t cnt[4096]; // tuples in it (flushed + buffered); block = "needs one"
-    uint16_t ids[4096];
-    for (uint32_t p = 0; p < parts; p++) { cur[p] = 0; cnt[p] = block; }
-    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = (oP && Pv) ? (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4) : nullptr;
-    if (!bufK || (oP && Pv && !bufP)) { free(bufK); free(bufP); return false; }
-    std::vector<HostBlock> blocks;
+    const bool pay = oP && Pv;
+    const uint32_t batch = std::min<uint32_t>(1u << 18, std::max<uint32_t>(4096, parts * 128));
+    std::vector<uint64_t> cur(parts, 0);        // start of the partition's current block (tuples)
+    std::vector<uint32_t> cnt(parts, block);    // tuples in it (flushed + staged); block = "needs one"
     std::vector<uint8_t> opened(parts, 0);
+    std::vector<uint16_t> ids(batch);
+    std::vector<uint32_t> hist((size_t)4 * parts), pos(parts);
+    std::vector<int32_t> sk(batch + 16), sp(pay ? batch + 16 : 0);
+    int32_t *bufK = (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4), *bufP = pay ? (int32_t *)aligned_alloc(64, (size_t)parts * HWC * 4) : nullptr;
+    if (!bufK || (pay && !bufP)) { free(bufK); free(bufP); return false; }
+    std::vector<HostBlock> blocks;
     bool good = true;
     uint64_t low = arena; // the lowest block still open: everything below it is complete
-    for (uint64_t b = lo; b < hi && good; b += 4096) {
-        const uint64_t m = std::min<uint64_t>(4096, hi - b);
-        shard_block<uint16_t>(K + b, m, parts, ids);
-        for (uint64_t j = 0; j < m; j++) {
-            const uint32_t p = ids[j];
-            uint32_t c = cnt[p];
-            if (c == block) { // the partition needs a (new) block
-                const bool was_low = opened[p] && cur[p] == low;
-                if (opened[p]) blocks.push_back(HostBlock{p, cur[p], c});
-                if (arena + block > arena_end) { good = false; break; } // cannot happen: the arena holds every case
-                cur[p] = arena; arena += block; c = 0; opened[p] = 1;
-                if (was_low) { // the lowest open block has just been closed: publish the new complete prefix of the arena
-                    low = cur[p];
-                    for (uint32_t q = 0; q < parts; q++) if (opened[q] && cur[q] < low) low = cur[q];
-                    if (upto) { wc_fence(); upto->store(low, std::memory_order_release); }
+    for (uint64_t b = lo; b < hi && good; b += batch) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(batch, hi - b);
+        shard_block<uint16_t>(K + b, m, parts, ids.data());
+        std::fill(hist.begin(), hist.end(), 0u);
+        {
+            uint32_t *h0 = hist.data(), *h1 = h0 + parts, *h2 = h1 + parts, *h3 = h2 + parts;
+            uint32_t j = 0;
+            for (; j + 4 <= m; j += 4) { h0[ids[j]]++; h1[ids[j + 1]]++; h2[ids[j + 2]]++; h3[ids[j + 3]]++; }
+            for (; j < m; j++) h0[ids[j]]++;
+            uint32_t run = 0;
+            for (uint32_t p = 0; p < parts; p++) { const uint32_t c = h0[p] + h1[p] + h2[p] + h3[p]; pos[p] = run; h0[p] = run; h1[p] = c; run += c; } // h0 = start, h1 = length
+        }
+        if (pay) for (uint32_t j = 0; j < m; j++) { const uint32_t o = pos[ids[j]]++; sk[o] = K[b + j]; sp[o] = Pv[b + j]; }
+        else for (uint32_t j = 0; j < m; j++) sk[pos[ids[j]]++] = K[b + j];
+        const uint32_t *start = hist.data(), *length = hist.data() + parts;
+        for (uint32_t p = 0; p < parts && good; p++) {
+            const int32_t *srcK = sk.data() + start[p], *srcP = pay ? sp.data() + start[p] : nullptr;
+            uint32_t len = length[p];
+            while (len) {
+                uint32_t c = cnt[p];
+                if (c == block) { // the partition needs a (new) block
+                    const bool was_low = opened[p] && cur[p] == low;
+                    if (opened[p]) blocks.push_back(HostBlock{p, cur[p], c});
+                    if (arena + block > arena_end) { good = false; break; } // cannot happen: the arena holds every case
+                    cur[p] = arena; arena += block; c = 0; opened[p] = 1;
+                    if (was_low) { // the lowest open block has just been closed: publish the new complete prefix of the arena
+                        low = cur[p];
+                        for (uint32_t q = 0; q < parts; q++) if (opened[q] && cur[q] < low) low = cur[q];
+                        if (upto) { wc_fence(); upto->store(low, std::memory_order_release); }
+                    }
                 }
-            }
-            const uint32_t s = c & (HWC - 1);
-            bufK[p * HWC + s] = K[b + j];
-            if (bufP) bufP[p * HWC + s] = Pv[b + j];
-            cnt[p] = ++c;
-            if (s == HWC - 1) { // the line is complete: blocks are whole 64-byte lines, every line streams out
-                const uint64_t o = cur[p] + c - HWC;
-                if (stream) { wc_flush_line(oK + o, bufK + p * HWC); if (bufP) wc_flush_line(oP + o, bufP + p * HWC); }
-                else { memcpy(oK + o, bufK + p * HWC, HWC * 4); if (bufP) memcpy(oP + o, bufP + p * HWC, HWC * 4); }
+                uint32_t take = std::min(len, block - c);
+                len -= take;
+                const uint32_t f = c & (HWC - 1);
+                if (f) { // complete the partition's partly filled line in its staging line first
+                    const uint32_t n1 = std::min(take, HWC - f);
+                    memcpy(bufK + p * HWC + f, srcK, n1 * 4);
+                    if (pay) memcpy(bufP + p * HWC + f, srcP, n1 * 4);
+                    if (f + n1 == HWC) {
+                        const uint64_t o = cur[p] + c - f;
+                        if (stream) { wc_flush_line(oK + o, bufK + p * HWC); if (pay) wc_flush_line(oP + o, bufP + p * HWC); }
+                        else { memcpy(oK + o, bufK + p * HWC, HWC * 4); if (pay) memcpy(oP + o, bufP + p * HWC, HWC * 4); }
+                    }
+                    c += n1; take -= n1; srcK += n1; if (pay) srcP += n1;
+                }
+                const uint32_t lines = take / HWC; // c is a whole number of lines here (or take is 0)
+                if (lines) {
+                    const uint64_t o = cur[p] + c;
+                    if (stream) { wc_stream_lines(oK + o, srcK, lines); if (pay) wc_stream_lines(oP + o, srcP, lines); }
+                    else { memcpy(oK + o, srcK, (size_t)lines * HWC * 4); if (pay) memcpy(oP + o, srcP, (size_t)lines * HWC * 4); }
+                    c += lines * HWC; take -= lines * HWC; srcK += lines * HWC; if (pay) srcP += lines * HWC;
+                }
+                if (take) { // the rest opens the next line in the staging line
+                    memcpy(bufK + p * HWC, srcK, take * 4);
+                    if (pay) memcpy(bufP + p * HWC, srcP, take * 4);
+                    c += take; srcK += take; if (pay) srcP += take;
+                }
+                cnt[p] = c;
             }
         }
     }
@@ -291,7 +345,7 @@ static bool split_blocks_worker(const int32_t *K, const int32_t *Pv, const uint6
         if (!opened[p]) continue;
         const uint32_t tail = cnt[p] & (HWC - 1);
         const uint64_t o = cur[p] + cnt[p] - tail;
-        for (uint32_t j = 0; j < tail; j++) { oK[o + j] = bufK[p * HWC + j]; if (bufP) oP[o + j] = bufP[p * HWC + j]; }
+        for (uint32_t j = 0; j < tail; j++) { oK[o + j] = bufK[p * HWC + j]; if (pay) oP[o + j] = bufP[p * HWC + j]; }
         blocks.push_back(HostBlock{p, cur[p], cnt[p]});
     }
     wc_fence();

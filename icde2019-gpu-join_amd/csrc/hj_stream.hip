@@ -288,6 +288,9 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     if ((nR && !h_R) || (nS && !h_S)) return fail(c, HJ_EINVAL, "keys == NULL");
     if (level0_parts == 0) level0_parts = 16;
     if (level0_parts > 4096) return fail(c, HJ_EINVAL, "level0_parts out of range");
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() * 1e3; };
+    double mark[6] = {0, 0, 0, 0, 0, 0}; // HJ_DEBUG: ms since entry at the end of each phase
     if (host_threads == 0) {
         host_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
         // containers: honour the cgroup v2 CPU quota (oversubscribed threads partition slower, not faster)
@@ -456,17 +459,21 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     // ---- the pipeline: with one residency group both relations cross PCIe while the host is still splitting ----
     bool r_uploaded = false;
     if (!rc && one_group) rc = ensure_staging(nR, nS);
+    mark[0] = since();
     const auto t_split0 = std::chrono::steady_clock::now();
     double split_s = 0;
     if (!rc) rc = split(0);
+    mark[1] = since();
     split_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split0).count();
     if (!rc && one_group && nR) {
         rc = upload_rest(0);
         r_uploaded = !rc;
     }
+    mark[2] = since();
     const auto t_split1 = std::chrono::steady_clock::now();
     if (!rc) rc = split(1);
     split_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_split1).count();
+    mark[3] = since();
     // bytes read + written by the scatter (keys, + payloads where given), like partition-primitives.cu:218
     c->host_split_gbs = split_s > 0 ? ((srcP[0] ? 16.0 : 8.0) * (double)nR + (srcP[1] ? 16.0 : 8.0) * (double)nS) / split_s / 1e9 : 0;
     // Residency groups (the reference decides which level-0 partitions are resident together with a knapsack over PARTS_RESIDENT
@@ -524,6 +531,7 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     };
     uint64_t tot_m = 0, tot_a = 0;
     if (!rc && ngroups) rc = upload(0);
+    mark[4] = since();
     for (uint32_t g = 0; g < ngroups && !rc; g++) {
         const int b = (int)(g & 1);
         if (g + 1 < ngroups && (rc = upload(g + 1))) break; // the other pair of buffers was joined + synchronised last round
@@ -536,6 +544,11 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
         tot_m += m; tot_a += a;
     }
     (void)hipStreamSynchronize(c->copy);
+    mark[5] = since();
+    if (getenv("HJ_DEBUG"))
+        fprintf(stderr, "[hj] coprocess: setup %.2f ms, split R %.2f, R's rest queued %.2f, split S %.2f, groups + rest queued %.2f, joins done %.2f (streamed while splitting: %llu + %llu tuples)\n",
+                mark[0], mark[1] - mark[0], mark[2] - mark[1], mark[3] - mark[2], mark[4] - mark[3], mark[5] - mark[4],
+                (unsigned long long)streamed[0], (unsigned long long)streamed[1]);
     c->rel[0].bound = c->rel[1].bound = false; // the staging buffers are not user relations
     invalidate(c);
     if (rc) return rc;
