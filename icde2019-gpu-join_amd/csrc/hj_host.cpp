@@ -354,11 +354,16 @@ static bool split_blocks_worker(const int32_t *K, const int32_t *Pv, const uint6
     return good;
 }
 
-uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t threads) {
+uint32_t host_split_workers(uint64_t n, uint32_t threads) {
+    // a worker per 2^16 tuples at least: every worker costs a partly filled block per partition, and a small input does not pay for threads
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max(1u, threads), n >> 16));
+}
+
+uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t workers) {
     // partly filled blocks (one per partition and worker at most) cost capacity, small blocks cost uploads: an eighth of the mean
-    // (worker, partition) share, a power of two between 2^12 and 2^20 tuples
-    const uint64_t share = n / ((uint64_t)std::max(1u, threads) * std::max(1u, parts) * 8);
-    uint32_t b = 4096;
+    // (worker, partition) share, a power of two between 2^8 and 2^20 tuples
+    const uint64_t share = n / ((uint64_t)std::max(1u, workers) * std::max(1u, parts) * 8);
+    uint32_t b = 256;
     while (b < (1u << 20) && (uint64_t)b * 2 <= share) b *= 2;
     return b;
 }
@@ -367,7 +372,7 @@ uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t threads) {
 static uint64_t split_arena_tuples(uint64_t chunk, uint32_t parts, uint32_t block) { return ((chunk + block - 1) / block + parts) * (uint64_t)block; }
 
 uint64_t host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads) {
-    if (threads < 1) threads = 1;
+    threads = host_split_workers(n, threads);
     const uint32_t block = host_split_block_size(n, parts, threads);
     uint64_t cap = 0;
     for (uint32_t t = 0; t < threads; t++) cap += split_arena_tuples(n * (t + 1) / threads - n * t / threads, parts, block);
@@ -377,8 +382,8 @@ uint64_t host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads
 bool host_level0_split_blocks(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t parts, uint32_t threads, int32_t *oK, int32_t *oP,
                               std::vector<HostBlock> &blocks, std::vector<uint64_t> &part_size, const std::vector<int> *pin_cpus,
                               const std::function<void(const HostSplitProgress &)> *while_running) {
-    if (threads < 1) threads = 1;
     if (parts > 4096) return false;
+    threads = host_split_workers(n, threads);
     const uint32_t block = host_split_block_size(n, parts, threads);
     const bool stream = host_has_streaming_stores() && (((uintptr_t)oK | (uintptr_t)oP) & 63) == 0;
     const bool pin = pin_cpus && !pin_cpus->empty();
@@ -493,7 +498,7 @@ int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, u
             if (memcmp(sn.k.data(), out_keys + sn.start, sn.k.size() * 4) != 0) return HJ_EIO; // published before it was complete
             covered += sn.k.size();
         }
-        const uint32_t bs = host_split_block_size(n, parts, threads);
+        const uint32_t bs = host_split_block_size(n, parts, host_split_workers(n, threads));
         for (const HostBlock &hb : blocks) { // everything below a worker's mark is whole, FULL blocks
             const size_t t = (size_t)(std::upper_bound(arena.begin(), arena.end(), hb.start) - arena.begin()) - 1;
             if (!sent.empty() && hb.start < sent[t]) { if (hb.count != bs || hb.start + bs > sent[t]) return HJ_EIO; in_full_blocks += hb.count; }

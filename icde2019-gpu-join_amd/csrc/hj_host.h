@@ -22,11 +22,12 @@ bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
                        int32_t *oK, int32_t *oP, std::vector<uint64_t> &off, const std::vector<int> *pin_cpus = nullptr);
 
 // The same split in ONE pass over the input, for the co-processing path: a partition comes out as a list of blocks (each worker takes
-// blocks of host_split_block_size() tuples from its own arena of the staging columns as its partitions fill up: nothing can overflow,
+// blocks of host_split_block_size() tuples (2^8 … 2^20) from its own arena of the staging columns as its partitions fill up: nothing can overflow,
 // there is no histogram pass and no partition-id column).  oK / oP must hold host_split_blocks_capacity(n, parts, threads) tuples and
 // be 64-byte aligned; oP is written only when Pv is given.  blocks: sorted by (partition, start); part_size[parts].
 struct HostBlock { uint32_t part; uint64_t start, count; };
-uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t threads);
+uint32_t host_split_workers(uint64_t n, uint32_t threads);                      // workers the split really starts: one per 2^16 tuples at least
+uint32_t host_split_block_size(uint64_t n, uint32_t parts, uint32_t workers);    // (workers = host_split_workers(n, threads))
 uint64_t host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads);
 // While the workers run: worker t's arena is [arena[t], arena[t + 1]) and everything in [arena[t], done(t)) is complete — whole blocks,
 // all of them full, their streaming stores fenced.  A caller that does not care which partition a tuple belongs to (one residency group)

@@ -416,7 +416,7 @@ int hj_join_coprocess(hj_ctx *c, const int32_t *h_R, const int32_t *h_Pr, uint64
     };
     // staging columns of one residency group: R's partitions of the group in cop_k/p[b], S's in seg_k/p[b], each a contiguous run
     auto ensure_staging = [&](uint64_t maxR, uint64_t maxS) -> int {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < (one_group ? 1 : 2); i++) { // one group: nothing to double-buffer
             RET(ensure(c, c->cop_k[i], (size_t)(maxR + PAD) * 4)); RET(ensure(c, c->cop_p[i], (size_t)(maxR + PAD) * 4));
             RET(ensure(c, c->seg_k[i], (size_t)(maxS + PAD) * 4)); RET(ensure(c, c->seg_p[i], (size_t)(maxS + PAD) * 4));
             // payloads that are not given: ones, filled on the device (the buffers keep them for every group of the call)

@@ -385,7 +385,7 @@ def host_split_blocks(keys, pays, parts, threads=0):
         return a[sh:sh + cap]
     ok = aligned()
     op = aligned() if pays is not None else None
-    maxb = cap // 4096 + 1
+    maxb = cap // 256 + 1
     bp, bs, bc = np.zeros(maxb, np.uint32), np.zeros(maxb, np.uint64), np.zeros(maxb, np.uint32)
     nb, gbs = C.c_uint64(), C.c_double()
     rc = L.hj_host_split_blocks(kp, pp, len(keys), parts, threads, ok.ctypes.data_as(C.c_void_p),

@@ -157,6 +157,12 @@ def test_host_one_pass_block_split_parity():
         assert published > 0
     finally:
         del os.environ["HJ_HOST_SPLIT_TEST_PROGRESS"]
+    # the staging capacity stays in proportion: at most an eighth more than the tuples once there is a block's worth per (worker,
+    # partition), and a small input does not pay for the threads and partitions it was offered (one worker per 2^16 tuples)
+    cap_of = p._lib.lib().hj_host_split_blocks_capacity
+    assert cap_of(0, 4096, 64) <= 1 << 20 and cap_of(1000, 16, 16) <= 8192
+    for n, parts, threads in ((1 << 20, 16, 16), (1 << 27, 16, 16), (1 << 31, 16, 64), (3_000_001, 16, 7)):
+        assert n <= cap_of(n, parts, threads) <= n + n // 8 + 2 * parts * 256 * threads, (n, parts, threads)
     # too small a capacity is refused, not overrun
     L = p._lib.lib()
     import ctypes as C
