@@ -803,6 +803,28 @@ def test_coprocess_many_blocks_per_partition(P):
         assert hj.join_coprocess(R, None, S, None, 16, 8)[0] == expect[0]
 
 
+def test_coprocess_2p24_with_payload_columns(P):
+    """2^24 x 2^24 from host memory WITH payload columns (four columns through the one-pass split and the uploads that run beside it),
+    against closed forms: unique keys on both sides -> 2^24 matches, aggregate = sum over the keys of payR * payS (torch, int64 wrap)."""
+    import torch
+    n = 1 << 24
+    g = torch.Generator().manual_seed(9)
+    R = torch.randperm(n, generator=g, dtype=torch.int32)
+    S = torch.randperm(n, generator=g, dtype=torch.int32)
+    Pr = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, generator=g)
+    Ps = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, generator=g)
+    pr_by_key = torch.empty(n, dtype=torch.int64)
+    ps_by_key = torch.empty(n, dtype=torch.int64)
+    pr_by_key[R.long()] = Pr.long()
+    ps_by_key[S.long()] = Ps.long()
+    expect = int((pr_by_key * ps_by_key).sum().item()) % 2**64          # int64 arithmetic wraps mod 2^64 like the device's
+    with P.HashJoin(0) as hj:
+        for threads in (0, 3):
+            m, agg = hj.join_coprocess(R.numpy(), Pr.numpy(), S.numpy(), Ps.numpy(), 16, threads)
+            assert (m, agg) == (n, expect), threads
+        assert hj.coprocess_groups() == 1
+
+
 def test_reference_entry_dispatch(P, golden_dir, capfd, monkeypatch):
     """hj_ClusteredProbe's three-way dispatch (hjcp.cu:2001-2008): resident / streamed S / co-processing."""
     R = _load(golden_dir, "unique_4096.bin")
