@@ -766,7 +766,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
     uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
-    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0; // experiment knobs are read per call: same-context A/B (tools/launch_ab.py)
+    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0; // experiment knobs are read per call: same-context A/B (tools/experiments/launch_ab.py)
     const bool atomic_plan = c->plan_atomic;
     if (nparts <= 1024 && !Pb.sampled && !general) { // one workgroup's worth of partitions: plan + scan + expand in one single-workgroup launch
         Timed t(c, "k_join_plan");

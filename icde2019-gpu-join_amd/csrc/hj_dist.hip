@@ -56,7 +56,7 @@ using namespace hjx;
 namespace {
 
 constexpr uint64_t PAD = 16;
-constexpr size_t MSG_CHUNK = (size_t)512 << 20; // RCCL 2.26 / ROCm 7 corrupted single messages of >= 2 GiB (tools/rccl_2gib_repro.py)
+constexpr size_t MSG_CHUNK = (size_t)512 << 20; // RCCL 2.26 / ROCm 7 corrupted single messages of >= 2 GiB (tools/experiments/rccl_2gib_repro.py)
 
 // librccl is bound at run time, not at link time: a process that has PyTorch loaded already carries PyTorch's own copy of
 // librccl, and a second copy pulled in by libhj.so's dependency list gives two sets of RCCL globals in one process (observed:

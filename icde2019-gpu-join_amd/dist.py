@@ -54,7 +54,7 @@ class ShardedJoin:
         return t
 
     # RCCL (2.26, ROCm 7) returns wrong data for a single all-to-all message of 2 GiB or more (measured:
-    # 2^28 int32 elements fine, 2^29 corrupted — tools/rccl_2gib_repro.py), and at 2 GPUs a peer's share of a 2^30-
+    # 2^28 int32 elements fine, 2^29 corrupted — tools/experiments/rccl_2gib_repro.py), and at 2 GPUs a peer's share of a 2^30-
     # tuple column is exactly 2^29 elements.  Columns therefore travel as grouped point-to-point
     # sends/receives of at most CHUNK elements (512 MiB): one ncclGroup per column = one all-to-all-v.
     CHUNK = 1 << 27

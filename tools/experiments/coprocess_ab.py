@@ -2,9 +2,9 @@
 """Same-context A/B of the co-processing join's host split: one pass into blocks with the uploads running beside it (the default), the same
 with the uploads after the split (HJ_COPROCESS_SPLIT=3), and the two-pass split of round 4
 (HJ_COPROCESS_SPLIT=2, read per call), alternating calls on the same context and the same host arrays.
-    python3 tools/coprocess_ab.py [log2n] [rounds]"""
+    python3 tools/experiments/coprocess_ab.py [log2n] [rounds]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import __graft_entry__ as g
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of experiment knobs on one box: tools/gpu_ab.sh "ENV1=.. ENV2=.." "ENV.." ...  (each arg = one environment, "-" = none)
+# A/B of experiment knobs on one box: tools/experiments/gpu_ab.sh "ENV1=.. ENV2=.." "ENV.." ...  (each arg = one environment, "-" = none)
 cd $GRAFT_REPO_ROOT
 summ='
 import json,sys

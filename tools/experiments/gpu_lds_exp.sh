@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_lds_exp.sh — LDS-side analysis of wc_fast, one box: the experiment builds of `make exp`
+# tools/experiments/gpu_lds_exp.sh — LDS-side analysis of wc_fast, one box: the experiment builds of `make exp`
 # (libhj_exp<N>.so, csrc/hj_part.hip HJ_EXP) copied over libhj.so one after the other; per build the pass kernels' times (two
 # alternating rounds) and one rocprofv3 --pmc pass of the LDS counters.  Output: gpurun_out/lds/.
 cd $GRAFT_REPO_ROOT
@@ -12,14 +12,14 @@ lib() { if [ "$1" = "0" ]; then cp $P/libhj_ship.so $P/libhj.so; else cp $P/libh
 for rep in 1 2; do
   for v in $VARIANTS; do
     lib $v
-    HJ_EXP_TAG=$v timeout 300 python3 tools/lds_exp.py 30 10 2>/dev/null | tee -a $OUT/times.txt
+    HJ_EXP_TAG=$v timeout 300 python3 tools/experiments/lds_exp.py 30 10 2>/dev/null | tee -a $OUT/times.txt
   done
 done
 cd /tmp && export TMPDIR=/tmp
 for v in $VARIANTS; do
   ( cd $GRAFT_REPO_ROOT && lib $v )
   HJ_EXP_TAG=$v timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_ADDR_CONFLICT \
-     --kernel-trace --output-format csv -d $OUT/pmc$v -- python3 $GRAFT_REPO_ROOT/tools/lds_exp.py 30 2 > $OUT/pmc$v.log 2>&1
+     --kernel-trace --output-format csv -d $OUT/pmc$v -- python3 $GRAFT_REPO_ROOT/tools/experiments/lds_exp.py 30 2 > $OUT/pmc$v.log 2>&1
   echo "pmc $v rc=$?"
 done
 cd $GRAFT_REPO_ROOT

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Thread scaling of the two host splits on this box (no GPU work): Mtuples/s of hj_host_split_blocks (one pass) and hj_host_split
 (two passes) at 2^log2n keys for a list of thread counts.
-    python3 tools/host_split_scaling.py [log2n] [threads,threads,...]"""
+    python3 tools/experiments/host_split_scaling.py [log2n] [threads,threads,...]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/launch_ab.py [rounds] [sizes...] — same-process A/B of the launch structure of a step: contexts that share
+"""tools/experiments/launch_ab.py [rounds] [sizes...] — same-process A/B of the launch structure of a step: contexts that share
 the SAME input columns and differ in $HJ_MERGE_LOG2 (both relations' passes in one launch per pass, no k_set_root, no event fork) and
 $HJ_PLAN_ATOMIC (plan + expand in one launch), interleaved round-robin; ms per hj_join step (wall, synchronised)."""
 import json
@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/lds_ab.py [log2n] [rounds] [reps] [variants...] — same-process A/B of the LDS-side variants of the write-combining rounds
+"""tools/experiments/lds_ab.py [log2n] [rounds] [reps] [variants...] — same-process A/B of the LDS-side variants of the write-combining rounds
 (csrc/hj_part.hip: template parameter WV of wc_fast, selected per launch by $HJ_WCV): the SAME buffers, the variants interleaved
 round-robin, per-kernel times from HIP events with the passes serialised; every variant's join count is checked first."""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 

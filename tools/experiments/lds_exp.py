@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/lds_exp.py [log2n] [reps] — the two histogram-free passes of both relations, timed per kernel (HIP events, passes serialised),
+"""tools/experiments/lds_exp.py [log2n] [reps] — the two histogram-free passes of both relations, timed per kernel (HIP events, passes serialised),
 nothing checked: the attribution builds of the LDS-side analysis (csrc/hj_part.hip HJ_EXP) write garbage on purpose.  Only
 k_part1_fast is meaningful under those builds (pass 2 reads what pass 1 wrote).  One JSON line."""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does rocprofv3's kernel trace survive a process that keeps creating short-lived host threads which launch kernels?  (hj_dist's
 in-process groups started one host thread per rank PER CALL; the GPU suite crashed under rocprofv3 — never without it — at its ~23rd
-test, some hundred such threads into the process.)  Usage (GPU box): rocprofv3 --kernel-trace --stats -d /tmp/x -- python3 tools/rocprof_thread_repro.py [threads]"""
+test, some hundred such threads into the process.)  Usage (GPU box): rocprofv3 --kernel-trace --stats -d /tmp/x -- python3 tools/experiments/rocprof_thread_repro.py [threads]"""
 import sys, threading
 import torch
 

@@ -1,6 +1,6 @@
 """hj_shard_split throughput on one GPU: 2^30 tuples, G = 2, 4, 8 shards (the pre-exchange step of the multi-GPU path)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch, __graft_entry__ as g
 pkg = g.load_package()

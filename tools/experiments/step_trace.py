@@ -1,8 +1,8 @@
 """Per-step times of the headline step over the first N steps of a fresh process (is there a settling phase?), with the device
 addresses of the input columns (does the level of a process follow where its buffers landed?).
-usage: python tools/step_trace.py [N=60] [log2n=30]"""
+usage: python tools/experiments/step_trace.py [N=60] [log2n=30]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.hjtest import pkg
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60

@@ -1,5 +1,5 @@
 import os, sys, subprocess, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = r'''
 import sys, os
 sys.path.insert(0, %r)

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/zipf_ab.py [rounds] — same-CONTEXT A/B of how the big relation of config 4 (PK-FK 2^27 x 2^31) is partitioned: one context, the
+"""tools/experiments/zipf_ab.py [rounds] — same-CONTEXT A/B of how the big relation of config 4 (PK-FK 2^27 x 2^31) is partitioned: one context, the
 same columns and partition buffers, variants switched by hj_configure (radix bits of the two passes) and per-call experiment knobs
 (HJ_FORCE_SAMPLED, HJ_TARGET_SPANS, HJ_VAR_GUIDE, HJ_REPLAN), interleaved; per-kernel ms from HIP events (passes serialised)."""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
