@@ -18,7 +18,6 @@
 #include <string>
 #include <system_error>
 #include <thread>
-#include <mutex>
 #include <vector>
 
 #include "hj.h"
@@ -932,19 +931,6 @@ int hj_create(hj_ctx **out, int device) {
     if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
     if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // bit 0: R, bit 1: S
     (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
-    {   // the library's kernels resolved for this device before any other host thread can launch one (hj_part.hip: preload_part_kernels)
-        static std::mutex mu;
-        static bool done[64] = {};
-        std::lock_guard<std::mutex> lock(mu);
-        if (device >= 64 || !done[device]) {
-            if (preload_part_kernels() != hipSuccess || preload_join_kernels() != hipSuccess || preload_util_kernels() != hipSuccess) {
-                (void)hipGetLastError();
-                hj_destroy(c);
-                return HJ_EHIP;
-            }
-            if (device < 64) done[device] = true;
-        }
-    }
     *out = c;
     return HJ_OK;
 }

@@ -1212,10 +1212,6 @@ int hj_dist_create_transport(hj_dist **out, int nranks, const int *devices, cons
         d->ranks.push_back(k);
         k->rank = r; k->world = nranks; k->own_ctx = true;
         rc = hj_create(&k->c, d->dev[r]);
-        if (!rc) { // (this file's own kernel resolved for the device here, by this one thread, like hj_create does for the library's)
-            hipFuncAttributes at;
-            if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_sum_ranks)) != hipSuccess) (void)hipGetLastError();
-        }
         if (!rc) rc = rank_init(k);
     }
     if (!rc) rc = make_links(d, transport ? transport : "");

@@ -159,10 +159,6 @@ hipError_t launch_digest(hipStream_t st, const int32_t *a, const int32_t *b, con
 hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const int32_t *pays, const uint64_t *beg,
                                     const uint64_t *end, uint32_t nparts, uint32_t id_shift, uint32_t id_base,
                                     uint64_t *misplaced, uint64_t *digests, uint64_t *sizes);
-// every kernel instance of a kernel file resolved for the current device (hj_create: once per device, one thread)
-hipError_t preload_part_kernels();
-hipError_t preload_join_kernels();
-hipError_t preload_util_kernels();
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n);
 hipError_t launch_shard_count(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nshards, uint64_t *counts);
 

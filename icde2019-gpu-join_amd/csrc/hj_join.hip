@@ -899,26 +899,4 @@ hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg,
     return hipSuccess;
 }
 
-
-// Every kernel instance of this file resolved for the current device NOW (hipFuncGetAttributes loads the code object and builds the
-// function like a first launch does).  hj_create calls the preload_* functions once per device under a lock: contexts are created by one
-// thread, joins are then enqueued by one host thread per rank (hj_dist) — without this their first launches of a kernel meet inside the
-// runtime's lazy initialisation (and, under rocprofv3, inside the profiler's registration of the kernel symbols: the GPU suite faulted
-// there in 3 of 26 profiled runs, profiles/r5_rocprof_suite_crash.txt).
-hipError_t preload_join_kernels() {
-    const void *fns[] = {
-        reinterpret_cast<const void *>(&k_join<true, 0, false>), reinterpret_cast<const void *>(&k_join<false, 0, false>),
-        reinterpret_cast<const void *>(&k_join<true, 2, false>), reinterpret_cast<const void *>(&k_join<false, 2, false>),
-        reinterpret_cast<const void *>(&k_join<true, 0, true>), reinterpret_cast<const void *>(&k_join<false, 0, true>),
-        reinterpret_cast<const void *>(&k_join_mat_reg<true, false, false>), reinterpret_cast<const void *>(&k_join_mat_reg<false, false, false>),
-        reinterpret_cast<const void *>(&k_join_mat_reg<true, true, false>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true, false>),
-        reinterpret_cast<const void *>(&k_join_mat_reg<true, true, true>), reinterpret_cast<const void *>(&k_join_mat_reg<false, true, true>),
-        reinterpret_cast<const void *>(&k_join_plan), reinterpret_cast<const void *>(&k_join_expand), reinterpret_cast<const void *>(&k_join_plan_fused),
-        reinterpret_cast<const void *>(&k_join_plan_atomic), reinterpret_cast<const void *>(&k_join_plan_gen), reinterpret_cast<const void *>(&k_join_expand_gen),
-        reinterpret_cast<const void *>(&k_sum2), reinterpret_cast<const void *>(&k_dot)};
-    hipFuncAttributes at;
-    for (const void *f : fns) { const hipError_t e = hipFuncGetAttributes(&at, f); if (e != hipSuccess) return e; }
-    return hipSuccess;
-}
-
 } // namespace hj

@@ -1141,27 +1141,4 @@ hipError_t launch_compact(hipStream_t st, const int32_t *k, const int32_t *p, co
     return hipSuccess;
 }
 
-
-// Every kernel instance of this file resolved for the current device NOW (hipFuncGetAttributes loads the code object and builds the
-// function like a first launch does).  hj_create calls the preload_* functions once per device under a lock: contexts are created by one
-// thread, joins are then enqueued by one host thread per rank (hj_dist) — without this their first launches of a kernel meet inside the
-// runtime's lazy initialisation (and, under rocprofv3, inside the profiler's registration of the kernel symbols: the GPU suite faulted
-// there in 3 of 26 profiled runs, profiles/r5_rocprof_suite_crash.txt).
-hipError_t preload_part_kernels() {
-    const void *fns[] = {
-        reinterpret_cast<const void *>(&k_part1_fast<2, 0, false>), reinterpret_cast<const void *>(&k_part1_fast<2, 1, true>),
-        reinterpret_cast<const void *>(&k_part1_fast<2, 1, false>), reinterpret_cast<const void *>(&k_part2_fast<2>),
-        reinterpret_cast<const void *>(&k_part1_fast2<2>), reinterpret_cast<const void *>(&k_part2_fast2<2>),
-        reinterpret_cast<const void *>(&k_part1_var<2, false>), reinterpret_cast<const void *>(&k_part1_var<2, true>),
-        reinterpret_cast<const void *>(&k_part2_var<2>), reinterpret_cast<const void *>(&k_scatter_wc<2, 0>), reinterpret_cast<const void *>(&k_scatter_wc<2, 1>),
-        reinterpret_cast<const void *>(&k_hist<0>), reinterpret_cast<const void *>(&k_hist<1>), reinterpret_cast<const void *>(&k_scan_local<uint32_t>),
-        reinterpret_cast<const void *>(&k_scan_top), reinterpret_cast<const void *>(&k_offsets), reinterpret_cast<const void *>(&k_plan),
-        reinterpret_cast<const void *>(&k_set_root), reinterpret_cast<const void *>(&k_sample_joint), reinterpret_cast<const void *>(&k_dist_segments),
-        reinterpret_cast<const void *>(&k_shard_count), reinterpret_cast<const void *>(&k_compact), reinterpret_cast<const void *>(&k_ubench<0, 2>),
-        reinterpret_cast<const void *>(&k_ubench<1, 2>), reinterpret_cast<const void *>(&k_ubench_oneway)};
-    hipFuncAttributes at;
-    for (const void *f : fns) { const hipError_t e = hipFuncGetAttributes(&at, f); if (e != hipSuccess) return e; }
-    return hipSuccess;
-}
-
 } // namespace hj

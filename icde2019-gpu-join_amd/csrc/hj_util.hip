@@ -265,21 +265,4 @@ hipError_t launch_verify_partitions(hipStream_t st, const int32_t *keys, const i
     return hipSuccess;
 }
 
-
-// Every kernel instance of this file resolved for the current device NOW (hipFuncGetAttributes loads the code object and builds the
-// function like a first launch does).  hj_create calls the preload_* functions once per device under a lock: contexts are created by one
-// thread, joins are then enqueued by one host thread per rank (hj_dist) — without this their first launches of a kernel meet inside the
-// runtime's lazy initialisation (and, under rocprofv3, inside the profiler's registration of the kernel symbols: the GPU suite faulted
-// there in 3 of 26 profiled runs, profiles/r5_rocprof_suite_crash.txt).
-hipError_t preload_util_kernels() {
-    const void *fns[] = {
-        reinterpret_cast<const void *>(&k_fill), reinterpret_cast<const void *>(&k_gen_unique), reinterpret_cast<const void *>(&k_gen_zipf),
-        reinterpret_cast<const void *>(&k_digest), reinterpret_cast<const void *>(&k_verify_partitions), reinterpret_cast<const void *>(&k_np_max),
-        reinterpret_cast<const void *>(&k_np_build_perfect), reinterpret_cast<const void *>(&k_np_probe_perfect),
-        reinterpret_cast<const void *>(&k_np_build_chains), reinterpret_cast<const void *>(&k_np_probe_chains)};
-    hipFuncAttributes at;
-    for (const void *f : fns) { const hipError_t e = hipFuncGetAttributes(&at, f); if (e != hipSuccess) return e; }
-    return hipSuccess;
-}
-
 } // namespace hj
