@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _native_backtrace_on_fault():
+    """HJ_TEST_SEGV_BT=<path of tools/segv_bt.c built as a shared library>: (re-)install its fault handler before every test — a native
+    backtrace of the faulting thread where pytest's faulthandler has Python frames only (tools/gpu_dist_soak.sh)."""
+    lib = os.environ.get("HJ_TEST_SEGV_BT")
+    if lib:
+        import ctypes
+        ctypes.CDLL(lib).segv_bt_install()
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
