@@ -21,7 +21,7 @@ done
 fi
 if [ $MODE != plain ]; then
 for i in $(seq 1 $N); do
-  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace$i -- python3 -m pytest $TESTS -m gpu -q -x -p no:cacheprovider -p no:faulthandler > $OUT/rocprof.$i.log 2>&1; rc=$?
+  timeout 1200 rocprofv3 --disable-signal-handlers true --kernel-trace --stats --output-format csv -d $OUT/trace$i -- python3 -m pytest $TESTS -m gpu -q -x -p no:cacheprovider -p no:faulthandler > $OUT/rocprof.$i.log 2>&1; rc=$?
   echo "rocprof $i rc=$rc $(grep -E 'passed|failed|error' $OUT/rocprof.$i.log | tail -1)"
   if [ $rc -ge 128 ]; then   # a fault: keep the log under its own name and, when the kernel left a core file, every thread's backtrace
     cp $OUT/rocprof.$i.log $OUT/crash.$(date +%H%M%S).log
