@@ -7,8 +7,13 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/coverage
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
-timeout 3000 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest.log 2>&1
-echo "pytest rc=$?"; tail -2 $OUT/pytest.log
+# (the profiled suite dies of a fault in about one run of six — never unprofiled: profiles/r5_rocprof_suite_crash.txt — so: up to three tries)
+for try in 1 2 3; do
+  rm -rf $OUT/trace
+  timeout 3000 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest.log 2>&1
+  rc=$?; echo "pytest rc=$rc (try $try)"; tail -2 $OUT/pytest.log
+  [ $rc -lt 128 ] && break
+done
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 out = sys.argv[1]
