@@ -9,6 +9,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 { echo "# tools/fuzz_medium.py 36 on one MI355X: differential runs against the oracle, 2^18-2^23-tuple relations, six key distributions,"
   echo "# default and exact_only, second join with the learned skew, one-probe materialisation digest, three joins with hj_config.graph"
   timeout 900 python tools/fuzz_medium.py 36 2>&1
-  timeout 600 python tools/fuzz_more.py 40 400 2>&1 | tail -1; } > $OUT/fuzz.txt
-tail -2 $OUT/fuzz.txt
+  timeout 600 python tools/fuzz_more.py 40 400 2>&1 | tail -1
+  echo "# tools/fuzz_dist.py 300: the multi-GPU join (in-process group on one GPU, world 2-8, count-only and materialising) against the oracle"
+  timeout 900 python tools/fuzz_dist.py 300 2>&1 | tail -3; } > $OUT/fuzz.txt
+tail -4 $OUT/fuzz.txt
 sha256sum icde2019-gpu-join_amd/libhj.so | tee $OUT/libhj.sha256
