@@ -21,6 +21,10 @@ for seed in range(first, first + n_cases):
     world = int(rng.choice([2, 3, 4, 5, 8]))
     kind = ["unique", "dups", "skew"][int(rng.integers(0, 3))]
     mat = bool(rng.integers(0, 2))
+    if os.environ.get("FUZZ_WORLD"):      # pin the world size / the kind of join (experiments)
+        world = int(os.environ["FUZZ_WORLD"])
+    if os.environ.get("FUZZ_MAT"):
+        mat = os.environ["FUZZ_MAT"] == "1"
     big = 150_000 if mat else 400_000
     nR = int(rng.integers(2_000, big))
     nS = int(rng.integers(2_000, big * 2))
@@ -34,6 +38,8 @@ for seed in range(first, first + n_cases):
     dist_cfg = dict(slices=int(rng.integers(1, 6)))
     if rng.random() < 0.3:
         dist_cfg["single_group"] = True
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case seed %d world %d kind %s mat %s nR %d nS %d cuts %s bits %s cfg %s" % (seed, world, kind, mat, nR, nS, cuts, bits, dist_cfg), flush=True)
     try:
         if mat:
             stats = T._run_materialize([0] * world, R, S, cuts=cuts, dist_cfg=dist_cfg, ctx_cfg=bits)

@@ -7,6 +7,9 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/coverage
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
+# Several host threads submitting to ONE hardware queue under the kernel trace's queue interception kill the process (the in-process
+# multi-rank tests; profiles/r5_rocprof_suite_crash.txt): give every stream a queue of its own while profiling.
+export GPU_MAX_HW_QUEUES=16
 # (the profiled suite dies of a fault in about one run of six — never unprofiled: profiles/r5_rocprof_suite_crash.txt — so: up to three tries)
 for try in 1 2 3; do
   rm -rf $OUT/trace
