@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Does rocprofv3's kernel trace survive a process that keeps creating short-lived host threads which launch kernels?  (hj_dist's
-in-process groups started one host thread per rank PER CALL; the GPU suite crashed under rocprofv3 — never without it — at its ~23rd
-test, some hundred such threads into the process.)  Usage (GPU box): rocprofv3 --kernel-trace --stats -d /tmp/x -- python3 tools/experiments/rocprof_thread_repro.py [threads]"""
+"""A hypothesis that did NOT hold (profiles/r5_rocprof_suite_crash.txt): does rocprofv3's kernel trace survive a process that keeps
+creating short-lived host threads which launch kernels?  It does — 6000 threads, no fault.  (What kills the profiled GPU suite is four or
+more host threads submitting to one hardware queue: tools/experiments/rocprof_dist_bisect.sh.)
+Usage (GPU box): rocprofv3 --kernel-trace --stats -d /tmp/x -- python3 tools/experiments/rocprof_thread_repro.py [threads]"""
 import sys, threading
 import torch
 
