@@ -59,15 +59,15 @@ def test_fails_loudly_without_gpu():
     assert r["status"] != 0 and r["matches"] == 0
 
 
-def _build_c_client(tmp_path):
+def _build_c_client(tmp_path, name="c_abi_client"):
     """gcc (not hipcc), C99, only include/*.h: the ABI is consumable from plain C."""
     import subprocess
     p = pkg()
     p._lib.build()
-    exe = str(tmp_path / "c_abi_client")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(p._lib.LIB_PATH)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c_abi_client.c"), "-o", exe, "-L", libdir, "-lhj",
+                           os.path.join(ROOT, "tests", name + ".c"), "-o", exe, "-L", libdir, "-lhj",
                            "-Wl,-rpath," + libdir])
     return exe
 
@@ -85,6 +85,23 @@ def test_c_client_on_gpu(tmp_path):
     r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_abi_client ok: 150000 matches" in r.stdout
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_c_dist_client_builds_and_fails_loudly_without_gpu(tmp_path):
+    """include/hj_dist.h from plain C (gcc -std=c99 -Werror): builds against the library; without a GPU the group cannot be made."""
+    import subprocess
+    r = subprocess.run([_build_c_client(tmp_path, "c_abi_dist_client")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_dist_client_on_gpu(tmp_path):
+    """The multi-GPU ABI driven from plain C: three ranks on cuda:0, count-only and materialising, every output tuple checked."""
+    import subprocess
+    r = subprocess.run([_build_c_client(tmp_path, "c_abi_dist_client")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_abi_dist_client ok: 180000 matches over 3 ranks (device-copy transport)" in r.stdout
 
 
 def test_host_write_combining_split_parity():
