@@ -1560,8 +1560,10 @@ int hj_fill_payload(hj_ctx *c, int32_t *d_pays, uint64_t n, int mode, uint64_t f
 
 int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p, uint64_t n,
               uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch) {
-    if (!c || kind < 0 || kind > 3 || !reps) return HJ_EINVAL;
+    if (!c || kind < 0 || kind > 7 || !reps) return HJ_EINVAL;
     if (n < 32 || !d_in_k || !d_in_p || !d_out_k || !d_out_p) return fail(c, HJ_EINVAL, "hj_ubench needs four columns of >= 32 tuples");
+    if (kind >= 4 && (d_in_p != d_in_k + n || d_out_p != d_out_k + n || (n & 31)))
+        return fail(c, HJ_EINVAL, "hj_ubench kinds 4-7 move ONE array per side: the payload column must follow the key column (p == k + n, n a multiple of 32)");
     if (((uintptr_t)d_in_k | (uintptr_t)d_in_p | (uintptr_t)d_out_k | (uintptr_t)d_out_p) & 15) return fail(c, HJ_EINVAL, "columns must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     hipEvent_t a = get_event(c), b = get_event(c);
@@ -1577,6 +1579,12 @@ int hj_ubench(hj_ctx *c, int kind, const int32_t *d_in_k, const int32_t *d_in_p,
     uint64_t lines = n / 32, pow2 = 1;
     while (pow2 * 2 <= lines) pow2 *= 2;
     if (avg_ms) *avg_ms = (double)ms / reps;
+    if (kind >= 4) { // line PAIRS (32 tuples, 256 bytes): the scattering kinds cover a power-of-two number of them
+        uint64_t p2 = 1;
+        while (p2 * 2 <= lines) p2 *= 2;
+        if (bytes_per_launch) *bytes_per_launch = ((kind == 6 || kind == 7) ? p2 : lines) * 32 * 16;
+        return HJ_OK;
+    }
     if (bytes_per_launch) *bytes_per_launch = (kind == 1 ? pow2 * 32 : (n / 4) * 4) * (kind >= 2 ? 8 : 16); // 8 B read + 8 B written per tuple (one-way kinds: one of them)
     return HJ_OK;
 }

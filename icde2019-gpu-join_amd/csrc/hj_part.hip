@@ -921,8 +921,64 @@ __global__ __launch_bounds__(256) void k_ubench_oneway(const int4 *__restrict__ 
     if (!write && acc == 0x9E3779B9u) ok[0] = make_int4(0, 0, 0, 0); // practically never: keeps the loads alive
 }
 
+// KIND 4-7 (round 6, the layout gate): the SAME bytes as kinds 0/1 moved as ONE array per side — the caller's two columns are the
+// halves of one allocation (ip == ik + n, op == ok + n).  Four 16-byte loads per lane in flight before the first store, like kinds 0/1.
+//   4  plain one-array copy (the guide's float4-copy shape): two streams instead of four
+//   5  line-interleaved pairs: a tuple line is 256 contiguous bytes, its 32 keys then its 32 payloads; 8 lanes move one line pair
+//      (loads at a and a + 128): what the INTERMEDIATE partitions would look like if phase C of wc_fast stored its two halves adjacently
+//   6  kind 5 with every 256-byte line pair stored at a pseudo-random line-pair position of the one output array (kind 1's scatter
+//      with 256-byte chunks into one array)
+//   7  two columns in (the API layout), line-interleaved pairs out, scattered as in 6: pass 1 with interleaved intermediates
+template <int KIND>
+__global__ __launch_bounds__(256) void k_ubench1(const int4 *__restrict__ in, int4 *__restrict__ out, uint64_t np16, uint64_t stride16,
+                                                 uint64_t pair_mask, uint64_t mul) {
+    // np16 = 16-byte units per column that are moved; stride16 = distance between the two input columns (kind 7)
+    if (KIND == 4) {
+        const uint64_t n16 = np16 * 2;
+        for (uint64_t base = (uint64_t)blockIdx.x * 1024; base < n16; base += (uint64_t)gridDim.x * 1024) {
+            int4 a[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x; if (u < n16) a[j] = in[u]; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x; if (u < n16) out[u] = a[j]; }
+        }
+        return;
+    }
+    for (uint64_t base = (uint64_t)blockIdx.x * 512; base < np16; base += (uint64_t)gridDim.x * 512) {
+        int4 a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u < np16) {
+                if (KIND == 7) { a[j] = in[u]; b[j] = in[stride16 + u]; }
+                else { const uint64_t p = (u >> 3) * 16 + (u & 7); a[j] = in[p]; b[j] = in[p + 8]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint64_t u = base + (uint64_t)j * 256 + threadIdx.x;
+            if (u < np16) {
+                const uint64_t pair = KIND == 5 ? (u >> 3) : (((u >> 3) * mul) & pair_mask);
+                const uint64_t p = pair * 16 + (u & 7);
+                out[p] = a[j]; out[p + 8] = b[j];
+            }
+        }
+    }
+}
+
 hipError_t launch_ubench(hipStream_t st, int kind, const int32_t *ik, const int32_t *ip, int32_t *ok, int32_t *op, uint64_t n) {
     const uint64_t n16 = n / 4;
+    if (kind >= 4) { // one array per side: the columns are the halves of one allocation (checked by hj_ubench)
+        uint64_t pairs = n16 / 8, p2 = 1;
+        while (p2 * 2 <= pairs) p2 *= 2;
+        const uint64_t np16 = (kind == 6 || kind == 7) ? p2 * 8 : pairs * 8; // the scatter covers a power-of-two number of line pairs
+        const uint64_t mul1 = 0x9E3779B97F4A7C15ULL | 1;
+        dim3 g1(16384), b1(256);
+#define UB1(K_) hipLaunchKernelGGL((k_ubench1<K_>), g1, b1, 0, st, (const int4 *)ik, (int4 *)ok, np16, n16, p2 - 1, mul1)
+        if (kind == 4) UB1(4); else if (kind == 5) UB1(5); else if (kind == 6) UB1(6); else UB1(7);
+#undef UB1
+        return hipGetLastError();
+    }
     uint64_t lines = n16 / 8, pow2 = 1;
     while (pow2 * 2 <= lines) pow2 *= 2;
     const uint64_t used16 = kind == 1 ? pow2 * 8 : n16; // the scatter covers the largest power-of-two number of lines

@@ -330,10 +330,11 @@ class HashJoin:
 
     def ubench(self, kind, in_k, in_p, out_k, out_p, n, reps=5):
         """HBM ceiling of a radix pass's access pattern with no partitioning work: kind 'copy' or 'line_scatter'; 'read' / 'write':
-        both columns streamed in only / out only (the two ends of a kernel's read:write mix).  Returns GB/s (bytes read + written
-        per second)."""
+        both columns streamed in only / out only (the two ends of a kernel's read:write mix); 'copy1' / 'pairs' / 'pairs_scatter' /
+        'soa_to_pairs_scatter' (round 6, the layout gate): the same bytes as ONE array per side — in_p must be in_k + n, out_p out_k + n.
+        Returns GB/s (bytes read + written per second)."""
         ms, nb = C.c_double(), C.c_uint64()
-        self._ck(self._L.hj_ubench(self._h, {"copy": 0, "line_scatter": 1, "read": 2, "write": 3}[kind], _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(out_k),
+        self._ck(self._L.hj_ubench(self._h, _UBENCH_KINDS[kind], _dev_ptr(in_k), _dev_ptr(in_p), _dev_ptr(out_k),
                                    _dev_ptr(out_p), n, reps, C.byref(ms), C.byref(nb)))
         return nb.value / (ms.value * 1e-3) / 1e9
 
@@ -346,6 +347,9 @@ class HashJoin:
         d = C.c_uint64()
         self._ck(self._L.hj_digest_triples(self._h, _dev_ptr(d_key), _dev_ptr(d_pr), _dev_ptr(d_ps), n, C.byref(d)))
         return d.value
+
+
+_UBENCH_KINDS = {"copy": 0, "line_scatter": 1, "read": 2, "write": 3, "copy1": 4, "pairs": 5, "pairs_scatter": 6, "soa_to_pairs_scatter": 7}
 
 
 def host_split(keys, pays, parts, threads=0):

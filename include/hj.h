@@ -264,6 +264,10 @@ int hj_verify_partitions(hj_ctx *ctx, int rel, uint64_t *misplaced, uint64_t *d_
  *      128-byte line stored at a pseudo-random aligned line position (the write pattern of the write-combining
  *      flush); kind 2 = both input columns streamed in only, kind 3 = both output columns streamed out only (what HBM gives
  *      pure reads / pure writes: a kernel reading R and writing W bytes is bounded by (R + W) / (R / read + W / write)).
+ *      Kinds 4-7 (the layout gate of round 6) move the same bytes as ONE array per side: d_in_p must be d_in_k + n and d_out_p
+ *      d_out_k + n, n a multiple of 32.  4 = plain one-array copy; 5 = line-interleaved pairs (a 256-byte line pair: 32 keys, then
+ *      their 32 payloads); 6 = kind 5 with every line pair stored at a pseudo-random line-pair position; 7 = two columns in,
+ *      scattered line pairs out.
  *      avg_ms per launch over reps launches (HIP events), bytes moved per launch (read + written). [sync] ---- */
 int hj_ubench(hj_ctx *ctx, int kind, const int32_t *d_in_k, const int32_t *d_in_p, int32_t *d_out_k, int32_t *d_out_p,
               uint64_t n, uint32_t reps, double *avg_ms, uint64_t *bytes_per_launch);

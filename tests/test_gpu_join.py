@@ -898,6 +898,38 @@ def test_hbm_ceiling_microbenchmarks_move_what_they_say(P):
         assert hj.ubench("write", a, b, c, d, n, reps=2) > 0 and not bool((c == -1).any())
 
 
+def test_layout_gate_microbenchmarks_move_what_they_say(P):
+    """hj_ubench kinds 4-7 (the layout gate of round 6): one array per side.  The one-array copy copies; the line-pair copy copies;
+    the two scattering kinds write every 256-byte line pair of their power-of-two prefix exactly once, keys in front of their payloads;
+    columns that are not the halves of one allocation are refused."""
+    import torch
+    n = (1 << 18) + 2048
+    dev = torch.device("cuda:0")
+    src = torch.arange(2 * n, dtype=torch.int32, device=dev)
+    dst = torch.full((2 * n,), -1, dtype=torch.int32, device=dev)
+    a, b, c, d = src[:n], src[n:], dst[:n], dst[n:]
+    with P.HashJoin(0) as hj:
+        for kind in ("copy1", "pairs"):
+            dst.fill_(-1)
+            assert hj.ubench(kind, a, b, c, d, n, reps=2) > 0
+            assert torch.equal(dst, src), kind
+        m = 1 << 18                                                  # line pairs covered: the largest power of two, 2^13 of 32 tuples
+        dst.fill_(-1)
+        assert hj.ubench("pairs_scatter", a, b, c, d, n, reps=2) > 0
+        pin, pout = src[:2 * m].view(-1, 64), dst[:2 * m].view(-1, 64)
+        assert torch.equal(pout[:, 1:] - pout[:, :1], pin[:, 1:] - pin[:, :1])                  # whole 256-byte pairs, order kept inside
+        assert torch.equal(torch.sort(pout[:, 0]).values, pin[:, 0])                                # every pair exactly once
+        assert bool((dst[2 * m:] == -1).all())
+        dst.fill_(-1)
+        assert hj.ubench("soa_to_pairs_scatter", a, b, c, d, n, reps=2) > 0                         # columns in, line pairs out
+        pout = dst[:2 * m].view(-1, 64)
+        assert torch.equal(pout[:, 32:], pout[:, :32] + n)                                          # a line's payloads behind its keys
+        assert torch.equal(torch.sort(pout[:, 0]).values, torch.arange(0, m, 32, dtype=torch.int32, device=dev))
+        assert torch.equal(pout[:, 1:32] - pout[:, :1], torch.arange(1, 32, dtype=torch.int32, device=dev).expand(m // 32, 31))
+        with pytest.raises(Exception):
+            hj.ubench("copy1", a, torch.empty_like(a), c, d, n, reps=1)
+
+
 def test_nonpartitioned_baselines(P, golden_dir):
     rng = np.random.default_rng(32)
     R = _load(golden_dir, "unique_4096.bin")
