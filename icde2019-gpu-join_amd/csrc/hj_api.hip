@@ -109,7 +109,7 @@ void resolve_completed(hj_ctx *c) {
 // RAII: HIP events on the context stream around one kernel launch
 bool Timed::is_main(const char *n) {
     return !strncmp(n, "k_hist", 6) || !strncmp(n, "k_scatter", 9) || !strncmp(n, "k_part", 6) || !strncmp(n, "k_join_count", 12) ||
-           !strncmp(n, "k_join_mat", 10) || !strncmp(n, "k_join_late", 11) || !strncmp(n, "k_np_", 5) || !strncmp(n, "k_split", 7);
+           !strncmp(n, "k_join_mat", 10) || !strncmp(n, "k_join_late", 11) || !strncmp(n, "k_np_", 5) || !strncmp(n, "k_split", 7) || !strncmp(n, "k_hot_build", 11);
 }
 // Each timed launch costs two event records on the stream; timing all ~35 launches of a step costs 4 %
 // at 2^30 x 2^30 and 27 % at 2^24 (measured), so by default only the kernels that move data are timed.
@@ -293,15 +293,86 @@ bool plan_fast(const hj_ctx *c, uint64_t n, uint32_t P1, uint32_t P2, FastPlan &
 // ranges (JoinArgs.rpart).  Once per binding: later partition calls reuse the tables, with no histogram and no host read.
 constexpr uint32_t SAMPLE_STRIDE = 8;
 
-int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2);
-int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
+// ---- the heavy-hitter bypass: candidates ----
+// Once per binding (first call of hj_join / hj_join_and_materialize that finds the relation skewed): up to 2^20 keys of the relation are
+// counted in a device hash table, the keys seen at least 8 times come back to the host, which puts them — most frequent first — into the
+// direct-mapped candidate table (a key whose slot is taken is left out: it takes the ordinary path).  k_hot_build then looks
+// at the other relation as it is now: only candidates it holds exactly once are joined by pass 1.  Returns 0 with sp.hot_ready set, or
+// 1: the bypass does not pay here (less than hot_min_share of the relation).
+int hot_prepare(hj_ctx *c, Rel &R, const Rel &O, Rel::Sampled &sp) {
     const double t0 = now_ms(), a0 = c->prof.alloc_ms;
-    const int rc = plan_sampled_impl(c, R, b1, b2);
+    sp.hot_ready = false; sp.hot_keys = 0; sp.hot_share = 0;
+    uint32_t nsamp = 1u << 20;
+    while ((uint64_t)nsamp * 4 > R.n && nsamp > 4096) nsamp >>= 1;
+    if (R.n < 16 * (uint64_t)(nsamp >> 4)) return 1;
+    const uint32_t slots = nsamp * 2, cap = nsamp / 8, thr = 8;
+    hipStream_t st = c->stream;
+    Buf tk, tc, outp;
+    std::vector<uint2> pairs;
+    uint32_t nout = 0;
+    int rc = 0;
+    do {
+        if ((rc = ensure(c, tk, (size_t)slots * 4)) || (rc = ensure(c, tc, (size_t)slots * 4 + 16)) || (rc = ensure(c, outp, (size_t)cap * 8))) break;
+        uint32_t *d_nout = (uint32_t *)tc.p + slots;
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)tk.p, (int)(uint32_t)HOT_NEVER, slots, st);
+        if (e == hipSuccess) e = hipMemsetAsync(tc.p, 0, (size_t)slots * 4 + 16, st);
+        if (e == hipSuccess) { Timed t(c, "k_hot_sample"); e = launch_hot_sample(st, R.in_k, R.n, nsamp, (uint32_t *)tk.p, (uint32_t *)tc.p, slots); }
+        if (e == hipSuccess) { Timed t(c, "k_hot_collect"); e = launch_hot_collect(st, (const uint32_t *)tk.p, (const uint32_t *)tc.p, slots, thr, (uint2 *)outp.p, d_nout, cap); }
+        if (e == hipSuccess) e = hipMemcpyAsync(&nout, d_nout, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess && nout) {
+            pairs.resize(std::min(nout, cap));
+            e = hipMemcpyAsync(pairs.data(), outp.p, pairs.size() * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (e != hipSuccess) rc = fail(c, HJ_EHIP, "hot-key sample: %s", hipGetErrorString(e));
+    } while (0);
+    release(tk); release(tc); release(outp);
+    if (rc) return rc;
+    std::sort(pairs.begin(), pairs.end(), [](const uint2 &a, const uint2 &b) { return a.y != b.y ? a.y > b.y : a.x < b.x; });
+    std::vector<uint32_t> cand(HOT_SLOTS), ccount(HOT_SLOTS, 0);
+    for (uint32_t i = 0; i < HOT_SLOTS; i++) cand[i] = hot_filler(i);
+    uint32_t nkeys = 0;
+    uint64_t covered = 0;
+    for (const uint2 &kc : pairs) {
+        if (nkeys == HOT_SLOTS) break;
+        const uint32_t sl = hot_slot(kc.x);
+        if (ccount[sl]) continue;
+        cand[sl] = kc.x; ccount[sl] = kc.y;
+        nkeys++; covered += kc.y;
+    }
+    int verdict = 1;
+    if (nkeys && (double)covered / nsamp >= c->hot_min_share) {
+        // what the other relation holds for them right now
+        RET(ensure(c, sp.hot_tab, (size_t)HOT_SLOTS * 4 * 3));
+        uint32_t *d_cand = (uint32_t *)sp.hot_tab.p, *d_cnt = d_cand + HOT_SLOTS;
+        int32_t *d_pay = (int32_t *)(d_cnt + HOT_SLOTS);
+        std::vector<uint32_t> cnt(HOT_SLOTS, 0);
+        HIPCHK(c, hipMemcpyAsync(d_cand, cand.data(), HOT_SLOTS * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, (size_t)HOT_SLOTS * 4 * 2, st));
+        { Timed t(c, "k_hot_build"); HIPCHK(c, launch_hot_build(st, O.in_k, O.in_p, O.n, d_cand, d_cnt, d_pay, nullptr)); }
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, HOT_SLOTS * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st)); // (cand, cnt: pageable host vectors)
+        uint64_t taken = 0;
+        uint32_t unique = 0;
+        for (uint32_t i = 0; i < HOT_SLOTS; i++) if (ccount[i] && cnt[i] == 1) { taken += ccount[i]; unique++; }
+        sp.hot_keys = unique; sp.hot_share = (double)taken / nsamp;
+        if (sp.hot_share >= c->hot_min_share) { sp.hot_ready = true; verdict = 0; }
+        if (c->debug) fprintf(stderr, "[hj] hot keys: %u candidates (%.3f of the sample), %u unique in the other relation (%.3f): %s\n", nkeys, (double)covered / nsamp, unique, sp.hot_share, verdict ? "no bypass" : "bypass");
+    }
+    c->prof.plan_ms += (now_ms() - t0) - (c->prof.alloc_ms - a0);
+    return verdict;
+}
+
+// rc 0: planned; 1: not plannable (positions); 2: planned for the bypass, but the rest of the relation still has a dominant digit
+int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled &sp);
+int plan_sampled(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled &sp) {
+    const double t0 = now_ms(), a0 = c->prof.alloc_ms;
+    const int rc = plan_sampled_impl(c, R, b1, b2, sp);
     c->prof.plan_ms += (now_ms() - t0) - (c->prof.alloc_ms - a0); // sampling kernel + read-back + host planning + table upload
     return rc;
 }
-int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
-    Rel::Sampled &sp = R.sp;
+int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled &sp) {
     const uint32_t P1 = 1u << b1, P2 = 1u << b2, NP = P1 * P2;
     hipStream_t st = c->stream;
     // sample: device histogram -> host
@@ -312,7 +383,8 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     int rc = 0;
     do {
         hipError_t e = hipMemsetAsync(hist.p, 0, (size_t)NP * 4 + 8, st);
-        if (e == hipSuccess) { Timed t(c, "k_sample_joint"); e = launch_sample_joint(st, R.in_k, R.n, b1 + b2, SAMPLE_STRIDE, (uint32_t *)hist.p, (uint64_t *)((uint32_t *)hist.p + NP)); }
+        const uint32_t *hc = sp.hot_ready ? (const uint32_t *)sp.hot_tab.p : nullptr; // the bypass takes these keys' tuples out in pass 1: they enter no bin
+        if (e == hipSuccess) { Timed t(c, "k_sample_joint"); e = launch_sample_joint(st, R.in_k, R.n, b1 + b2, SAMPLE_STRIDE, (uint32_t *)hist.p, (uint64_t *)((uint32_t *)hist.p + NP), hc, hc ? hc + HOT_SLOTS : nullptr); }
         if (e == hipSuccess) e = hipMemcpyAsync(h.data(), hist.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(&ns, (uint32_t *)hist.p + NP, 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -367,8 +439,6 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
     };
     // pass 1
     // spans like the exact passes' (four per CU): the pieces are uneven under skew, many of them balance better than few
-    if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
-    if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
     const uint32_t target = c->target_spans ? c->target_spans : TARGET_SPANS;
     uint64_t span = (R.n + target - 1) / target;
     span = ((span + TILE - 1) / TILE) * TILE;
@@ -390,6 +460,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
         maxfd = std::max(maxfd, fd[d]);
         if (posA >= ((uint64_t)1 << 32) - ((uint64_t)1 << 20)) return 1; // does not fit 32-bit positions: not plannable
     }
+    if (sp.hot_ready && maxfd > 0.25) return 2; // (the bypass kernels have no wave-aggregated ranking: the plain sampled path takes such a relation)
     // pass 2
     std::vector<uint32_t> cbase2(NP), cap2(NP), lt2(NP), own2((size_t)P1 * 512, 0xFFFFu), heavy2(P1, 0), wg, rpart, pr0(NP), pnr(NP);
     uint64_t posB = 0;
@@ -444,7 +515,7 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
             W += cap;
         }
         for (uint32_t i = 0; i < 512; i++) own2[(size_t)d * 512 + i] = own[i];
-        if (getenv("HJ_DEBUG") && J > 1) {
+        if (c->debug && J > 1) {
             uint32_t qm = 0;
             for (uint32_t q = 0; q < P2; q++) if (sh[q] > sh[qm]) qm = q;
             fprintf(stderr, "[hj] parent %u Ed %.0f J %u maxshare %.4f first wg %zu heavy %u child %u share %.4f cap %u lines %u W %llu\n", d, Ed, J, maxshare, wg.size() / 4, heavy2[d], qm, sh[qm], cap2[d * P2 + qm], lines[qm], (unsigned long long)W);
@@ -479,13 +550,26 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2) {
 int ensure_part(hj_ctx *c, Buf &b, size_t bytes);
 
 // the two launches; *done = false when the relation cannot take this path (the caller goes on to the exact passes)
-int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag, bool *done) {
+int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag, bool *done, bool want_hot) {
     Rel &R = c->rel[r];
-    Rel::Sampled &sp = R.sp;
+    const Rel &O = c->rel[1 - r];
     *done = false;
-    if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2 || getenv("HJ_REPLAN")) {
+    // the heavy-hitter bypass: wanted by the running entry point, this is the probe side, and the look at the keys said it pays
+    if (want_hot && !R.sph.hot_ready) {
+        const int hr = hot_prepare(c, R, O, R.sph);
+        if (hr < 0) return hr;
+        if (hr > 0) { R.hot_useless = true; want_hot = false; }
+    }
+    if (want_hot && (!R.sph.valid || R.sph.n != R.n || R.sph.b1 != b1 || R.sph.b2 != b2)) {
+        R.sph.valid = false;
+        const int rc = plan_sampled(c, R, b1, b2, R.sph);
+        if (rc < 0) return rc;
+        if (rc > 0 || !R.sph.valid) { R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = true; want_hot = false; } // the plain plan below
+    }
+    Rel::Sampled &sp = want_hot ? R.sph : R.sp;
+    if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2 || c->replan) {
         sp.valid = false;
-        const int rc = plan_sampled(c, R, b1, b2);
+        const int rc = plan_sampled(c, R, b1, b2, sp);
         if (rc < 0) return rc;
         if (rc > 0 || !sp.valid) { R.sampled_failed = true; return 0; }
     }
@@ -502,6 +586,20 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     fa.obeg = (uint64_t *)R.s1beg.p; fa.oend = (uint64_t *)R.s1end.p; fa.ovf = flag;
     VarArgs va{};
     va.vbase = sp.vbase1; va.vcap = sp.vcap1; va.lt = sp.lt1; va.own = sp.own1; va.heavy = sp.heavy1_d; va.wg = nullptr;
+    if (want_hot) { // what the other relation holds for the candidates NOW (4 bytes per tuple of it), then pass 1 joins their tuples itself
+        uint64_t *sc = (uint64_t *)c->scalars.p;
+        uint32_t *d_cand = (uint32_t *)sp.hot_tab.p, *d_cnt = d_cand + HOT_SLOTS;
+        int32_t *d_pay = (int32_t *)(d_cnt + HOT_SLOTS);
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, (size_t)HOT_SLOTS * 4, st));
+        { Timed t(c, "k_hot_build"); HIPCHK(c, launch_hot_build(st, O.in_k, O.in_p, O.n, d_cand, d_cnt, d_pay, reinterpret_cast<unsigned long long *>(sc + 13))); }
+        va.hot.mode = (uint32_t)c->hot_request; va.hot.cand = d_cand; va.hot.cnt = d_cnt; va.hot.pay = d_pay;
+        va.hot.acc = reinterpret_cast<unsigned long long *>(sc + 13);
+        va.hot.out_key = c->hot_out[0];
+        va.hot.out_tab = r == HJ_REL_S ? c->hot_out[1] : c->hot_out[2]; // the other relation's payload column
+        va.hot.out_str = r == HJ_REL_S ? c->hot_out[2] : c->hot_out[1];
+        va.hot.out_cap = c->hot_cap;
+        va.hot.cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    }
     { Timed t(c, "k_part1_var"); HIPCHK(c, launch_part1_var(st, fa, va, sp.heavy1)); }
     FastArgs fb{};
     fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
@@ -521,6 +619,7 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
     R.pb1 = b1; R.pb2 = b2;
     R.partitioned = true; R.fast_tried = true; R.sampled = true;
     R.flag_unread = true;
+    R.hot_mode = want_hot ? c->hot_request : 0;
     c->join_planned = false;
     *done = true;
     return 0;
@@ -543,7 +642,6 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     // checked here before anything is (re)allocated — pass-1 and final buffers of both columns, ~1.14 x 16 bytes per tuple on top
     // of the input (the reference's CLI accepts up to ULONG_MAX/4 tuples, main.cu:491-514).
     if (R.n > ((uint64_t)1 << 34)) return fail(c, HJ_EINVAL, "relation too large (n <= 2^34 tuples: pass-2 parents are addressed in 32-bit units)");
-    if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // (experiment knobs are read per call: same-context A/B)
     if (c->force_sampled & (1 << r)) R.prefer_exact = true; // experiment knob: this relation takes the sampled path whatever its distribution
     else if (c->force_sampled & (4 << r)) { R.prefer_exact = false; R.sampled_failed = false; } // bits 2, 3: forget what was learned (back to the plain passes)
     choose_bits(c);
@@ -568,11 +666,18 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     uint32_t *const flag = reinterpret_cast<uint32_t *>((uint64_t *)c->scalars.p + 8 + r); // travels with the result block
     // root offsets for the exact passes + the flag reset — not needed in front of histogram-free passes whose flag is known to be 0
     // (steady-state steps of hj_join: two launches fewer per step)
-    if (!(assume_clean && histogram_free && !R.flag_unread && !R.flag_maybe_set)) {
+    // histogram_free is a PREDICTION of the path taken below (the sampled path can still decline): every branch that reads R.root asks
+    // for it again, so a skipped launch is made up for in front of the exact passes
+    bool root_done = false;
+    auto set_root = [&]() -> int {
+        if (root_done) return 0;
         Timed t(c, "k_set_root");
         HIPCHK(c, launch_set_root(st, (uint64_t *)R.root.p, R.n, flag));
         R.flag_unread = false; R.flag_maybe_set = false; // reset in stream order
-    }
+        root_done = true;
+        return 0;
+    };
+    if (!(assume_clean && histogram_free && !R.flag_unread && !R.flag_maybe_set)) RET(set_root());
     uint32_t b1 = c->bits1, b2 = c->bits2;
     // A relation known to be skewed (its histogram-free attempt overflowed) is split as evenly as possible between
     // the two exact passes: fewer than 512 digits per pass leave LDS lines to deal to the heavy digits (k_scatter_wc).
@@ -583,6 +688,7 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     R.part_off = nullptr;
     R.n_bound = 0;
     R.sampled = false; R.rpart = nullptr; R.pr0 = R.pnr = nullptr;
+    R.hot_mode = 0;
     // known to be skewed: the sampled path — on either side of the join since round 4 (a build partition that is a list of ranges
     // is built into the LDS table piece by piece: general items, plan_join).  Up to 17 radix bits: at 16 (2^28 x 2^31 Zipf) it takes
     // 18.9 ms where the exact passes take 24.6, at 17 bits 23.6 against 26.9; at 18 bits both passes are 512-way, a heavy digit has
@@ -590,11 +696,17 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     // r4_sampled_16_17_bits.txt)
     if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 17 && c->fast_path && !c->cfg.exact_only &&
         R.n >= ((uint64_t)1 << 20)) {
+        // the heavy-hitter bypass: asked for by the running entry point (hj_join: count; hj_join_and_materialize: write), for the PROBE side
+        // of the join, whose other side is there to be looked at
+        const Rel &O = c->rel[1 - r];
+        const bool want_hot = c->hot_request && c->hot_enable && r == 1 - c->build && !R.hot_useless && O.bound && O.n && !c->rel[c->build].sampled &&
+                              !c->rel[c->build].prefer_exact;
         bool done = false;
-        RET(partition_sampled(c, r, b1, b2, flag, &done));
+        RET(partition_sampled(c, r, b1, b2, flag, &done, want_hot));
         if (done) return 0;
     }
     if (b1 == 0) { // nothing to partition: one partition = the input itself
+        RET(set_root());
         R.part_k = R.in_k; R.part_p = R.in_p; R.nparts = 1; R.nranges = 1; R.n_alloc = R.n;
         R.part_off = (const uint64_t *)R.root.p;
         R.part_beg = R.part_off; R.part_end = R.part_off + 1;
@@ -615,6 +727,7 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     uint64_t *beg = (uint64_t *)R.beg.p, *end = (uint64_t *)R.end.p;
     if (b2 == 0) {
         RET(ensure(c, R.off2, (size_t)(P1 + 1) * 8));
+        RET(set_root());
         RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, 0, P1, P1 - 1, (int32_t *)R.b_k.p,
                      (int32_t *)R.b_p.p, (uint64_t *)R.off2.p, beg, end));
     } else {
@@ -648,6 +761,7 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
         } else {
             RET(ensure(c, R.off1, (size_t)(P1 + 1) * 8));
             RET(ensure(c, R.off2, ((size_t)P1 * P2 + 1) * 8));
+            RET(set_root());
             // pass 1 on key bits [b2, b2+b1), pass 2 on bits [0, b2): final partition id = low b1+b2 key
             // bits, pass-1 digit major — the order of jp.cu:402 ((pid << log_parts2) + j)
             RET(run_pass(c, r, 0, R.in_k, R.in_p, R.n, (const uint64_t *)R.root.p, 1, b2, P1, P1 - 1, (int32_t *)R.a_k.p,
@@ -692,6 +806,7 @@ int resolve_layout(hj_ctx *c, Rel &R) {
 // introspection wants one gap-free range per partition: a sampled layout is redone with the exact passes
 int exact_for_introspection(hj_ctx *c, Rel &R) {
     drop_graph(c); // resolve_layout / the exact redo rewrite the relation's layout state under a captured step
+    RET(whole_partitions(c, 0));
     RET(resolve_layout(c, R));
     if (!R.sampled) return 0;
     R.force_exact = true;
@@ -766,7 +881,6 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
     uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
-    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0; // experiment knobs are read per call: same-context A/B (tools/experiments/launch_ab.py)
     const bool atomic_plan = c->plan_atomic;
     if (nparts <= 1024 && !Pb.sampled && !general) { // one workgroup's worth of partitions: plan + scan + expand in one single-workgroup launch
         Timed t(c, "k_join_plan");
@@ -809,13 +923,16 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
     // n_items is a uint64 on the device; the reductions take its low word as their length (little endian)
     const uint32_t *len = reinterpret_cast<const uint32_t *>(sc + 0);
     // matches and aggregate in one launch into sc[1], sc[2] (zeroed by k_join_plan)
-    { Timed t(c, "k_sum2"); HIPCHK(c, launch_sum2(st, a.wave_counts, a.wave_agg, len, JOIN_WAVES, sc + 1)); }
+    // ... plus what pass 1 of the probe side counted itself (the heavy-hitter bypass)
+    const Rel &Pb = c->rel[1 - c->build];
+    { Timed t(c, "k_sum2"); HIPCHK(c, launch_sum2(st, a.wave_counts, a.wave_agg, len, JOIN_WAVES, sc + 1, (!late && Pb.hot_mode == 1) ? sc + 13 : nullptr)); }
     return 0;
 }
 
 int fetch_scalars(hj_ctx *c) {
-    // one 88-byte copy: the results, the overflow flags of the two relations' histogram-free passes, the output cursor
-    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 11 * 8, hipMemcpyDeviceToHost, c->stream));
+    // one 120-byte copy: the results, the overflow flags of the two relations' histogram-free passes, the output cursor, what the
+    // heavy-hitter bypass counted
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 15 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->redo_mask = 0;
     for (int r = 0; r < 2; r++) {
@@ -823,8 +940,11 @@ int fetch_scalars(hj_ctx *c) {
         if (!R.fast_tried || R.flag_known_good) continue;
         R.flag_unread = false; R.flag_maybe_set = (uint32_t)c->h_scalars[8 + r] != 0;
         if ((uint32_t)c->h_scalars[8 + r]) { // slots overflowed: ranges invalid
-            if (getenv("HJ_DEBUG")) fprintf(stderr, "[hj] rel %d overflow flag 0x%x (sampled %d) nwg2 %u nspans %u\n", r, (uint32_t)c->h_scalars[8 + r], (int)R.sampled, R.sp.nwg2, R.sp.nspans);
-            if (R.sampled) R.sampled_failed = true; // even the sampled capacities: the exact passes are what is left
+            if (c->debug) fprintf(stderr, "[hj] rel %d overflow flag 0x%x (sampled %d) nwg2 %u nspans %u\n", r, (uint32_t)c->h_scalars[8 + r], (int)R.sampled, R.sp.nwg2, R.sp.nspans);
+            // even the sampled capacities: the exact passes are what is left — unless the plan was the bypass's (the other relation may
+            // have stopped holding a candidate exactly once: its tuples came back into slots sized without them): the plain sampled path then
+            if (R.sampled && R.hot_mode) { R.hot_useless = true; R.sph.valid = false; R.sph.hot_ready = false; }
+            else if (R.sampled) R.sampled_failed = true;
             R.prefer_exact = true; c->redo_mask |= 1u << r;
         }
         else R.flag_known_good = true;
@@ -840,8 +960,8 @@ int count_and_fetch(hj_ctx *c, JoinArgs &a, bool &tag16, const JoinArgs *late = 
     RET(fetch_scalars(c));
     if (c->redo_mask && c->prof.t0 > 0 && c->prof.attempt_ms == 0) // the optimistic attempt of this call came back flagged: what it cost
         c->prof.attempt_ms = (now_ms() - c->prof.t0) - c->prof.alloc_ms;
-    for (int attempt = 0; c->redo_mask; attempt++) { // histogram-free -> sampled capacities -> exact passes: at most two redos
-        if (attempt == 2) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+    for (int attempt = 0; c->redo_mask; attempt++) { // histogram-free -> (sampled capacities with the heavy-hitter bypass ->) sampled capacities -> exact passes: at most three redos
+        if (attempt == 3) return fail(c, HJ_EHIP, "exact passes reported an overflow");
         const uint32_t m = c->redo_mask;
         for (int r = 0; r < 2; r++)
             if (m & (1u << r)) RET(partition_rel(c, r));
@@ -873,6 +993,7 @@ int hj_join_count_enqueue(hj_ctx *c) {
 int hj_join_materialize_enqueue(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, bool keep_cursor) {
     JoinArgs a;
     bool tag16;
+    RET(whole_partitions(c, c->hot_request == 2 ? 2 : 0)); // (hj_join_and_materialize: pass 1 wrote the hot tuples to these very columns)
     RET(plan_join(c, a, tag16, true, keep_cursor));
     a.out_key = d_key;
     a.out_bpay = c->build == HJ_REL_R ? d_payR : d_payS;
@@ -882,6 +1003,24 @@ int hj_join_materialize_enqueue(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int3
     if (lds > 160 * 1024) return fail(c, HJ_EINVAL, "LDS hash table of %zu bytes exceeds 160 KiB", lds);
     { Timed t(c, "k_join_materialize"); HIPCHK(c, launch_join_mat_reg(c->stream, a, c->max_items, tag16)); }
     c->join_planned = false;
+    return 0;
+}
+
+// Partitions made under the heavy-hitter bypass lack the tuples pass 1 joined itself.  An entry point that needs them all (a
+// materialising probe after hj_join, introspection, ...) gets the relation partitioned again without the bypass (hot_request is 0
+// outside hj_join / hj_join_and_materialize).  ok_mode: a bypass mode the caller can work with (1: the counts are in scalars[13], [14]).
+int whole_partitions(hj_ctx *c, int ok_mode) {
+    for (int r = 0; r < 2; r++) {
+        Rel &R = c->rel[r];
+        if (R.partitioned && R.hot_mode && R.hot_mode != ok_mode) {
+            drop_graph(c);
+            const int saved = c->hot_request;
+            c->hot_request = 0;
+            const int rc = partition_rel(c, r);
+            c->hot_request = saved;
+            RET(rc);
+        }
+    }
     return 0;
 }
 
@@ -903,7 +1042,22 @@ void hj_invalidate_all(hj_ctx *c) {
 // ================================================================================================
 extern "C" {
 
-const char *hj_version(void) { return "hj-mi355x 0.4 (gfx950)"; }
+const char *hj_version(void) { return "hj-mi355x 0.5 (gfx950)"; }
+
+// every experiment / test knob the single-GPU path reads (DESIGN.md §9 lists them): once per context
+static void read_knobs(hj_ctx *c) {
+    if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
+    if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
+    if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
+    if (const char *ml = getenv("HJ_MERGE_LOG2")) c->merge_log2 = (uint32_t)std::max(0, std::min(40, atoi(ml)));
+    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0;
+    if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
+    if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // bit 0: R, bit 1: S; bits 2, 3: forget what was learned
+    c->replan = getenv("HJ_REPLAN") != nullptr;
+    if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
+    if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
+    c->debug = getenv("HJ_DEBUG") != nullptr;
+}
 
 int hj_create(hj_ctx **out, int device) {
     if (!out) return HJ_EINVAL;
@@ -923,15 +1077,18 @@ int hj_create(hj_ctx **out, int device) {
     if (hipHostMalloc((void **)&c->h_scalars, 128, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
     memset(c->h_scalars, 0, 128);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
-    if (const char *fp = getenv("HJ_FAST_PATH")) c->fast_path = atoi(fp); // 0: exact (histogram) passes only
-    if (const char *ts = getenv("HJ_TARGET_SPANS")) c->target_spans = (uint32_t)atoi(ts);
-    if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
-    if (const char *ml = getenv("HJ_MERGE_LOG2")) c->merge_log2 = (uint32_t)std::max(0, std::min(40, atoi(ml)));
-    if (const char *pa = getenv("HJ_PLAN_ATOMIC")) c->plan_atomic = atoi(pa) != 0;
-    if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
-    if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // bit 0: R, bit 1: S
+    read_knobs(c);
     (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
     *out = c;
+    return HJ_OK;
+}
+
+/* experiments only (tools/experiments/: same-context A/Bs switch a knob between two calls): read the environment knobs again.  The
+ * library itself reads them ONCE, in hj_create — a variable set later by the host application changes nothing, and no entry point of the
+ * path calls getenv. */
+int hj_reload_knobs(hj_ctx *c) {
+    if (!c) return HJ_EINVAL;
+    read_knobs(c);
     return HJ_OK;
 }
 
@@ -949,6 +1106,7 @@ int hj_destroy(hj_ctx *c) {
         release(R.beg); release(R.end); release(R.s1beg); release(R.s1end);
         release(R.comp_k); release(R.comp_p); release(R.comp_off);
         release(R.sp.tab); release(R.sp.rbeg); release(R.sp.rend);
+        release(R.sph.tab); release(R.sph.rbeg); release(R.sph.rend); release(R.sph.hot_tab);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); if (c->seg_joined[i]) (void)hipEventDestroy(c->seg_joined[i]); }
@@ -1039,7 +1197,8 @@ int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, u
     R.n = n;
     R.bound = true;
     R.prefer_exact = false; // new data: the histogram-free passes get their chance again
-    R.sampled_failed = false; R.sp.valid = false;
+    R.sampled_failed = false; R.sp.valid = false; R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = false;
+    { Rel &O = c->rel[1 - rel]; O.sph.valid = false; O.sph.hot_ready = false; O.hot_useless = false; } // its bypass plan looked at THIS relation's keys
     invalidate(c, rel);
     return HJ_OK;
 }
@@ -1050,7 +1209,11 @@ int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_p
     if (((uintptr_t)d_keys | (uintptr_t)d_pays) & 15) return fail(c, HJ_EINVAL, "device columns must be 16-byte aligned");
     Rel &R = c->rel[rel];
     // re-binding the same columns keeps what the last run learned about them (skewed keys: exact passes at once)
-    if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) { R.prefer_exact = false; R.sampled_failed = false; R.sp.valid = false; }
+    if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) {
+        R.prefer_exact = false; R.sampled_failed = false; R.sp.valid = false; R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = false;
+        Rel &O = c->rel[1 - rel]; // its bypass plan looked at THIS relation's keys
+        O.sph.valid = false; O.sph.hot_ready = false; O.hot_useless = false;
+    }
     R.in_k = d_keys; R.in_p = d_pays; R.n = n; R.bound = true;
     invalidate(c, rel);
     return HJ_OK;
@@ -1066,6 +1229,7 @@ int hj_partition(hj_ctx *c, int rel) {
 int hj_join_count(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     if (!c) return HJ_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    RET(whole_partitions(c, 1)); // (partitions whose hot tuples were COUNTED by pass 1 are fine: their count is added in)
     JoinArgs a;
     bool tag16;
     RET(count_and_fetch(c, a, tag16));
@@ -1083,7 +1247,8 @@ namespace hjx {
 
 // ONE probe: plan the work items, k_join_mat_reg finds, reserves and writes; the cursor comes back with the result block
 int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
-    for (int attempt = 0; attempt < 3; attempt++) {
+    RET(whole_partitions(c, 0));
+    for (int attempt = 0; attempt < 4; attempt++) {
         JoinArgs a;
         bool tag16;
         if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
@@ -1102,7 +1267,7 @@ int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_pay
         c->join_planned = false;
         RET(fetch_scalars(c)); // [sync]
         if (!c->redo_mask) break;
-        if (attempt == 2) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+        if (attempt == 3) return fail(c, HJ_EHIP, "exact passes reported an overflow");
         const uint32_t m = c->redo_mask; // slots overflowed (skew): the kernel did nothing; sampled capacities / exact passes, then again
         for (int r = 0; r < 2; r++)
             if (m & (1u << r)) RET(partition_rel(c, r));
@@ -1142,8 +1307,6 @@ namespace {
 // |R|+|S| (log2) that forks.  Not with kernel events on (the instrumented steps time serial kernels).  Works the same under
 // stream capture (fork / join by events).
 int partition_both(hj_ctx *c) {
-    if (const char *ml = getenv("HJ_MERGE_LOG2")) c->merge_log2 = (uint32_t)std::max(0, std::min(40, atoi(ml)));
-    if (const char *fl = getenv("HJ_FORK_LOG2")) c->fork_log2 = (uint32_t)std::max(0, std::min(40, atoi(fl)));
     const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->fork_log2) && c->events == 0;
     // Small and medium inputs: ONE launch per pass for both relations (k_part1_fast2 / k_part2_fast2), one stream, no event fork and
     // join, no k_set_root in front of a relation whose flag is known to be 0, the join's item counter zeroed by pass 2: a steady-state
@@ -1152,7 +1315,15 @@ int partition_both(hj_ctx *c) {
     if (c->merge_log2 && c->events == 0 && c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->merge_log2) && c->rel[0].n && c->rel[1].n &&
         std::max(c->rel[0].n, c->rel[1].n) < 4 * std::min(c->rel[0].n, c->rel[1].n)) {
         FastPair pr[2];
-        for (int r = 0; r < 2; r++) RET(partition_rel(c, r, &pr[r], true));
+        for (int r = 0; r < 2; r++) {
+            const int rc = partition_rel(c, r, &pr[r], true);
+            if (rc) { // a relation prepared earlier in this loop was marked partitioned, but its launches were deferred and never made
+                invalidate(c);
+                for (int q = 0; q < 2; q++) { c->rel[q].fast_tried = false; c->rel[q].flag_known_good = false; c->rel[q].flag_unread = true; }
+                c->items_zeroed = false;
+                return rc;
+            }
+        }
         if (pr[0].used && pr[1].used) {
             pr[0].fb.zero_items = (uint64_t *)c->scalars.p + 0;
             { Timed t(c, "k_part1_fast2"); HIPCHK(c, launch_part1_fast2(c->stream, pr[0].fa, pr[1].fa)); }
@@ -1227,7 +1398,7 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
         JoinArgs a;
         bool tag16 = false;
         if (!rc) rc = run_count(c, a, tag16);
-        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(c->h_scalars, c->scalars.p, 11 * 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(c->h_scalars, c->scalars.p, 15 * 8, hipMemcpyDeviceToHost, c->stream);
         const hipError_t e2 = hipStreamEndCapture(c->stream, &gr);
         if (rc || e != hipSuccess || e2 != hipSuccess || !gr) { // not capturable: the eager path answers this call (and reports its own errors)
             if (gr) (void)hipGraphDestroy(gr);
@@ -1250,7 +1421,8 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
         if (!R.fast_tried) continue;
         R.flag_unread = false; R.flag_maybe_set = (uint32_t)c->h_scalars[8 + r] != 0;
         if ((uint32_t)c->h_scalars[8 + r]) { // the data under the binding changed: skewed now
-            if (R.sampled) R.sampled_failed = true;
+            if (R.sampled && R.hot_mode) { R.hot_useless = true; R.sph.valid = false; R.sph.hot_ready = false; }
+            else if (R.sampled) R.sampled_failed = true;
             R.prefer_exact = true; c->redo_mask |= 1u << r;
         }
         else R.flag_known_good = true;
@@ -1275,20 +1447,75 @@ int hj_partition_both(hj_ctx *c) {
     return partition_both(c);
 }
 
-int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
-    if (!c) return HJ_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+static int join_impl(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
     bool done = false;
-    c->prof = hj_ctx::CallProf{};
-    c->prof.t0 = now_ms();
     RET(join_graph(c, matches, agg, &done));
     if (!done) {
         RET(partition_both(c));
         RET(hj_join_count(c, matches, agg));
         if (c->cfg.graph) { set_key(c); c->graph_warm = true; } // the next call on this binding may capture
     }
+    return HJ_OK;
+}
+
+int hj_join(hj_ctx *c, uint64_t *matches, uint64_t *agg) {
+    if (!c) return HJ_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof = hj_ctx::CallProf{};
+    c->prof.t0 = now_ms();
+    c->hot_request = 1; // a skewed probe side: pass 1 counts the matches of its heavy hitters itself (the result is all this call hands out)
+    const int rc = join_impl(c, matches, agg);
+    c->hot_request = 0;
     c->prof.total_ms = now_ms() - c->prof.t0;
     c->prof.t0 = 0;
+    return rc;
+}
+
+static int join_and_materialize_impl(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+    uint64_t *sc = (uint64_t *)c->scalars.p;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        // the output cursor starts at 0 BEFORE the passes: pass 1 of a skewed probe side appends the tuples of its heavy hitters, the probe
+        // appends the rest behind them (plan_join leaves the cursor alone)
+        HIPCHK(c, hipMemsetAsync(sc + 10, 0, 8, c->stream));
+        RET(partition_both(c));
+        RET(hj_join_materialize_enqueue(c, d_key, d_payR, d_payS, cap, true));
+        RET(fetch_scalars(c)); // [sync]
+        if (!c->redo_mask) break;
+        if (attempt == 3) return fail(c, HJ_EHIP, "exact passes reported an overflow");
+        // slots overflowed (skew): nothing of this attempt counts; the flagged relation takes its next path (sampled capacities, exact
+        // passes), and BOTH are partitioned again — the tuples pass 1 wrote belong to a cursor that restarts
+    }
+    if (n_out) *n_out = c->h_scalars[10];
+    return 0;
+}
+
+int hj_join_and_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out) {
+    if (!c) return HJ_EINVAL;
+    if (cap && (!d_key || !d_payR || !d_payS)) return fail(c, HJ_EINVAL, "output columns == NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_graph(c);
+    c->prof = hj_ctx::CallProf{};
+    c->prof.t0 = now_ms();
+    c->hot_request = 2; c->hot_out[0] = d_key; c->hot_out[1] = d_payR; c->hot_out[2] = d_payS; c->hot_cap = cap;
+    uint64_t n = 0;
+    const int rc = join_and_materialize_impl(c, d_key, d_payR, d_payS, cap, &n);
+    c->hot_request = 0; c->hot_out[0] = c->hot_out[1] = c->hot_out[2] = nullptr; c->hot_cap = 0;
+    c->prof.total_ms = now_ms() - c->prof.t0;
+    c->prof.t0 = 0;
+    RET(rc);
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu", (unsigned long long)n, (unsigned long long)cap);
+    return HJ_OK;
+}
+
+int hj_hot_stats(const hj_ctx *c, int *mode, uint32_t *keys, double *share, uint64_t *matches) {
+    if (!c) return HJ_EINVAL;
+    const hj_ctx::Rel *H = nullptr;
+    for (int r = 0; r < 2; r++) if (c->rel[r].partitioned && c->rel[r].hot_mode) H = &c->rel[r];
+    if (mode) *mode = H ? H->hot_mode : 0;
+    if (keys) *keys = H ? H->sph.hot_keys : 0;
+    if (share) *share = H ? H->sph.hot_share : 0.0;
+    if (matches) *matches = (H && H->hot_mode == 1) ? c->h_scalars[13] : 0;
     return HJ_OK;
 }
 
@@ -1336,6 +1563,7 @@ int hj_join_late_materialize(hj_ctx *c, const int32_t *d_Dr, uint32_t ncolR, uin
     if ((ncolR && strideR < c->rel[HJ_REL_R].n) || (ncolS && strideS < c->rel[HJ_REL_S].n))
         return fail(c, HJ_EINVAL, "column stride smaller than the relation");
     HIPCHK(c, hipSetDevice(c->device));
+    RET(whole_partitions(c, 0));
     choose_bits(c);
     JoinArgs late{};
     const bool r_builds = c->build == HJ_REL_R;

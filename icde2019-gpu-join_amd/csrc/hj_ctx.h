@@ -71,7 +71,14 @@ struct Rel {
         const uint32_t *vbase1 = nullptr, *vcap1 = nullptr, *lt1 = nullptr, *own1 = nullptr, *heavy1_d = nullptr;
         const uint32_t *cbase2 = nullptr, *cap2 = nullptr, *lt2 = nullptr, *own2 = nullptr, *heavy2 = nullptr, *wg2 = nullptr, *rpart = nullptr, *pr0 = nullptr, *pnr = nullptr;
         Buf rbeg, rend;           // ranges written by pass 2 [nranges]
-    } sp;
+        // the heavy-hitter bypass (only in Rel::sph): the plan's capacities leave out the tuples pass 1 joins itself
+        bool hot_ready = false;   // the candidate table is on the device
+        Buf hot_tab;              // cand[HOT_SLOTS] | cnt[HOT_SLOTS] | pay[HOT_SLOTS]
+        uint32_t hot_keys = 0;    // candidates in the table
+        double hot_share = 0;     // sampled share of the relation's tuples the bypass takes (candidates unique in the other relation)
+    } sp, sph;                    // sph: the plan used when pass 1 bypasses the heavy hitters (hj_join, hj_join_and_materialize)
+    int hot_mode = 0;             // the CURRENT partitions lack the tuples pass 1 joined itself: 1 = counted (scalars[13], [14]), 2 = written to the output
+    bool hot_useless = false;     // the bypass was looked at for this binding and does not pay (or cannot be planned): plain sampled path
 };
 
 } // namespace hjx
@@ -88,7 +95,7 @@ struct hj_ctx {
     // workspace
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
-    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat
+    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat, [12] scratch, [13],[14] matches / aggregate of the heavy-hitter bypass
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
     hj::JoinArgs last_args{};
@@ -106,6 +113,15 @@ struct hj_ctx {
     double var_guide = 2.0;         // HJ_VAR_GUIDE: pass-2 piece sizing of the sampled path (plan_sampled); 0 = pieces of one span
     bool force_build_r = false;     // streaming probe side: R builds whatever the segment size
     int fast_path = 1;              // histogram-free passes first, exact passes as the fallback (HJ_FAST_PATH=0 / hj_config.exact_only)
+    // the heavy-hitter bypass: what the entry point that is running wants from pass 1 of a skewed probe side (0 nothing — every entry
+    // point but hj_join (1: count) and hj_join_and_materialize (2: write to hot_out)); partition_rel reads it
+    int hot_request = 0;
+    int32_t *hot_out[3] = {nullptr, nullptr, nullptr}; // key, payR, payS
+    uint64_t hot_cap = 0;
+    bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
+    bool debug = false;             // HJ_DEBUG: stderr diagnostics
+    int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)
+    double hot_min_share = 0.10;    // HJ_HOT_MIN_SHARE: smallest sampled share of the relation worth the lookups
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)
     uint64_t *h_shard_off = nullptr;
@@ -166,6 +182,7 @@ int hj_join_materialize_enqueue(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int3
 int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out);
 void hj_invalidate_all(hj_ctx *c);
 void drop_graph(hj_ctx *c);
+int whole_partitions(hj_ctx *c, int ok_mode); // partitions made under the heavy-hitter bypass are redone without it unless hot_mode == ok_mode
 // (hj_stream.hip: the host-memory paths drive the same partition / plan / join steps)
 // defer != nullptr: a relation that takes the plain histogram-free passes is prepared (buffers, state) but NOT launched — the two
 // launches come back in *defer (used = true) and the caller enqueues them, e.g. merged with the other relation's.

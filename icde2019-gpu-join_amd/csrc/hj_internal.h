@@ -117,14 +117,41 @@ hipError_t launch_part2_fast(hipStream_t st, const FastArgs &fa);
 hipError_t launch_part1_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb); // both relations of a join in one launch per pass
 hipError_t launch_part2_fast2(hipStream_t st, const FastArgs &fa, const FastArgs &fb);
 uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
+// The heavy-hitter bypass (round 6).  A relation known to be skewed has a DIRECT-MAPPED table of up to HOT_SLOTS candidate keys (its most
+// frequent keys by a sample, slot = hot_slot(key); of two candidates with one slot the more frequent stays — a first version with 4-way
+// buckets held 3 points more of config 4's S and cost pass 1 a 16-byte LDS read and four compares per tuple: slower); every step k_hot_build scans the OTHER relation for them (cnt = its tuples
+// with that key, pay = the payload of one of them), and pass 1 of the skewed relation joins the tuples of candidates that are UNIQUE
+// in the other relation where it first sees them — they never enter a partition.  mode 1: the matches are counted (acc[0] += 1,
+// acc[1] += pay * payload); mode 2: (key, table payload, streamed payload) tuples are written at *cursor (one exact reservation per
+// workgroup and round, positions >= out_cap are not written).  The reference's remedy for a hot build partition is the role flip of
+// jp.cu:929-1003; this removes the hot PROBE tuples from both passes and the probe.
+constexpr uint32_t HOT_SLOTS = 1024;
+constexpr int32_t HOT_NEVER = INT32_MIN; // never a candidate (the sentinel of the sampling table)
+struct HotArgs {
+    uint32_t mode = 0;           // 0 off, 1 count, 2 emit
+    const uint32_t *cand = nullptr, *cnt = nullptr; // [HOT_SLOTS] candidate keys (a filler never maps to its own slot) / tuples of the other relation per candidate
+    const int32_t *pay = nullptr;                   // [HOT_SLOTS] payload of one such tuple
+    unsigned long long *acc = nullptr;              // mode 1: {matches, aggregate}
+    int32_t *out_key = nullptr, *out_tab = nullptr, *out_str = nullptr; // mode 2: output columns (key, the other relation's payload, this relation's payload)
+    uint64_t out_cap = 0;
+    unsigned long long *cursor = nullptr;
+};
+__host__ __device__ inline uint32_t hot_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 22; }
+static_assert(HOT_SLOTS == 1024, "hot_slot yields 10 bits");
+__host__ __device__ inline uint32_t hot_filler(uint32_t slot) { return slot == 0 ? 1u : 0u; } // a key of ANOTHER slot: hot_slot(0) = 0, hot_slot(1) = 0x278
 // the sampled path of skewed relations (hj_part.hip: k_part1_var, k_part2_var)
 struct VarArgs {
     const uint32_t *vbase, *vcap; // pass 1: per digit [P]; pass 2: per (parent, child) [nparents*P]
     const uint32_t *lt, *own;     // lines dealt: (lines << 16 | first line) per digit [P] (pass 2: per parent row), owner digit per LDS line [512]
     const uint32_t *heavy;        // pass 1: [1]; pass 2: per parent — one digit holds more than a quarter of the input
     const uint4 *wg;              // pass 2: per workgroup {parent d, first pass-1 span, spans, output position of its sub-slots}
+    HotArgs hot;                  // pass 1: the heavy-hitter bypass
 };
-hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled);
+hipError_t launch_hot_sample(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t *tkey, uint32_t *tcnt, uint32_t slots);
+hipError_t launch_hot_collect(hipStream_t st, const uint32_t *tkey, const uint32_t *tcnt, uint32_t slots, uint32_t thr, uint2 *out, uint32_t *nout, uint32_t cap);
+hipError_t launch_hot_build(hipStream_t st, const int32_t *keys, const int32_t *pays, uint64_t n, const uint32_t *cand, uint32_t *cnt, int32_t *pay, unsigned long long *zero_acc);
+hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled,
+                               const uint32_t *hot_cand = nullptr, const uint32_t *hot_cnt = nullptr);
 hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy);
 hipError_t launch_part2_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, uint32_t nwg, bool any_heavy, bool any_light);
 hipError_t launch_dist_segments(hipStream_t st, const uint64_t *oend, uint32_t G, uint32_t nsp, uint32_t cap, uint32_t me, uint64_t base,
@@ -138,7 +165,8 @@ hipError_t launch_join_plan_fused(hipStream_t st, const JoinArgs &a, uint32_t np
 // caller (or the pass-2 kernel before it, FastArgs.zero_items) has zeroed; the items come out in no particular order
 hipError_t launch_join_plan_atomic(hipStream_t st, const JoinArgs &a, uint32_t nparts, JoinItem *items, uint64_t *zero2, uint64_t *zero_cursor,
                                    uint64_t *n_items);
-hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2);
+hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2,
+                       const uint64_t *extra2 = nullptr); // extra2: two more words added in (the matches / aggregate of the heavy-hitter bypass)
 hipError_t launch_join_expand(hipStream_t st, const JoinArgs &a, uint32_t nparts, const uint32_t *items_scanned,
                               const uint64_t *chunk_prefix, JoinItem *items);
 size_t join_lds_bytes(uint32_t nh, uint32_t cap, bool tag16);

@@ -747,8 +747,10 @@ __global__ __launch_bounds__(JOIN_THREADS, 6) void k_join_mat_reg(JoinArgs a) { 
 }
 
 // count-only result: sums of the per-wave match counts and aggregates into out[0], out[1] (zeroed by k_join_plan)
+// extra (optional): two more words added in by one thread — what the heavy-hitter bypass of pass 1 counted (hj_part.hip, HOT 1)
 __global__ __launch_bounds__(256) void k_sum2(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ agg,
-                                              const uint32_t *__restrict__ len_ptr, uint64_t mul, unsigned long long *__restrict__ out) {
+                                              const uint32_t *__restrict__ len_ptr, uint64_t mul, unsigned long long *__restrict__ out,
+                                              const uint64_t *__restrict__ extra) {
     const uint64_t L = (uint64_t)(*len_ptr) * mul;
     uint64_t s = 0, t = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (uint64_t)gridDim.x * blockDim.x) { s += cnt[i]; t += agg[i]; }
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(256) void k_sum2(const uint64_t *__restrict__ cnt, 
     if (threadIdx.x == 0) {
         s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         t = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (extra && blockIdx.x == 0) { s += extra[0]; t += extra[1]; }
         if (s) atomicAdd(out, (unsigned long long)s);
         if (t) atomicAdd(out + 1, (unsigned long long)t);
     }
@@ -893,8 +896,8 @@ hipError_t launch_join(hipStream_t st, const JoinArgs &a, uint32_t max_items, bo
     return hipSuccess;
 }
 
-hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2) {
-    hipLaunchKernelGGL(k_sum2, dim3(256), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2));
+hipError_t launch_sum2(hipStream_t st, const uint64_t *cnt, const uint64_t *agg, const uint32_t *len_ptr, uint64_t mul, uint64_t *out2, const uint64_t *extra2) {
+    hipLaunchKernelGGL(k_sum2, dim3(256), dim3(256), 0, st, cnt, agg, len_ptr, mul, reinterpret_cast<unsigned long long *>(out2), extra2);
     HJ_LAUNCH_CHECK();
     return hipSuccess;
 }

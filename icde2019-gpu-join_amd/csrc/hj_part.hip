@@ -239,6 +239,7 @@ struct WfLds {
     uint32_t *pc4, *sb;          // pass 2: prefix of 4-tuple units per segment [nseg+1]; segment start | padding
     uint32_t *lo;                // exact pass: first valid slot of a digit's first line (aliases pc4: never both)
     uint32_t *lt, *own;          // exact pass under skew: lines << 16 | first line per digit; owner digit per line
+    uint32_t *hk, *hot;          // heavy-hitter bypass (pass 1 only: aliases the segment tables): hk[HOT_SLOTS] (key, payload) pairs; hot[64] reduction words
 };
 
 // digit d's output slot has index slotA + d*slotB (that is where its range [beg, end) is written) and, with uniform capacities,
@@ -276,13 +277,19 @@ __device__ __forceinline__ uint32_t slot_lines(const FastGeom &g, uint32_t d) { 
 // says each will receive per round (L_.lt[d] = lines << 16 | first line, L_.own[line] = digit), instead of K each.
 // MODE 1 (exact pass only): the digit is the multi-GPU shard of the key (digit_of<1>: hash, optional position table), P
 // need not be a power of two (K = the largest power of two <= 512/P lines per digit).
-template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0>
+// HOT (pass 1 of a relation known to be skewed; SRC 0): the heavy-hitter bypass.  L_.hk is a direct-mapped table of (key, payload the
+// OTHER relation has for it) pairs; a tuple whose key sits in its slot is joined here and takes no slot of a partition.  HOT 1: counted
+// (matches and payload products, one atomic pair per workgroup at the end).  HOT 2: written to the join's output columns — the hits of
+// round r are ranked by ballots, the workgroup reserves their exact number on the output cursor with ONE returning atomic issued in
+// phase B, and they are written at the start of round r + 1 (the atomic has phases B and C to return; the tuples are still in kk/pp).
+template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0, int HOT = 0>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
                                         uint32_t P, const FastGeom g, int32_t *__restrict__ out_keys,
                                         int32_t *__restrict__ out_pays, uint64_t *__restrict__ obeg,
                                         uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf,
-                                        const uint32_t *__restrict__ remap = nullptr) {
+                                        const uint32_t *__restrict__ remap = nullptr, const HotArgs *hotp = nullptr) {
+    static_assert(HOT == 0 || (SRC == 0 && !EXACT && MODE == 0), "the bypass belongs to pass 1 of the histogram-free passes");
     int2 *buf = L_.buf;
     uint32_t *hh = L_.hh, *line = L_.line;
     const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)MAX_PARTS / P);
@@ -351,10 +358,40 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     const uint32_t my_base = tid < P ? slot_line(g, tid) : 0u, my_lim = my_base + (tid < P ? slot_lines(g, tid) : 0u);
     const uint32_t my_gran = (VAR && tid < P) ? (L_.lt[tid] >> 16) : K;
     const uint32_t trash = MAX_PARTS * WC_LINE + tid;
+    // ---- heavy-hitter bypass state ----
+    const uint2 *hk2 = reinterpret_cast<const uint2 *>(L_.hk);
+    uint32_t *hwtot = L_.hot, *hwpre = L_.hot + 16;                                   // HOT 2: hits per wave / their exclusive prefix
+    unsigned long long *hbase = reinterpret_cast<unsigned long long *>(L_.hot + 32); // HOT 2: the round's reservation
+    uint32_t hcnt = 0, hw = 0; // HOT 1: this thread's hits / hit bits of the round's 8 tuples
+    uint64_t hagg = 0;
+    unsigned long long hres = 0;
+    // HOT 2: the hits of the round whose tuples are in (kk, pp) go out — every wave runs the same ballots
+    auto hot_emit = [&]() {
+        uint64_t wb = (uint64_t)(*hbase) + hwpre[wv];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int j = u * 4 + e;
+                const bool hit = (hw >> j) & 1u;
+                const uint64_t m = __ballot(hit);
+                if (hit) {
+                    const uint64_t pos = wb + (uint32_t)__popcll(m & (((uint64_t)1 << ln) - 1));
+                    if (pos < hotp->out_cap) {
+                        const uint32_t key = (uint32_t)elem(kk[u], e);
+                        hotp->out_key[pos] = (int32_t)key;
+                        hotp->out_str[pos] = elem(pp[u], e);
+                        hotp->out_tab[pos] = (int32_t)hk2[hot_slot(key)].y;
+                    }
+                }
+                wb += (uint32_t)__popcll(m);
+            }
+    };
     uint32_t par = 0;
     for (uint32_t round = 0; round < nrounds; round++, par ^= 1) {
         uint32_t *h = hh + par * WC_HSTRIDE, *hprev = hh + (par ^ 1) * WC_HSTRIDE;
         // ---- A ----
+        if (HOT == 2 && round) hot_emit();
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -385,18 +422,47 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             fetch(round + 1, u, kv[u], pv[u], vm[u]);
         }
         uint32_t code[U * 4]; // digit << 16 | slot in the digit's lines ; WF_NONE = not a tuple
+        uint32_t htot = 0;    // HOT 2: the wave's hits this round (wave-uniform)
+        if (HOT) { // one 8-byte LDS read per tuple: the (key, payload) pair of its slot; hw = hit bits.  (Looking the NEXT round's tuples up
+                   // at the end of phase C instead — one LDS round trip less in phase A — measured 2.5 % slower.)
+            hw = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = u * 4 + e;
+                    const uint32_t key = (uint32_t)elem(kk[u], e);
+                    const uint2 en = hk2[hot_slot(key)];
+                    const bool hit = ((vmc[u] >> e) & 1u) && en.x == key;
+                    hw |= hit ? (1u << j) : 0u;
+                    if (HOT == 1) hagg += hit ? (uint64_t)((int64_t)(int32_t)en.y * (int64_t)elem(pp[u], e)) : (uint64_t)0;
+                    if (HOT == 2) htot += (uint32_t)__popcll(__ballot(hit));
+                }
+            if (HOT == 1) hcnt += (uint32_t)__popc(hw);
+        }
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const bool valid = (vmc[u] >> e) & 1u;
+                const bool valid = ((vmc[u] >> e) & 1u) && !(HOT && ((hw >> (u * 4 + e)) & 1u));
                 const uint32_t d = MODE == 0 ? (((uint32_t)elem(kk[u], e) >> shift) & mask) : digit_of<1>((uint32_t)elem(kk[u], e), 0, P, remap);
+                // (HOT: more than a third of the tuples may be hits, which take no slot: their LDS operations are masked off, not pointed at trash)
                 const uint32_t old = HEAVY ? rank_in_digit(h, d, valid, P <= 2)
+                                   : HOT ? (valid ? atomicAdd(&h[d], 1u) : 0u)
                                            : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
+        if (HOT == 2 && ln == 0) hwtot[wv] = htot;
         __syncthreads();
         // ---- B ----
+        if (HOT == 2 && tid < (uint32_t)(WC_THREADS / 64)) { // lanes 0..15 of wave 0: prefix of the waves' hits, one reservation for the workgroup
+            const uint32_t mine = hwtot[tid];
+            uint32_t v = mine;
+#pragma unroll
+            for (int o = 1; o < WC_THREADS / 64; o <<= 1) { const uint32_t t = __shfl_up(v, o, 64); if ((int)tid >= o) v += t; }
+            hwpre[tid] = v - mine;
+            if (tid == (uint32_t)(WC_THREADS / 64) - 1) hres = v ? atomicAdd(hotp->cursor, (unsigned long long)v) : 0ull; // (the wave goes on: the value is awaited at the end of C)
+        }
         const uint32_t stop = EXACT ? 0u : L_.wlist[(WC_THREADS / 64) * 32];
         uint32_t hw[U * 4];
 #pragma unroll
@@ -420,7 +486,8 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 const uint32_t capd = VAR ? (lt >> 16) * WC_LINE : capS, based = VAR ? (lt & 0xFFFFu) * WC_LINE : d * capS;
                 const bool now = valid && (leaves ? q < capd : full == 0);
                 any_bypass |= valid && leaves && q >= capd;
-                buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                if (!HOT) buf[now ? based + q : trash] = make_int2(elem(kk[u], e), elem(pp[u], e));
+                else if (now) buf[based + q] = make_int2(elem(kk[u], e), elem(pp[u], e));
                 keep[j] = (valid && !leaves && full != 0) ? based + (q - full) : WF_NONE;
             }
         if (any_bypass) { // rare: a digit received more than its K lines in one round; straight to HBM
@@ -481,8 +548,22 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 }
             }
         }
+        if (HOT == 2 && tid == (uint32_t)(WC_THREADS / 64) - 1) *hbase = hres;
         __syncthreads();
         if (stop) return; // workgroup-uniform: every thread read the same LDS word between the same barriers
+    }
+    if (HOT == 2 && nrounds) hot_emit(); // the last round's hits
+    if (HOT == 1) { // one atomic pair per workgroup
+        const uint64_t wc = wave_sum64((uint64_t)hcnt), wa = wave_sum64(hagg);
+        unsigned long long *red = reinterpret_cast<unsigned long long *>(L_.hot);
+        if (ln == 0) { red[wv] = wc; red[16 + wv] = wa; }
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t sc = 0, sa = 0;
+            for (int w = 0; w < WC_THREADS / 64; w++) { sc += red[w]; sa += red[16 + w]; }
+            if (sc) atomicAdd(hotp->acc, (unsigned long long)sc);
+            if (sa) atomicAdd(hotp->acc + 1, (unsigned long long)sa);
+        }
     }
     // ---- epilogue: phase A of the last round, the partially filled last line of every digit, the slot ranges ----
     uint32_t *hlast = hh + (par ^ 1) * WC_HSTRIDE;
@@ -530,10 +611,21 @@ __device__ __forceinline__ void wf_carve(WfLds &L_, unsigned char *smem) {
     L_.lo = L_.pc4;
     L_.lt = L_.sb + WF_MAXSEG;       // lines dealt by need: an area of their own (the segment tables of pass 2 are in use then)
     L_.own = L_.lt + MAX_PARTS;
+    L_.hk = L_.pc4;                  // 2 * HOT_SLOTS words of the WF_MAXSEG + 4 + WF_MAXSEG the two segment tables hold (16-byte aligned)
+    L_.hot = L_.own + MAX_PARTS;
+}
+static_assert(2 * HOT_SLOTS <= 2 * WF_MAXSEG + 4, "the hot-key table lives in the segment tables of pass 2");
+// the candidate table of the heavy-hitter bypass as a workgroup uses it: (key, payload) pairs; a candidate counts only while the other
+// relation holds it exactly once (cnt == 1, k_hot_build of this step); the others become fillers, which no key of their slot equals
+__device__ __forceinline__ void hot_load(uint32_t *hk, const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cnt, const int32_t *__restrict__ pay) {
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) {
+        hk[2 * i] = cnt[i] == 1u ? cand[i] : hot_filler(i);
+        hk[2 * i + 1] = (uint32_t)pay[i];
+    }
 }
 size_t fast_lds_bytes_impl() {
     return (size_t)WF_LINES * WC_LINE * 8 + (size_t)WC_HSTRIDE * 4 * 2 + (size_t)MAX_PARTS * 4 +
-           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2;
+           ((WC_THREADS / 64) * 32 + 4) * 4 + (size_t)(WF_MAXSEG + 4) * 4 + (size_t)WF_MAXSEG * 4 + (size_t)MAX_PARTS * 4 * 2 + 64 * 4;
 }
 
 // The exact pass: scatter one span to the positions the histogram + scan assigned.  The span's private output run of
@@ -660,13 +752,18 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_fast2(FastArgs a, FastArgs
 // SLICES and a workgroup counts the ids of ONE slice only; workgroups of the same slice share the sample between them, every slice
 // reads the whole sample (keys only, 1/stride of the relation: 2-8 x ~1 GiB for 2^31 tuples at 16-18 bits, once per binding).
 constexpr uint32_t SAMPLE_LDS_BITS = 15;
+// hot_cand / hot_cnt (optional): the heavy-hitter bypass will take the tuples of these keys out of the relation in pass 1 — they are
+// counted as sampled (the shares stay fractions of the WHOLE relation) but enter no bin
 __global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict__ keys, uint64_t n, uint32_t mask, uint32_t stride, uint32_t slice_bits,
-                                                       uint32_t *__restrict__ hist, unsigned long long *__restrict__ sampled) {
+                                                       uint32_t *__restrict__ hist, unsigned long long *__restrict__ sampled,
+                                                       const uint32_t *__restrict__ hot_cand, const uint32_t *__restrict__ hot_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
     const uint32_t slice = blockIdx.x & ((1u << slice_bits) - 1), wg = blockIdx.x >> slice_bits, nwg = gridDim.x >> slice_bits;
     const uint32_t lmask = slice_bits ? (1u << SAMPLE_LDS_BITS) - 1 : mask; // the bins of one workgroup
     for (uint32_t i = threadIdx.x; i <= lmask; i += 1024) h[i] = 0;
+    const uint2 *hk2 = reinterpret_cast<const uint2 *>(h + lmask + 1); // behind the bins
+    if (hot_cand) hot_load(h + lmask + 1, hot_cand, hot_cnt, reinterpret_cast<const int32_t *>(hot_cand));
     __syncthreads();
     // blocks of 4096 tuples, every stride-th one; the heavy key would serialise a wave's LDS atomics: aggregated rank
     uint64_t cnt = 0;
@@ -675,8 +772,11 @@ __global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict
         for (int u = 0; u < 4; u++) {
             const uint64_t i = b * 4096 + (uint64_t)u * 1024 + threadIdx.x;
             const bool valid = i < n;
-            const uint32_t id = valid ? ((uint32_t)keys[i] & mask) : 0u;
-            const bool mine = valid && (id >> SAMPLE_LDS_BITS) == (slice_bits ? slice : id >> SAMPLE_LDS_BITS);
+            const uint32_t key = valid ? (uint32_t)keys[i] : 0u;
+            const uint32_t id = key & mask;
+            bool cold = true;
+            if (hot_cand) cold = hk2[hot_slot(key)].x != key;
+            const bool mine = valid && cold && (id >> SAMPLE_LDS_BITS) == (slice_bits ? slice : id >> SAMPLE_LDS_BITS);
             (void)rank_in_digit(h, mine ? (id & lmask) : 0u, mine);
             cnt += valid;
         }
@@ -688,26 +788,27 @@ __global__ __launch_bounds__(1024) void k_sample_joint(const int32_t *__restrict
     if (slice == 0 && lane_id() == 0 && cnt) atomicAdd(sampled, (unsigned long long)cnt); // (every slice sees the whole sample: counted once)
 }
 
-hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled) {
+hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled,
+                               const uint32_t *hot_cand, const uint32_t *hot_cnt) {
     static bool set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (bits > SAMPLE_LDS_BITS + 3) return hipErrorInvalidValue;
     const uint32_t slice_bits = bits > SAMPLE_LDS_BITS ? bits - SAMPLE_LDS_BITS : 0u;
-    const size_t lds = ((size_t)1 << (slice_bits ? SAMPLE_LDS_BITS : bits)) * 4;
+    const size_t lds = ((size_t)1 << (slice_bits ? SAMPLE_LDS_BITS : bits)) * 4 + (hot_cand ? (size_t)2 * HOT_SLOTS * 4 : 0);
     {
         std::lock_guard<std::mutex> lock(g_attr_mutex);
         if (dev < 0 || dev >= 64 || !set[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_joint), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_joint), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 2 * HOT_SLOTS * 4);
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_sample_joint, dim3(256), dim3(1024), lds, st, keys, n, (1u << bits) - 1, stride, slice_bits, hist, reinterpret_cast<unsigned long long *>(sampled));
+    hipLaunchKernelGGL(k_sample_joint, dim3(256), dim3(1024), lds, st, keys, n, (1u << bits) - 1, stride, slice_bits, hist, reinterpret_cast<unsigned long long *>(sampled), hot_cand, hot_cnt);
     return hipGetLastError();
 }
 
-template <int U, bool HEAVY>
+template <int U, bool HEAVY, int HOT>
 __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WfLds L_;
@@ -722,11 +823,80 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[tid]; }
     if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
+    if (HOT) hot_load(L_.hk, v.hot.cand, v.hot.cnt, v.hot.pay);
     __syncthreads();
     // 512 digits: every digit has exactly one of the 512 lines, there is nothing to deal — the fixed-geometry rounds (no per-digit
     // line table in the inner loops) with the sampled slot capacities (a 512-way pass under skew: 9.8 -> see r4_sampled_16_17_bits.txt)
-    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
-    else wc_fast<U, 0, 0, false, HEAVY, true, 0>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0, HOT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
+    else wc_fast<U, 0, 0, false, HEAVY, true, 0, HOT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
+}
+
+// ---- the heavy-hitter bypass: finding the candidates (once per binding) and what the other relation holds for them (every step) ----
+// k_hot_sample: nsamp keys of the relation (runs of 16, evenly spread) counted in an open-addressing table in HBM (slots >= 2 * nsamp)
+__global__ __launch_bounds__(256) void k_hot_sample(const int32_t *__restrict__ keys, uint64_t n, uint32_t nsamp, uint32_t *__restrict__ tkey,
+                                                    uint32_t *__restrict__ tcnt, uint32_t mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamp) return;
+    const uint64_t stride = n / (nsamp >> 4); // >= 16: the runs do not overlap
+    const uint64_t pos = (uint64_t)(i >> 4) * stride + (i & 15u);
+    if (pos >= n) return;
+    const uint32_t key = (uint32_t)keys[pos];
+    if ((int32_t)key == HOT_NEVER) return; // the table's "empty"
+    uint32_t slot = fmix32(key) & mask;
+    for (;;) {
+        const uint32_t prev = atomicCAS(&tkey[slot], (uint32_t)HOT_NEVER, key);
+        if (prev == (uint32_t)HOT_NEVER || prev == key) { atomicAdd(&tcnt[slot], 1u); return; }
+        slot = (slot + 1) & mask;
+    }
+}
+// the keys sampled at least thr times, as (key, count) pairs in no particular order; *nout counts all of them (it may exceed cap)
+__global__ __launch_bounds__(256) void k_hot_collect(const uint32_t *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t slots, uint32_t thr,
+                                                     uint2 *__restrict__ out, uint32_t *__restrict__ nout, uint32_t cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    const uint32_t c = tcnt[i];
+    if (c >= thr) {
+        const uint32_t at = atomicAdd(nout, 1u);
+        if (at < cap) out[at] = make_uint2(tkey[i], c);
+    }
+}
+// every step: cnt[slot] = tuples of the scanned relation whose key is candidate `slot`, pay[slot] = the payload of one of them.
+// 4 B per tuple read (keys only; the payload of a hit is fetched on its own).  cnt must be zero at launch; *zero_acc (two words) is
+// zeroed for the pass that follows on the same stream.
+__global__ __launch_bounds__(256) void k_hot_build(const int32_t *__restrict__ keys, const int32_t *__restrict__ pays, uint64_t n,
+                                                   const uint32_t *__restrict__ cand, uint32_t *__restrict__ cnt, int32_t *__restrict__ pay,
+                                                   unsigned long long *__restrict__ zero_acc) {
+    __shared__ uint32_t hk[HOT_SLOTS];
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) hk[i] = cand[i];
+    if (zero_acc && blockIdx.x == 0 && threadIdx.x < 2) zero_acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (uint64_t)gridDim.x * blockDim.x * 4) {
+        const int4 kv = load4(keys, i, n);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (i + e >= n) break;
+            const uint32_t key = (uint32_t)elem(kv, e);
+            const uint32_t slot = hot_slot(key);
+            if (hk[slot] == key) {
+                atomicAdd(&cnt[slot], 1u);
+                pay[slot] = pays[i + e];
+            }
+        }
+    }
+}
+hipError_t launch_hot_sample(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t *tkey, uint32_t *tcnt, uint32_t slots) {
+    hipLaunchKernelGGL(k_hot_sample, dim3((nsamp + 255) / 256), dim3(256), 0, st, keys, n, nsamp, tkey, tcnt, slots - 1);
+    return hipGetLastError();
+}
+hipError_t launch_hot_collect(hipStream_t st, const uint32_t *tkey, const uint32_t *tcnt, uint32_t slots, uint32_t thr, uint2 *out, uint32_t *nout, uint32_t cap) {
+    hipLaunchKernelGGL(k_hot_collect, dim3((slots + 255) / 256), dim3(256), 0, st, tkey, tcnt, slots, thr, out, nout, cap);
+    return hipGetLastError();
+}
+hipError_t launch_hot_build(hipStream_t st, const int32_t *keys, const int32_t *pays, uint64_t n, const uint32_t *cand, uint32_t *cnt, int32_t *pay, unsigned long long *zero_acc) {
+    const uint64_t want = (n / 4 + 255) / 256;
+    const uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(k_hot_build, dim3(blocks), dim3(256), 0, st, keys, pays, n, cand, cnt, pay, zero_acc);
+    return hipGetLastError();
 }
 
 template <int U>
@@ -1139,17 +1309,16 @@ hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
 }
 
 hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy) {
-    static bool set[2][64] = {};
+    static bool set[4][64] = {};
     hipError_t e;
-    if (heavy) {
-        auto fn = k_part1_var<2, true>;
-        if ((e = fast_attr(fn, set[0])) != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va);
-    } else {
-        auto fn = k_part1_var<2, false>;
-        if ((e = fast_attr(fn, set[1])) != hipSuccess) return e;
-        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va);
-    }
+#define HJ_P1V(IDX, HV, HT) do { auto fn = k_part1_var<2, HV, HT>; if ((e = fast_attr(fn, set[IDX])) != hipSuccess) return e; \
+        hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va); } while (0)
+    if (va.hot.mode && heavy) return hipErrorInvalidValue; // (the host does not bypass where the residue still has a dominant digit)
+    if (va.hot.mode == 1) HJ_P1V(2, false, 1);
+    else if (va.hot.mode == 2) HJ_P1V(3, false, 2);
+    else if (heavy) HJ_P1V(0, true, 0);
+    else HJ_P1V(1, false, 0);
+#undef HJ_P1V
     return hipGetLastError();
 }
 

@@ -226,6 +226,32 @@ class HashJoin:
                                              C.byref(n)))
         return n.value
 
+    def join_and_materialize_into(self, d_key, d_payR, d_payS, cap):
+        """hj_join_and_materialize: partition both + ONE probe in one call (a skewed probe side's hot keys are written by pass 1)."""
+        n = C.c_uint64()
+        self._ck(self._L.hj_join_and_materialize(self._h, _dev_ptr(d_key), _dev_ptr(d_payR), _dev_ptr(d_payS), cap, C.byref(n)))
+        return n.value
+
+    def join_and_materialize(self, cap):
+        """Host numpy columns (key, payR, payS) of hj_join_and_materialize."""
+        bufs = [self.device_malloc(max(cap, 1) * 4) for _ in range(3)]
+        try:
+            n = self.join_and_materialize_into(bufs[0], bufs[1], bufs[2], cap)
+            return tuple(self.to_host(b, n, np.int32) for b in bufs)
+        finally:
+            for b in bufs:
+                self.device_free(b)
+
+    def hot_stats(self):
+        """The heavy-hitter bypass of the last join() / join_and_materialize(): mode (0 none, 1 counted, 2 written), keys, share, matches."""
+        m, k, s, x = C.c_int(), C.c_uint32(), C.c_double(), C.c_uint64()
+        self._ck(self._L.hj_hot_stats(self._h, C.byref(m), C.byref(k), C.byref(s), C.byref(x)))
+        return {"mode": m.value, "keys": k.value, "share": s.value, "matches": x.value}
+
+    def reload_knobs(self):
+        """Experiments: re-read the HJ_* environment knobs (the library reads them once, in hj_create)."""
+        self._ck(self._L.hj_reload_knobs(self._h))
+
     def join_materialize(self, cap=None):
         """Returns host numpy columns (key, payR, payS); sizes the output with a count run if cap is None."""
         if cap is None:

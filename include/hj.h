@@ -121,8 +121,22 @@ int hj_join_count(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
  * n_out > cap (nothing beyond cap is written).  [sync] */
 int hj_join_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap,
                         uint64_t *n_out);
-/* One call = hj_partition(R) + hj_partition(S) + hj_join_count (the timed region hjcp.cu:881-933). [sync] */
+/* One call = hj_partition(R) + hj_partition(S) + hj_join_count (the timed region hjcp.cu:881-933). [sync]
+ * Because the call hands out nothing but the result, a probe side known to be skewed takes the HEAVY-HITTER BYPASS (round 6): its
+ * most frequent keys (up to 1024, from a sample taken once per binding) are looked up in LDS by pass 1, and a tuple whose key the
+ * other relation holds exactly once is joined right there — counted, never partitioned (config 4: 39 % of S skips 32 of its 40 bytes).
+ * Keys the other relation repeats or lacks take the ordinary path.  The reference's remedy for the overflow case is the role flip of
+ * jp.cu:929-1003; SURVEY §7 step 5 names heavy-hitter handling. */
 int hj_join(hj_ctx *ctx, uint64_t *matches, uint64_t *agg);
+/* One call = hj_partition(R) + hj_partition(S) + hj_join_materialize: the reference's lead timed run (partition both, then
+ * join_partitioned_results, hjcp.cu:881-913).  Same output contract as hj_join_materialize.  With the output columns known to the
+ * partition passes, the heavy-hitter bypass WRITES the (key, payR, payS) tuples of the hot keys from pass 1 (one exact reservation on
+ * the output cursor per workgroup and round); the probe appends the rest.  [sync] */
+int hj_join_and_materialize(hj_ctx *ctx, int32_t *d_key, int32_t *d_payR, int32_t *d_payS, uint64_t cap, uint64_t *n_out);
+/* The bypass as the last hj_join / hj_join_and_materialize used it: *mode 0 = not used, 1 = hot tuples counted, 2 = written; keys of the
+ * table the other relation held exactly once when the table was planned; the sampled share of the probe relation's tuples they cover;
+ * (mode 1) the matches pass 1 counted itself.  Any pointer may be NULL. */
+int hj_hot_stats(const hj_ctx *ctx, int *mode, uint32_t *keys, double *share, uint64_t *matches);
 
 /* ---- late materialisation / wide payloads (join_partitioned_varpayload jp.cu:1420-1557,
  *      outOfGPU_Join_payload_var hjcp.cu:542-708): the relations must be partitioned with ROW-ID payloads;
@@ -219,6 +233,9 @@ int hj_partition_layout(hj_ctx *ctx, int rel, int *slotted);
  * user still waits for it). */
 int hj_last_call_breakdown(const hj_ctx *ctx, double *alloc_ms, uint32_t *allocations, double *failed_attempt_ms,
                            double *sample_plan_ms, double *total_ms);
+/* experiments only: read the environment knobs again.  The library reads them ONCE, in hj_create; no entry point of the
+ * path calls getenv.  tools/experiments/ switch a knob between two calls of one context with this. */
+int hj_reload_knobs(hj_ctx *ctx);
 int hj_enable_timings(hj_ctx *ctx, int level); /* 0 off, 1 data-moving kernels, 2 every launch.  [sync] */
 int hj_timings_reset(hj_ctx *ctx);
 /* [sync] fills up to cap entries, returns the number of kernels known in *n. */

@@ -311,3 +311,138 @@ def test_stream_probe_segments_that_overflow_are_redone(P):
         for _ in range(2):
             assert hj.join_stream_probe(S, Ps, segment_tuples=seg) == (em, eagg)
         assert hj.join_stream_probe(S, None, "rowid", segment_tuples=seg) == (em, eagg)
+
+
+# ---- the heavy-hitter bypass (round 6): hj_join / hj_join_and_materialize join the probe side's hottest keys in pass 1 ----
+
+def _zipf_fk(P, nR, nS, theta, seed):
+    g = P.generator
+    g.seed_generator(seed)
+    R = g.create_relation_unique(None, nR, nR)
+    S = g.create_relation_zipf(None, nS, nR, theta)
+    return R, S
+
+
+@pytest.mark.parametrize("theta,expect_mode", [(0.5, 0), (1.0, 1), (1.5, 1)])
+@pytest.mark.parametrize("cfg", [dict(bits1=8, bits2=7), dict(bits1=9, bits2=6)])
+def test_heavy_hitter_bypass_zipf(P, theta, expect_mode, cfg):
+    """PK-FK with Zipf foreign keys from the reference's generator stream.  theta 1.0 / 1.5: the top keys cover more than a tenth of S,
+    pass 1 joins them itself (hot_stats mode 1 / 2) — count, aggregate (signed payload products mod 2^64) and the materialised multiset
+    against the oracle; theta 0.5: the top 1024 keys cover ~6 %: the look at the keys says no, the plain sampled path runs.  Then the
+    call sequences around it: a materialising probe after hj_join (the relation is partitioned again, whole), a count after
+    hj_join_and_materialize, introspection, a capacity that is too small."""
+    import torch
+    nR, nS = 1 << 18, 3 << 20
+    R, S = _zipf_fk(P, nR, nS, theta, 777)
+    rng = np.random.default_rng(5)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = rng.integers(-2**31, 2**31 - 1, nS).astype(np.int32)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    dR, dPr, dS, dPs = (torch.from_numpy(x).cuda() for x in (R, Pr, S, Ps))
+    with P.HashJoin(0) as hj:
+        hj.configure(**cfg)
+        hj.bind_device(P.REL_R, dR, dPr)
+        hj.bind_device(P.REL_S, dS, dPs)
+        for i in range(3):       # overflow -> key sample + table -> bypass; then twice from what was learned
+            assert hj.join() == (em, eagg), i
+            st = hj.hot_stats()
+            assert st["mode"] == expect_mode, (i, st)
+            assert hj.partition_layout(P.REL_S) == "sampled"
+        if expect_mode:
+            assert st["keys"] > 100 and 0.1 < st["share"] < 1.0 and st["matches"] > 0.5 * st["share"] * nS, st
+            assert st["matches"] < em
+        # the count again on the same partitions (what pass 1 counted is still on the device)
+        assert hj.join_count() == (em, eagg)
+        # a materialising probe wants every tuple in a partition: S is partitioned again without the bypass
+        k, pr, ps = hj.join_materialize(cap=em)
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        assert hj.hot_stats()["mode"] == 0
+        # one call, the output columns known to pass 1: the hot keys' tuples are written from there
+        k, pr, ps = hj.join_and_materialize(cap=em)
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        assert hj.hot_stats()["mode"] == (2 if expect_mode else 0)
+        for a, b in zip(sorted_triples(k, pr, ps), sorted_triples(*o.join_materialize(R, Pr, S, Ps))):
+            assert np.array_equal(a, b)
+        # ... and a count on partitions whose hot tuples went to an output: partitioned again, whole
+        assert hj.join_count() == (em, eagg)
+        # too small a capacity: nothing beyond it is written, the true size comes back
+        bufs = [torch.full((em // 2 + 64,), -7, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+        with pytest.raises(P.HJError) as ei:
+            hj.join_and_materialize_into(bufs[0], bufs[1], bufs[2], em // 2)
+        assert ei.value.code == P.ECAPACITY and str(em) in str(ei.value)
+        assert all(bool((b[em // 2:] == -7).all()) for b in bufs)
+        # introspection after a bypassing join: oracle-identical gap-free partitions
+        assert hj.join() == (em, eagg)
+        c = hj.config()
+        gk, gp, goff = hj.partitions(P.REL_S, nS)
+        ok, op, ooff = o.radix_partition(S, Ps, 0, c["bits1"] + c["bits2"])
+        assert np.array_equal(goff, ooff) and np.array_equal(o.partition_digest(gk, gp, goff), o.partition_digest(ok, op, ooff))
+        assert hj.join() == (em, eagg) and hj.hot_stats()["mode"] == expect_mode
+
+
+@pytest.mark.parametrize("skewed_rel", [1, 0])
+def test_heavy_hitter_bypass_only_takes_keys_the_other_side_holds_once(P, skewed_rel):
+    """Four hot keys in the skewed relation: A and D are unique in the other relation (bypassed), B is held three times there (its
+    tuples take the ordinary path and match three times each), C not at all (ordinary path, no match).  Both bindings of the skewed
+    relation (as S and as R: the payload columns must not swap).  Then the other relation changes under its binding so that A is no
+    longer unique: the slots sized without A's tuples overflow, the call falls back and still answers right."""
+    import torch
+    rng = np.random.default_rng(96)
+    nB, nP = 1 << 18, 3 << 20
+    Bk = rng.permutation(nB).astype(np.int32) + 10            # the PK side: keys 10 .. nB+9
+    A, Bdup, D = int(Bk[3]), int(Bk[11]), int(Bk[12])
+    C = -12345                                                 # a key the PK side does not hold
+    Bk[100:102] = Bdup                                         # B three times
+    u = rng.random(nP)
+    Pk = np.where(u < 0.30, A, np.where(u < 0.45, Bdup, np.where(u < 0.55, C, np.where(u < 0.62, D, Bk[rng.integers(200, nB, nP)])))).astype(np.int32)
+    Bp = np.arange(nB, dtype=np.int32)
+    Pp = np.arange(nP, dtype=np.int32) + (1 << 24)             # disjoint from the other column: a swapped payload column shows
+    rels = {1 - skewed_rel: (Bk, Bp), skewed_rel: (Pk, Pp)}
+    (Rk, Rp), (Sk, Sp) = rels[0], rels[1]
+    em, eagg, echk = o.join_count(Rk, Rp, Sk, Sp, checksum=True)
+    dev = {r: tuple(torch.from_numpy(x).cuda() for x in rels[r]) for r in (0, 1)}
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=8, bits2=7)
+        hj.bind_device(P.REL_R, *dev[0])
+        hj.bind_device(P.REL_S, *dev[1])
+        for i in range(3):
+            assert hj.join() == (em, eagg), i
+        st = hj.hot_stats()
+        assert st["mode"] == 1 and st["keys"] == 2 and 0.30 < st["share"] < 0.45, st     # A and D only
+        assert abs(st["matches"] - int(((Pk == A) | (Pk == D)).sum())) == 0, st
+        k, pr, ps = hj.join_and_materialize(cap=em)
+        assert hj.hot_stats()["mode"] == 2
+        assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
+        for a, b in zip(sorted_triples(k, pr, ps), sorted_triples(*o.join_materialize(Rk, Rp, Sk, Sp))):
+            assert np.array_equal(a, b)
+        lo, hi = (pr, ps) if skewed_rel == 1 else (ps, pr)
+        assert int(lo.max()) < (1 << 24) <= int(hi.min())      # payR / payS in their own columns
+        # the PK side changes under its binding: A twice now.  A's tuples are no longer bypassed and come back into slots sized
+        # without them: overflow -> the plain sampled path (planned from the data as it is now)
+        Bk2 = Bk.copy()
+        Bk2[150] = A
+        dev[1 - skewed_rel][0].copy_(torch.from_numpy(Bk2).cuda())
+        rels2 = {1 - skewed_rel: (Bk2, Bp), skewed_rel: (Pk, Pp)}
+        em2, eagg2, echk2 = o.join_count(rels2[0][0], rels2[0][1], rels2[1][0], rels2[1][1], checksum=True)
+        assert em2 > em
+        for i in range(2):
+            assert hj.join() == (em2, eagg2), i
+        k, pr, ps = hj.join_and_materialize(cap=em2)
+        assert len(k) == em2 and o.triples_checksum(k, pr, ps) == echk2
+
+
+def test_heavy_hitter_bypass_under_a_captured_step(P):
+    """hj_config.graph: the step with the bypass (memset, k_hot_build, the bypassing pass 1) replays from a hipGraph."""
+    import torch
+    nR, nS = 1 << 18, 3 << 20
+    R, S = _zipf_fk(P, nR, nS, 1.0, 4242)
+    Pr, Ps = np.arange(nR, dtype=np.int32), (np.arange(nS, dtype=np.int64) * 7 % 1000003).astype(np.int32)
+    em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+    dR, dPr, dS, dPs = (torch.from_numpy(x).cuda() for x in (R, Pr, S, Ps))
+    with P.HashJoin(0) as hj:
+        hj.configure(bits1=8, bits2=7, graph=1)
+        hj.bind_device(P.REL_R, dR, dPr)
+        hj.bind_device(P.REL_S, dS, dPs)
+        for i in range(5):
+            assert hj.join() == (em, eagg), i
+        assert hj.hot_stats()["mode"] == 1

@@ -40,6 +40,7 @@ def main():
         acc = {name: [] for name, _ in VARIANTS}
         for name, hj in ctxs:
             os.environ.update(envs[name])
+            hj.reload_knobs()                        # (the library reads its knobs once, in hj_create)
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, Sk, Sp)
             for _ in range(3):
@@ -47,6 +48,7 @@ def main():
         for r in range(rounds):
             for name, hj in ctxs:
                 os.environ.update(envs[name])
+                hj.reload_knobs()
                 hj.join()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

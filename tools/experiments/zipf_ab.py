@@ -53,12 +53,14 @@ def main():
             ("uniform FK sampled", "uniformFK", {}, {"HJ_FORCE_SAMPLED": "2"}),
         ]
     os.environ["HJ_REPLAN"] = "1"
+    hj.reload_knobs()
     acc = {v[0]: [] for v in variants}
     for r in range(rounds):
         for label, dname, cfg, env in variants:
             for kn in KNOBS:
                 os.environ.pop(kn, None)
             os.environ.update(env)
+            hj.reload_knobs()                        # (the library reads its knobs once, in hj_create)
             hj.configure(**cfg)
             hj.bind_device(pkg.REL_R, Rk, Rp)
             hj.bind_device(pkg.REL_S, data[dname], Sp)
