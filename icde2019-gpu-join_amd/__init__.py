@@ -4,6 +4,6 @@ include/hj.h); this package is the thin host-side mirror used by tests, bench.py
 driver.  The directory name is not a Python identifier: load it with `__graft_entry__.load_package()`."""
 from . import _lib, generator  # noqa: F401
 from .join import (ECAPACITY, EHIP, EINVAL, ENOMEM, HJError, HashJoin, PAYLOAD_GIVEN, PAYLOAD_ONES, PAYLOAD_ROWID, REL_R, REL_S,  # noqa: F401
-                   hashJoinClusteredProbe, host_split, host_split_blocks, shard_of)
+                   hashJoinClusteredProbe, host_join, host_split, host_split_blocks, shard_of)
 
 build = _lib.build

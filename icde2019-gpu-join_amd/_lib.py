@@ -80,6 +80,7 @@ SIGNATURES = {
     "hj_host_split_blocks": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p,
                                        C.POINTER(C.c_double)]),
     "hj_coprocess_groups": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
+    "hj_host_join": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, u64p, u64p, C.POINTER(C.c_double)]),
     "hj_ubench": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), u64p]),
     "hj_partition_layout": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "hj_join_count": (C.c_int, [vp, u64p, u64p]),

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -406,8 +407,10 @@ bool host_level0_split_blocks(const int32_t *K, const int32_t *Pv, uint64_t n, u
                 for (int c : *pin_cpus) CPU_SET(c, &set);
                 (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
             }
-            okv[t] = split_blocks_worker(K, Pv, n * t / threads, n * (t + 1) / threads, astart[t], astart[t + 1], parts, block, oK, oP, stream, &mine[t],
-                                         &prog.upto[(size_t)t * 8]) ? 1 : 0;
+            try {
+                okv[t] = split_blocks_worker(K, Pv, n * t / threads, n * (t + 1) / threads, astart[t], astart[t + 1], parts, block, oK, oP, stream, &mine[t],
+                                             &prog.upto[(size_t)t * 8]) ? 1 : 0;
+            } catch (const std::bad_alloc &) { okv[t] = 0; } // (a worker's own vectors: the split reports HJ_ENOMEM instead of terminating the process)
             finished.fetch_add(1, std::memory_order_release);
         };
         const bool own_share = !pin && !while_running; // the calling thread is worker 0
@@ -515,5 +518,120 @@ int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, u
 }
 
 uint32_t hj_shard_of(int32_t key, uint32_t nshards) { return host_shard_of(key, nshards); }
+
+// ---- a CPU radix join out of the library's own host code (a reported baseline, never a fallback): what these host cores do with the
+// scheme of the GPU path.  Level 1: both relations through the one-pass block split above (up to 4096 partitions by hj_shard_of, software
+// write-combining, streaming stores — partition-primitives.cu:40-125's idea).  Level 2, one partition pair per thread at a time: a counting
+// sort of both sides by further hash bits into pieces whose build side fits the L1 cache, then a bucket-chained table per piece, built
+// and probed like the reference's joinCpu (hash_join_clustered_probe.cu:2013-2059: head/next arrays, one pass over each side).  Payloads NULL = ones.
+// matches and aggregate as hj_join defines them; *seconds = wall time of the join proper (allocation of the staging columns is outside it,
+// as the device allocations are outside the GPU's timed region). ----
+int hj_host_join(const int32_t *keysR, const int32_t *paysR, uint64_t nR, const int32_t *keysS, const int32_t *paysS, uint64_t nS,
+                 uint32_t threads, uint64_t *matches, uint64_t *agg, double *seconds) {
+    if ((nR && !keysR) || (nS && !keysS)) return HJ_EINVAL;
+    if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (matches) *matches = 0;
+    if (agg) *agg = 0;
+    if (seconds) *seconds = 0;
+    if (nR == 0 || nS == 0) return HJ_OK;
+    const uint64_t nmin = std::min(nR, nS);
+    uint32_t parts = 1;
+    while (parts < 4096 && nmin / parts > ((uint64_t)1 << 17)) parts <<= 1; // ~2^17 build tuples per level-1 partition (1 MiB: the per-core L2)
+    struct Side { const int32_t *k, *p; uint64_t n; int32_t *ok = nullptr, *op = nullptr; std::vector<HostBlock> blocks; std::vector<uint64_t> psize; std::vector<size_t> first; };
+    Side sd[2] = {{keysR, paysR, nR}, {keysS, paysS, nS}};
+    int rc = HJ_OK;
+    for (Side &x : sd) {
+        const uint64_t cap = host_split_blocks_capacity(x.n, parts, threads);
+        x.ok = (int32_t *)aligned_alloc(64, ((size_t)cap * 4 + 63) & ~(size_t)63);
+        x.op = x.p ? (int32_t *)aligned_alloc(64, ((size_t)cap * 4 + 63) & ~(size_t)63) : nullptr;
+        if (!x.ok || (x.p && !x.op)) rc = HJ_ENOMEM;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (Side &x : sd) {
+        if (rc) break;
+        if (!host_level0_split_blocks(x.k, x.p, x.n, parts, threads, x.ok, x.op, x.blocks, x.psize)) { rc = HJ_ENOMEM; break; }
+        x.first.assign(parts + 1, x.blocks.size());
+        for (size_t i = x.blocks.size(); i-- > 0;) x.first[x.blocks[i].part] = i; // blocks come sorted by (partition, start)
+        for (uint32_t p = parts; p-- > 0;) if (x.first[p] == x.blocks.size() || x.blocks[x.first[p]].part != p) x.first[p] = x.first[p + 1];
+    }
+    std::atomic<uint32_t> next{0};
+    std::vector<uint64_t> tm(threads, 0), ta(threads, 0);
+    std::vector<char> okv(threads, 1);
+    auto work = [&](uint32_t t) {
+        try {
+            std::vector<int32_t> bk, bp, qk, qp;       // the partition pair, sorted by piece
+            std::vector<uint32_t> hb, hq, head, nxt;
+            uint64_t m = 0, a = 0;
+            for (uint32_t p = next.fetch_add(1); p < parts; p = next.fetch_add(1)) {
+                const uint64_t nb = sd[0].psize[p], nq = sd[1].psize[p];
+                if (!nb || !nq) continue;
+                const bool r_builds = nb <= nq; // the smaller side of the pair builds
+                const Side &B = sd[r_builds ? 0 : 1], &Q = sd[r_builds ? 1 : 0];
+                const uint64_t cb = r_builds ? nb : nq, cq = r_builds ? nq : nb;
+                uint32_t pieces = 1, lg = 0;
+                while (pieces < 4096 && cb / pieces > 1024) { pieces <<= 1; lg++; } // ~1024 build tuples per piece: table + tuples in the L1
+                auto piece_of = [&](int32_t key) { uint32_t h = (uint32_t)key * 0x9E3779B1u; return (h >> 7) & (pieces - 1); }; // (bits hj_shard_of's murmur does not share)
+                auto sort_side = [&](const Side &X, uint64_t cnt, std::vector<int32_t> &ok2, std::vector<int32_t> &op2, std::vector<uint32_t> &hist) {
+                    hist.assign(pieces + 1, 0);
+                    ok2.resize(cnt); if (X.p) op2.resize(cnt);
+                    for (size_t i = X.first[p]; i < X.first[p + 1]; i++) {
+                        const HostBlock &hbk = X.blocks[i];
+                        for (uint64_t j = 0; j < hbk.count; j++) hist[piece_of(X.ok[hbk.start + j]) + 1]++;
+                    }
+                    for (uint32_t q = 0; q < pieces; q++) hist[q + 1] += hist[q];
+                    std::vector<uint32_t> cur(hist.begin(), hist.end() - 1);
+                    for (size_t i = X.first[p]; i < X.first[p + 1]; i++) {
+                        const HostBlock &hbk = X.blocks[i];
+                        for (uint64_t j = 0; j < hbk.count; j++) {
+                            const int32_t key = X.ok[hbk.start + j];
+                            const uint32_t o = cur[piece_of(key)]++;
+                            ok2[o] = key;
+                            if (X.p) op2[o] = X.op[hbk.start + j];
+                        }
+                    }
+                };
+                sort_side(B, cb, bk, bp, hb);
+                sort_side(Q, cq, qk, qp, hq);
+                for (uint32_t q = 0; q < pieces; q++) {
+                    const uint32_t b0 = hb[q], b1 = hb[q + 1], q0 = hq[q], q1 = hq[q + 1];
+                    if (b0 == b1 || q0 == q1) continue;
+                    uint32_t nh = 256;
+                    while (nh < (b1 - b0)) nh <<= 1;
+                    head.assign(nh, 0xFFFFFFFFu);
+                    nxt.resize(b1 - b0);
+                    for (uint32_t i = b0; i < b1; i++) {
+                        const uint32_t h = (((uint32_t)bk[i] * 0x9E3779B1u) >> (7 + lg)) & (nh - 1);
+                        nxt[i - b0] = head[h]; head[h] = i - b0;
+                    }
+                    for (uint32_t i = q0; i < q1; i++) {
+                        const int32_t key = qk[i];
+                        const int64_t pq = Q.p ? qp[i] : 1;
+                        for (uint32_t e = head[(((uint32_t)key * 0x9E3779B1u) >> (7 + lg)) & (nh - 1)]; e != 0xFFFFFFFFu; e = nxt[e])
+                            if (bk[b0 + e] == key) { m++; a += (uint64_t)((int64_t)(B.p ? bp[b0 + e] : 1) * pq); }
+                    }
+                }
+            }
+            tm[t] = m; ta[t] = a;
+        } catch (const std::bad_alloc &) { okv[t] = 0; }
+    };
+    if (!rc) {
+        std::vector<std::thread> th;
+        try {
+            for (uint32_t t = 1; t < threads; t++) th.emplace_back(work, t);
+        } catch (const std::system_error &) { rc = HJ_ENOMEM; next.store(parts); }
+        work(0);
+        for (auto &x : th) x.join();
+        for (char c : okv) if (!c) rc = HJ_ENOMEM;
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (Side &x : sd) { free(x.ok); free(x.op); }
+    if (rc) return rc;
+    uint64_t m = 0, a = 0;
+    for (uint32_t t = 0; t < threads; t++) { m += tm[t]; a += ta[t]; }
+    if (matches) *matches = m;
+    if (agg) *agg = a;
+    if (seconds) *seconds = dt;
+    return HJ_OK;
+}
 
 } // extern "C"

@@ -378,6 +378,22 @@ class HashJoin:
 _UBENCH_KINDS = {"copy": 0, "line_scatter": 1, "read": 2, "write": 3, "copy1": 4, "pairs": 5, "pairs_scatter": 6, "soa_to_pairs_scatter": 7}
 
 
+def host_join(R, Pr, S, Ps, threads=0):
+    """The library's own CPU radix join (a reported baseline; no GPU): (matches, agg, seconds)."""
+    R, rp = _host_i32(R)
+    S, sp = _host_i32(S)
+    prp = psp = None
+    if Pr is not None:
+        Pr, prp = _host_i32(Pr)
+    if Ps is not None:
+        Ps, psp = _host_i32(Ps)
+    m, a, dt = C.c_uint64(), C.c_uint64(), C.c_double()
+    rc = _lib.lib().hj_host_join(rp, prp, len(R), sp, psp, len(S), threads, C.byref(m), C.byref(a), C.byref(dt))
+    if rc:
+        raise HJError(rc, "hj_host_join")
+    return m.value, a.value, dt.value
+
+
 def host_split(keys, pays, parts, threads=0):
     """The host level-0 split on its own (no GPU): (out_keys, out_pays, offsets[parts+1], GB/s)."""
     keys, kp = _host_i32(keys)

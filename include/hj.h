@@ -199,6 +199,13 @@ uint64_t hj_host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t thre
 int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
                          int32_t *out_keys, int32_t *out_pays, uint64_t cap, uint32_t *block_part, uint64_t *block_start,
                          uint32_t *block_count, uint64_t max_blocks, uint64_t *n_blocks, double *gbs);
+/* A CPU radix join out of the library's own host code — a REPORTED BASELINE (bench.py `cpu_baseline.best_effort`, bench --cpu-baseline),
+ * never a fallback of the GPU path: both relations through hj_host_split_blocks' one-pass split (up to 4096 partitions), then one
+ * partition pair per thread at a time: a counting sort into cache-sized pieces and a bucket-chained table per piece, built and probed
+ * like the reference's joinCpu (hash_join_clustered_probe.cu:2013-2059).  Payload columns may be NULL (= ones); matches / agg as hj_join
+ * defines them; *seconds = wall time without the allocation of the staging columns.  No GPU involved. */
+int hj_host_join(const int32_t *keysR, const int32_t *paysR, uint64_t nR, const int32_t *keysS, const int32_t *paysS, uint64_t nS,
+                 uint32_t threads, uint64_t *matches, uint64_t *agg, double *seconds);
 /* NUMA placement of the last hj_join_coprocess call (partition-primitives.cu:129-253 keeps partitions and threads per
  * socket): NUMA nodes of the host, the node closest to the context's GPU (-1 unknown: pinned staging is allocated there by
  * hipHostMalloc), and how many of that node's CPUs the split's workers were bound to (0: not bound — one node, HJ_NUMA=0). */

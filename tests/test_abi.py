@@ -129,6 +129,31 @@ def test_host_write_combining_split_parity():
         assert np.array_equal(off2, off) and np.all(op2 == 1) and np.array_equal(np.sort(ok2), np.sort(keys))
 
 
+def test_host_radix_join_parity():
+    """hj_host_join (bench.py's `cpu_baseline.best_effort`: the library's own host code as a CPU radix join — one-pass block split, then
+    cache-sized chained tables, hash_join_clustered_probe.cu:2013-2059's build/probe per piece) against the oracle: match count and
+    aggregate with signed payloads, duplicates on both sides, keys one side lacks, empty sides, payload = ones.  Pure host code."""
+    import numpy as np
+    from oracle import pyoracle as o
+    p = pkg()
+    rng = np.random.default_rng(23)
+    for nR, nS, dup, threads in ((0, 10, False, 2), (7, 0, False, 1), (5, 3, True, 3), (1000, 4000, True, 4), (100_003, 400_001, False, 8),
+                                 (1 << 19, 1 << 20, True, 5)):
+        R = (rng.integers(-2**31, 2**31 - 1, nR) if dup else rng.permutation(max(nR, 1))[:nR]).astype(np.int32)
+        if dup and nR >= 3:
+            R[: nR // 3] = R[nR // 3: 2 * (nR // 3)][: nR // 3]
+        S = (R[rng.integers(0, nR, nS)] if nR else rng.integers(0, 9, nS)).astype(np.int32)
+        S[::7] = -5                                              # a heavy key R (almost surely) lacks
+        Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+        Ps = rng.integers(-2**31, 2**31 - 1, nS).astype(np.int32)
+        em, eagg, _ = o.join_count(R, Pr, S, Ps, checksum=False)
+        m, a, dt = p.host_join(R, Pr, S, Ps, threads)
+        assert (m, a) == (em, eagg), (nR, nS, threads)
+        em1, eagg1, _ = o.join_count(R, None, S, None, checksum=False)
+        assert p.host_join(R, None, S, None, threads)[:2] == (em1, eagg1)
+        assert p.host_join(S, Ps, R, Pr, threads)[:2] == (em, eagg)   # the larger side first: the smaller side of a pair builds
+
+
 def test_host_one_pass_block_split_parity():
     """hj_host_split_blocks (what hj_join_coprocess runs: one pass, partitions as lists of blocks taken from per-worker arenas — the
     reference's bucket chains, join-primitives.cu:138-192, on the host) against numpy: every block holds tuples of its partition only,

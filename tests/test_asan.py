@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # what the sanitizer leg runs: every CPU test that enters gen_ethz.cpp, hj_host.cpp, bench_main.cpp or oracle/*.c
 LEG = ["tests/test_generator.py", "tests/test_oracle_gen.py", "tests/test_oracle_join.py",
-       "tests/test_abi.py::test_host_write_combining_split_parity", "tests/test_abi.py::test_host_one_pass_block_split_parity"]
+       "tests/test_abi.py::test_host_write_combining_split_parity", "tests/test_abi.py::test_host_one_pass_block_split_parity",
+       "tests/test_abi.py::test_host_radix_join_parity"]
 
 
 def asan_env():
