@@ -415,7 +415,10 @@ PROBE_TARGET_FRAC = 0.70
 # Round 5 (profiles/r5_launch_structure_ab.txt): below 2^30 the target is the 2^30 target diluted by a FIXED cost of 60 us per launch —
 # the ramp-up and tail of a short kernel, measured as k_join_count 0.429 ms at 2^27 against 2.78 / 8 = 0.348 ms; removing launches from
 # the step (14 -> 6) did not move it.  At 2^27: 0.70 x 0.3835 / (0.3835 + 0.060) = 0.605.
-PROBE_FIXED_COST_MS = 0.060
+# Round 6 (profiles/r6_fixed_cost_2p27.txt): per-workgroup timelines put the fixed cost at 20-25 us per launch (first wave 7-10 us slower than a
+# steady workgroup, 4-11 us of tail, ~8 us between the start event and the first workgroup's work); the rest of round 5's 60 us was the
+# steady rate of the full-key tables below 16 radix bits, which the tag kernels now replace.  At 2^27: 0.70 x 0.3835 / (0.3835 + 0.025) = 0.657.
+PROBE_FIXED_COST_MS = 0.025
 
 
 def probe_target_frac(log2n):

@@ -89,6 +89,7 @@ SIGNATURES = {
     "hj_join_and_materialize": (C.c_int, [vp, vp, vp, vp, C.c_uint64, u64p]),
     "hj_hot_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double), u64p]),
     "hj_reload_knobs": (C.c_int, [vp]),
+    "hj_debug_set_stamps": (C.c_int, [vp, vp, vp]),
     "hj_join_late_materialize": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, vp, C.c_uint32, C.c_uint64, u64p, u64p]),
     "hj_join_nonpartitioned": (C.c_int, [vp, C.c_int, u64p, u64p]),
     "hj_join_stream_probe": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p]),

@@ -189,7 +189,8 @@ void choose_bits(hj_ctx *c) {
     // fewer than 16 radix bits: the LDS table stores full 4-byte keys (no 16-bit tags), 10 instead of 8 bytes per build
     // tuple.  With the default shape that is 62 KiB = 2 workgroups per CU; 4352 tuples + 2048 heads is 51.5 KiB = 3 per CU
     // (measured at 2^26-2^27: k_join_count 0.476 -> 0.439 ms, -8 %).
-    if (c->bits1 + c->bits2 < 16 && !g.lds_capacity && !g.lds_heads) {
+    // (round 6: 16-bit tags are exact whenever bits + log2(heads) >= 16 — plan_join — so this shape is left for the few-heads tables only)
+    if ((c->tags_legacy ? c->bits1 + c->bits2 : c->bits1 + c->bits2 + ceil_log2(c->nh)) < 16 && !g.lds_capacity && !g.lds_heads) {
         c->cap = 4352;
         if (c->nh > 2048) c->nh = 2048;
     }
@@ -751,6 +752,7 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
             fb.shift = 0; fb.P = P2; fb.cap = f.cap2;
             fb.out_keys = (int32_t *)R.b_k.p; fb.out_pays = (int32_t *)R.b_p.p;
             fb.obeg = beg; fb.oend = end; fb.ovf = ovf;
+            fb.stamps = c->stamps_part2;
             if (defer) { defer->fa = fa; defer->fb = fb; defer->used = true; } // the caller launches (merged with the other relation's)
             else {
                 { Timed t(c, "k_part1_fast"); HIPCHK(c, launch_part1_fast(st, fa)); }
@@ -847,7 +849,10 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     // The tag shortcut of jp.cu:1029 is exact with >= 16 radix bits (D2): what is left of a key fits the 16 stored bits.  Below that
     // the table stores full keys.  (Round 3 also built 16-bit tags at 14 / 15 radix bits, the extra key bits folded into the bucket
     // index: parity-green, measured no faster than full keys, removed — profiles/r3_tag_extra_ab.txt.)
-    tag16 = rbits >= 16 && c->nh >= 16;
+    // Round 6: exact whenever rbits + log2(heads) >= 16 — the key bits [rbits, 16) the tag drops are part of the bucket index, and the tag
+    // (key >> max(rbits, 16)) is only ever compared inside one bucket's chain.  Config 2 (2^27, 15 radix bits) and everything smaller now
+    // run the 8-byte-per-hop tag kernels; full keys are left for tables of very few heads.
+    tag16 = c->nh >= 16 && (c->tags_legacy ? rbits : rbits + ceil_log2(c->nh)) >= 16;
     const uint64_t held_b = B.n_bound ? B.n_bound : B.n, held_p = Pb.n_bound ? Pb.n_bound : Pb.n; // (multi-GPU: what this rank can hold, not the nominal size)
     const uint64_t max_items64 = (uint64_t)Pb.nranges + held_p / c->chunk + 1 + (general ? (uint64_t)B.nranges + held_b / c->chunk + 1 : 0); // flipped partitions are cut on the build relation
     if (max_items64 > 0x7FFFFFFFull) return fail(c, HJ_EINVAL, "too many work items");
@@ -880,6 +885,7 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
     a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    a.stamps = c->stamps_join;
     uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
     const bool atomic_plan = c->plan_atomic;
     if (nparts <= 1024 && !Pb.sampled && !general) { // one workgroup's worth of partitions: plan + scan + expand in one single-workgroup launch
@@ -1054,6 +1060,7 @@ static void read_knobs(hj_ctx *c) {
     if (const char *vg = getenv("HJ_VAR_GUIDE")) c->var_guide = atof(vg);
     if (const char *fs = getenv("HJ_FORCE_SAMPLED")) c->force_sampled = atoi(fs); // bit 0: R, bit 1: S; bits 2, 3: forget what was learned
     c->replan = getenv("HJ_REPLAN") != nullptr;
+    if (const char *tl = getenv("HJ_TAGS_LEGACY")) c->tags_legacy = atoi(tl) != 0;
     if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
     if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
     c->debug = getenv("HJ_DEBUG") != nullptr;
@@ -1505,6 +1512,16 @@ int hj_join_and_materialize(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t 
     RET(rc);
     if (n_out) *n_out = n;
     if (n > cap) return fail(c, HJ_ECAPACITY, "join produced %llu tuples, capacity %llu", (unsigned long long)n, (unsigned long long)cap);
+    return HJ_OK;
+}
+
+/* experiments only: device buffers (4 x uint64 per work item of the join / per parent of pass 2) that a library built with -DHJ_STAMPS
+ * (`make stamps`) fills with per-workgroup start / end times and hardware ids; the shipped build ignores them. */
+int hj_debug_set_stamps(hj_ctx *c, void *d_join, void *d_part2) {
+    if (!c) return HJ_EINVAL;
+    c->stamps_join = (unsigned long long *)d_join; c->stamps_part2 = (unsigned long long *)d_part2;
+    c->join_planned = false;
+    drop_graph(c);
     return HJ_OK;
 }
 

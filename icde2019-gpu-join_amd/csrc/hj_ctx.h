@@ -118,6 +118,8 @@ struct hj_ctx {
     int hot_request = 0;
     int32_t *hot_out[3] = {nullptr, nullptr, nullptr}; // key, payR, payS
     uint64_t hot_cap = 0;
+    unsigned long long *stamps_join = nullptr, *stamps_part2 = nullptr; // hj_debug_set_stamps: experiment builds (-DHJ_STAMPS) write per-workgroup timelines there
+    bool tags_legacy = false;       // HJ_TAGS_LEGACY=1 (A/B): 16-bit tags only at >= 16 radix bits, as until round 5
     bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
     bool debug = false;             // HJ_DEBUG: stderr diagnostics
     int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)

@@ -39,6 +39,16 @@ __device__ __forceinline__ uint64_t mix_triple(int32_t key, int32_t pr, int32_t 
     return fmix64(mix_pair(key, pr) ^ ((uint64_t)(uint32_t)ps * 0x9E3779B97F4A7C15ULL));
 }
 
+#ifdef HJ_STAMPS
+// experiment builds (`make stamps`, tools/experiments/fixed_cost.py): where and when a workgroup ran.  s_memrealtime counts at 100 MHz;
+// HW_ID (register 4): wave, SIMD, CU, SH, SE; XCC_ID (register 20): the XCD.
+__device__ __forceinline__ unsigned long long hj_now() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ unsigned long long hj_where() {
+    const uint32_t hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4), xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20);
+    return ((unsigned long long)xcc << 32) | hw;
+}
+#endif
+
 // Partition function.  MODE 0: the reference's (hasht(key) >> first_bit) & (parts-1) with hasht =
 // identity (common.h:45-47, jp.cu:126).  MODE 1: shard id for the multi-GPU level-0 split, a
 // multiplicative range reduction of a murmur-finalised key (independent of the low radix bits).

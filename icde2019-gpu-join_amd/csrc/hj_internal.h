@@ -62,6 +62,7 @@ struct FastArgs {
     uint32_t mode;               // pass 1: 0 = radix digit, 1 = multi-GPU shard of the key (hash; P = number of GPUs)
     uint32_t seg_pass1, span0;   // launch_part2_fast as a pass 1 over received segments: workgroup b is span span0 + b of nspans
     uint64_t *zero_items;        // pass 2, optional: the join's item counter, zeroed by workgroup 0 (k_join_plan_atomic reserves on it)
+    unsigned long long *stamps;  // experiment builds only (-DHJ_STAMPS, `make stamps`): per workgroup {start, end, hw id, -} in 100-MHz ticks
 };
 
 // one work item of the join: build partition [b0, b0+nb), probe chunk [q0, q1) of partition p
@@ -103,6 +104,7 @@ struct JoinArgs {
     const int32_t *Db, *Dp;  // build side / probe side tables
     uint32_t ncb, ncp;       // columns to gather
     uint64_t sb, sp;         // column stride (elements)
+    unsigned long long *stamps; // experiment builds only (-DHJ_STAMPS): per item {start, table built, end, hw id} in 100-MHz ticks
 };
 
 hipError_t launch_set_root(hipStream_t st, uint64_t *poff, uint64_t n, uint32_t *flag = nullptr);

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     const uint32_t tid = threadIdx.x, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // scalar: the probe stream state stays in SGPRs
     const JoinItem it = a.items[item];
     const uint32_t nr = item_nranges(it); // probe ranges of the item (list items: several whole ranges share one table build)
-    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    const uint32_t bits = a.radix_bits, nhm = a.nh - 1, tsh = a.radix_bits > 16u ? a.radix_bits : 16u; // tag = key >> tsh: see plan_join
     // the two sides of the item (wave-uniform; without GEN: the build relation is the table, the probe relation the stream)
     const bool swap = GEN && (it.p & JOIN_ITEM_SWAP), blist = GEN && (it.p & JOIN_ITEM_BLIST);
     const int32_t *const tk = swap ? a.pk : a.bk, *const tp = swap ? a.pp : a.bp, *const sk = swap ? a.bk : a.pk, *const sp = swap ? a.bp : a.pp;
@@ -336,8 +336,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
     };
     table_range(0);
     if (GEN) while (tb == te && tr + 1 < ntr) table_range(++tr);
-    // TAG16 only at >= 16 radix bits: what is left of a key then fits the 16 stored bits and the comparison is exact (the
-    // reference's tag shortcut, jp.cu:1029, is taken at any bit count, D2); below that the table stores full keys
+    // TAG16: the entry stores key >> max(bits, 16) — 16 bits.  The key bits below that which are not radix bits, [bits, 16), are part of
+    // the bucket index (key >> bits) & (nh - 1), so two keys of one chain that agree in the tag are equal: exact whenever
+    // bits + log2(nh) >= 16 (round 6; until then: only at >= 16 radix bits).  The reference takes its tag shortcut, jp.cu:1029, at any
+    // bit count (D2).  Otherwise the table stores full keys
     auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; };
 
     uint64_t my_matches = 0, my_agg = 0;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                             if (idx >= gb && idx < gb + nbc) {
                                 const uint32_t slot = filled + (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
                                 const uint32_t old = atomicExch(&head[hidx(key)], slot);
-                                if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                                if (TAG16) ent[slot] = make_uint2(((key >> tsh) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
                                 else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
                             }
                         }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                         if (pos != 0xFFFFu) {
                             const uint32_t key = (uint32_t)elem(kv, e);
                             const uint2 en = ent[pos];
-                            const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
+                            const bool eq = TAG16 ? ((en.x >> 16) == (key >> tsh)) : (en.x == key);
                             if (eq) {
                                 my_matches++;
                                 my_agg += (uint64_t)((int64_t)(int32_t)en.y * (int64_t)elem(pv, e));
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
                 pos &= 0xFFFFu; // chain links are 16 bit; 0xFFFF = end
                 while (pos != 0xFFFFu) {
                     const uint2 en = ent[pos];
-                    const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
+                    const bool eq = TAG16 ? ((en.x >> 16) == (key >> tsh)) : (en.x == key);
                     if (eq) {
                         my_matches++;
                         if (JM == 2) {
@@ -487,6 +489,14 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_join(JoinArgs a) {
         a.wave_counts[(uint64_t)item * JOIN_WAVES + wave] = my_matches;
         a.wave_agg[(uint64_t)item * JOIN_WAVES + wave] = my_agg;
     }
+#ifdef HJ_STAMPS
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned long long *s = a.stamps + (size_t)item * 4;
+        // END stamps only: a clock read at the start of this kernel — kept in a register, parked in LDS or stored at once — takes it from 72 to
+        // 94 VGPRs, i.e. from three workgroups per CU to two (measured: 2.83 -> 3.55 ms at 2^30); the timeline is rebuilt from the ends per CU
+        s[0] = 0; s[1] = 0; s[2] = hj_now(); s[3] = hj_where();
+    }
+#endif
 }
 
 // ---- materialisation in ONE probe, matches held in REGISTERS ----
@@ -528,7 +538,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
     constexpr uint32_t SUB = GEN ? 2 * JOIN_THREADS * 4 : MR_SUB;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, ln = lane_id();
     const uint32_t nr = (LISTS || GEN) ? item_nranges(it) : 1u;
-    const uint32_t bits = a.radix_bits, nhm = a.nh - 1;
+    const uint32_t bits = a.radix_bits, nhm = a.nh - 1, tsh = a.radix_bits > 16u ? a.radix_bits : 16u; // tag = key >> tsh: see plan_join
     auto hidx = [&](uint32_t key) -> uint32_t { return (key >> bits) & nhm; }; // see k_join
     const uint64_t lt_mask = ((uint64_t)1 << ln) - 1;
     constexpr uint32_t END = 0xFFFFu;
@@ -611,7 +621,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                                     if (idx >= gb && idx < gb + nbc) {
                                         const uint32_t slot = (GEN ? filled : 0u) + (uint32_t)(idx - gb), key = (uint32_t)elem(bkv[r], e);
                                         const uint32_t old = atomicExch(&head[hidx(key)], slot);
-                                        if (TAG16) ent[slot] = make_uint2(((key >> bits) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
+                                        if (TAG16) ent[slot] = make_uint2(((key >> tsh) << 16) | (old & 0xFFFFu), (uint32_t)elem(bpv[r], e));
                                         else { ent[slot] = make_uint2(key, (uint32_t)elem(bpv[r], e)); lnext[slot] = (uint16_t)old; }
                                     }
                                 }
@@ -675,7 +685,7 @@ __device__ __forceinline__ void join_mat_reg_item(const JoinArgs &a, const JoinI
                             if (s_ != END && !((mm >> j) & 1u)) {
                                 const uint32_t key = (uint32_t)elem(kk[t], e);
                                 const uint2 en = ent[s_];
-                                const bool eq = TAG16 ? ((en.x >> 16) == ((key >> bits) & 0xFFFFu)) : (en.x == key);
+                                const bool eq = TAG16 ? ((en.x >> 16) == (key >> tsh)) : (en.x == key);
                                 if (eq) mm |= 1u << j;
                                 else {
                                     const uint32_t nx = TAG16 ? (en.x & 0xFFFFu) : (uint32_t)lnext[s_];

@@ -972,6 +972,9 @@ __device__ __forceinline__ void part2_fast_body(const FastArgs &a, const uint32_
     // (the join's planning kernel reserves item slots on a counter: zeroed here, by the kernel that always runs just before it)
     if (a.zero_items && parent == 0 && threadIdx.x == 0) *a.zero_items = 0;
     if (*a.ovf) return; // pass 1 gave up: the exact passes take over
+#ifdef HJ_STAMPS
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 4] = hj_now();
+#endif
     WfLds L_;
     wf_carve(L_, smem);
     const uint32_t tid = threadIdx.x;
@@ -998,6 +1001,12 @@ __device__ __forceinline__ void part2_fast_body(const FastArgs &a, const uint32_
     __syncthreads();
     if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
     else wc_fast<U, 0, 1>(L_, a.keys, a.pays, 0, 0, 0, a.spp, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf);
+#ifdef HJ_STAMPS
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned long long *s = a.stamps + (size_t)blockIdx.x * 4;
+        s[1] = 0; s[2] = hj_now(); s[3] = hj_where();
+    }
+#endif
 }
 template <int U>
 __global__ __launch_bounds__(WC_THREADS) void k_part2_fast(FastArgs a) {

@@ -248,6 +248,10 @@ class HashJoin:
         self._ck(self._L.hj_hot_stats(self._h, C.byref(m), C.byref(k), C.byref(s), C.byref(x)))
         return {"mode": m.value, "keys": k.value, "share": s.value, "matches": x.value}
 
+    def debug_set_stamps(self, d_join, d_part2):
+        """Experiments (libhj_stamps.so): device buffers for per-workgroup timelines of the count kernel / pass 2."""
+        self._ck(self._L.hj_debug_set_stamps(self._h, _dev_ptr(d_join), _dev_ptr(d_part2)))
+
     def reload_knobs(self):
         """Experiments: re-read the HJ_* environment knobs (the library reads them once, in hj_create)."""
         self._ck(self._L.hj_reload_knobs(self._h))

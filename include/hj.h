@@ -243,6 +243,11 @@ int hj_last_call_breakdown(const hj_ctx *ctx, double *alloc_ms, uint32_t *alloca
 /* experiments only: read the environment knobs again.  The library reads them ONCE, in hj_create; no entry point of the
  * path calls getenv.  tools/experiments/ switch a knob between two calls of one context with this. */
 int hj_reload_knobs(hj_ctx *ctx);
+/* experiments only: per-workgroup timelines.  A library built with -DHJ_STAMPS (`make -C csrc stamps` -> libhj_stamps.so) writes
+ * {start, table built, end, hardware id} (s_memrealtime ticks of 10 ns; HW_ID | XCC_ID << 32) per work item of the count kernel into
+ * d_join and {start, 0, end, hardware id} per parent of pass 2 into d_part2 (4 x uint64 each; NULL = off).  The shipped build ignores
+ * the pointers.  tools/experiments/fixed_cost.py */
+int hj_debug_set_stamps(hj_ctx *ctx, void *d_join_stamps, void *d_part2_stamps);
 int hj_enable_timings(hj_ctx *ctx, int level); /* 0 off, 1 data-moving kernels, 2 every launch.  [sync] */
 int hj_timings_reset(hj_ctx *ctx);
 /* [sync] fills up to cap entries, returns the number of kernels known in *n. */
