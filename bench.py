@@ -15,6 +15,7 @@ import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -189,7 +190,7 @@ def bench_zipf(a, pkg, torch, dev, local):
     achieved = 16.0 * tuples / (avg_ms * 1e-3) / 1e9
     traffic = None
     try:
-        pmf = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_zipf.json")))
+        pmf = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_zipf.json")))
         key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom + "<")]
         if key and pmf.get("lib_sha256") == lib_sha256():
             traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
@@ -491,7 +492,7 @@ def join_cpu_baseline(hj, torch, dev, threads, log2n=22):
     m, _ = o.joinCpu(R, S, threads=threads)
     dt = time.perf_counter() - t0
     assert m == n, (m, n)
-    return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port", "best_effort": dict(best),
+    return {"value": round(2 * n / dt / 1e9, 4), "unit": "billion tuples/s", "cores": threads, "kind": "port",
             "sample": "2^%d x 2^%d unique uniform int32, oracle o_joinCpu (restatement of the reference's joinCpu, "
                       "hash_join_clustered_probe.cu:2013-2059: 2^20-slot chained table, serial build, %d-thread probe), %.2f s"
                       % (log2n, log2n, threads, dt)}
@@ -632,6 +633,465 @@ def alt_transport_leg(a, pkg, torch, world, n, domain, expect):
     return out
 
 
+# main() is a sequence of legs over one namespace B (round 6: one function per leg, no behaviour change).  A leg takes what it reads
+# from B into locals and keeps what later legs read (a name a leg did not assign — e.g. the N > 1 fields at N = 1 — is left alone).
+def _take(B, *names):
+    return [getattr(B, x, None) for x in names]
+
+
+def _keep(B, loc, *names):
+    for x in names:
+        if x in loc:
+            setattr(B, x, loc[x])
+
+
+def leg_inputs_and_driver(B):
+    """the context, the synthetic inputs of this rank and (N > 1) the multi-GPU driver; step() = one pass of the hot path, barrier()"""
+    a, backend, cdev, dev, dist, domain, local, n, pkg, rank = _take(B, "a", "backend", "cdev", "dev", "dist", "domain", "local", "n", "pkg", "rank")
+    torch, total_n, use_dist, world = _take(B, "torch", "total_n", "use_dist", "world")
+    if use_dist:
+        # a stream of our own for N>1: the all-to-alls run asynchronously next to local kernels, and HIP's
+        # legacy default stream would add implicit synchronisation with other blocking streams
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
+    if a.bits or a.probe_chunk or a.lds or a.exact_only:
+        hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
+                     lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0, exact_only=a.exact_only)
+    # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
+    # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
+    domain = min(total_n, 1 << 32)
+    Rk = torch.empty(n, dtype=torch.int32, device=dev)
+    Sk = torch.empty(n, dtype=torch.int32, device=dev)
+    Rp = torch.empty(n, dtype=torch.int32, device=dev)
+    Sp = torch.empty(n, dtype=torch.int32, device=dev)
+    hj.gen_unique(Rk, n, rank * n, domain, 1)
+    hj.gen_unique(Sk, n, rank * n, domain, 2)
+    hj.fill_payload(Rp, n, "ones")
+    hj.fill_payload(Sp, n, "ones")
+    hj.sync()
+    dup = max(1, total_n // domain)
+    expect = total_n * dup  # every key occurs dup times in R and in S
+
+    dj = None
+    c_impl = False
+    if use_dist:
+        from importlib import import_module
+        dmod = import_module(pkg.__name__ + ".dist")
+        c_impl = a.dist_impl == "c" and backend != "gloo" and a.balance == "hash"
+        dist_fallback = None
+        if c_impl:
+            # the exchange behind the C ABI: C++ host code over RCCL (ncclCommInitRank with an id broadcast over the control plane).
+            # If the communicator cannot be made (every rank agrees on that through an all-reduce), the torch.distributed driver of
+            # rounds 1-2 takes over and the line says so.
+            try:
+                dj = dmod.RankJoin(hj, rank, world)
+                dj.configure(slices=a.slices, exact_only=a.exact_only, phantom_world=a.phantom if world == 1 else 0, single_group=a.single_group)
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                ok, dist_fallback = 0, repr(e)
+            t_ok = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if int(t_ok.item()) == 0:
+                c_impl, dj = False, None
+                dist_fallback = dist_fallback or "another rank could not create its hj_dist_rank"
+        if not c_impl:
+            dj = dmod.ShardedJoin(hj, pkg, dev, balance=a.balance)
+            dj.force_exchange = a.force_dist
+
+    def step(verify=False):
+        if not use_dist:
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            return hj.join()[0]
+        # verify: the digest of everything sent must equal the digest of everything received (dist.ShardedJoin.join)
+        return dj.join(Rk, Rp, Sk, Sp, verify=verify)[0]
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    _keep(B, locals(), "Rk", "Rp", "Sk", "Sp", "barrier", "c_impl", "dist_fallback", "dj", "dup", "expect", "hj", "step")
+
+
+def leg_timed_headline(B):
+    """W warm-up steps (each checks the exchange), then EXACTLY K timed steps between barriers: value / ms_per_step"""
+    a, barrier, cdev, dist, expect, hj, step, torch, total_n, world = _take(B, "a", "barrier", "cdev", "dist", "expect", "hj", "step", "torch", "total_n", "world")
+    for _ in range(a.warmup):
+        got = step(verify=True)   # every warm-up step checks the exchange
+        assert got == expect, (got, expect)
+    hj.timings_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert got == expect, (got, expect)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = 2.0 * total_n * a.steps / dt / 1e9
+    _keep(B, locals(), "got", "ms_per_step", "value")
+
+
+def leg_instrumented_steps(B):
+    """further steps with HIP events around the data-moving kernels, outside the timed region: kernels / roofline / probe_phase come from them"""
+    a, barrier, expect, hj, pkg, step = _take(B, "a", "barrier", "expect", "hj", "pkg", "step")
+    # The headline loop above ran with the library's default: no HIP events around the kernels.  The per-kernel figures
+    # (roofline, probe phase, kernels) come from extra, instrumented steps of the same workload, outside the timed region.
+    hj.enable_timings(1)
+    hj.timings_reset()
+    isteps = max(1, min(a.steps, 5))
+    for _ in range(isteps):
+        assert step() == expect
+    barrier()
+    kt = hj.timings()
+    hj.enable_timings(0)
+    layout = [hj.partition_layout(pkg.REL_R), hj.partition_layout(pkg.REL_S)]
+    hj_cfg_bits = [hj.config()["bits1"], hj.config()["bits2"]]
+    _keep(B, locals(), "hj_cfg_bits", "isteps", "kt", "layout")
+
+
+def leg_dist_info(B):
+    """N > 1: who received what, the driver that ran, the timeline model of the sliced exchange"""
+    a, c_impl, cdev, dist, dist_fallback, dj, n, torch, use_dist, world = _take(B, "a", "c_impl", "cdev", "dist", "dist_fallback", "dj", "n", "torch", "use_dist", "world")
+    dist_info = None
+    if use_dist:
+        recv = torch.tensor(list(dj.last_received), dtype=torch.int64, device=cdev)
+        allrecv = [torch.empty_like(recv) for _ in range(world)]
+        dist.all_gather(allrecv, recv)
+        dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "driver": "hj_dist (C++ over RCCL, include/hj_dist.h)" if c_impl else "dist.py (torch.distributed)",
+                     "driver_fallback_reason": dist_fallback,
+                     "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
+        dist_info["transport"] = "rccl (grouped ncclSend/ncclRecv per slice, hj_dist)" if c_impl else "torch.distributed all_to_all_single (%s)" % dist.get_backend()
+        if c_impl:
+            st = dj.stats()
+            G = a.phantom if (world == 1 and a.phantom > 1) else world
+            dist_info["rank0"] = st
+            if st["path"] == "sliced" and G > 1:
+                # Timeline model (DESIGN.md §7): every ordered pair of GPUs has its own xGMI link; a rank's bytes to ONE peer
+                # cross ONE link direction at LINK_GBS.  Local stages measured by HIP events in this run; everything except the
+                # first split, the last pass 1, and pass 2 + join is enqueued to run under the exchange.
+                LINK_GBS = 76.8
+                per_peer = st["link_bytes"] / (G - 1)
+                link_ms = per_peer / (LINK_GBS * 1e9) * 1e3
+                local_ms = sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"]
+                exposed = st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"]
+                dist_info["model"] = {"gpus": G, "phantom": bool(world == 1), "link_GBs_per_direction": LINK_GBS,
+                                      "bytes_per_link_direction": per_peer, "link_ms": round(link_ms, 3),
+                                      "local_ms_total": round(local_ms, 3), "exposed_local_ms": round(exposed, 3),
+                                      "exposed_over_link": round(exposed / link_ms, 4),
+                                      "modelled_step_ms": round(max(link_ms, local_ms - exposed) + exposed, 3),
+                                      "modelled_Gtuples_per_s_per_gpu": round(2.0 * n / ((max(link_ms, local_ms - exposed) + exposed) * 1e-3) / 1e9, 2),
+                                      "note": "split(i+1) || exchange(i) || pass-1(i-1); exposed = first split + last pass 1 + pass 2 and join of the probe side's last group of slices"}
+    _keep(B, locals(), "dist_info")
+
+
+def leg_dist_materialize_and_strong(B):
+    """N > 1 (or the multi-GPU path on one GPU): the sharded MATERIALISING join and the strong-scaling point, each recorded as {error} if it fails"""
+    Rk, Rp, Sk, Sp, a, barrier, c_impl, cdev, dist, dj = _take(B, "Rk", "Rp", "Sk", "Sp", "a", "barrier", "c_impl", "cdev", "dist", "dj")
+    dup, expect, hj, n, pkg, rank, torch, use_dist, world = _take(B, "dup", "expect", "hj", "n", "pkg", "rank", "torch", "use_dist", "world")
+    # ---- N > 1 (or the multi-GPU path on one GPU): the materialising sharded join and the strong-scaling point ----
+    dist_mat, strong = None, None
+    # (the headline above is measured: a failure in one of the extra legs is recorded in the line, it does not take the line down —
+    # a rank that fails leaves its peers to the deadline of their next collective, after which they fail into the same handler)
+    if use_dist and c_impl and not a.no_materialize:
+        try:
+            dist_mat = dist_materialize_leg(a, pkg, torch, dist, hj, dj, (Rk, Rp, Sk, Sp), n, world, rank, expect, dup, cdev, barrier)
+        except Exception as e:   # noqa: BLE001
+            dist_mat = {"error": repr(e)}
+    if use_dist and c_impl and world > 1 and not a.no_strong and not (dist_mat or {}).get("error"):
+        try:
+            strong = strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier)
+        except Exception as e:   # noqa: BLE001
+            strong = {"error": repr(e)}
+    _keep(B, locals(), "dist_mat", "strong")
+
+
+def leg_roofline(B):
+    """roofline of the dominant kernel (N = 1: a radix pass against HBM, same-run ceilings; N > 1: the exchange against one xGMI link direction)"""
+    Rk, Rp, a, c_impl, dist_info, hj, isteps, kt, n, torch = _take(B, "Rk", "Rp", "a", "c_impl", "dist_info", "hj", "isteps", "kt", "n", "torch")
+    use_dist, world = _take(B, "use_dist", "world")
+    # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
+    # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written, SURVEY.md §8(d))
+    passes = ("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter")
+    dom = max(passes, key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
+    sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
+    roof = None
+    if sc["launches"] and not use_dist:
+        launches_per_step = sc["launches"] / isteps
+        tuples_per_launch = float(n)  # every pass launch moves one whole relation (keys + payloads)
+        avg_ms = sc["total_ms"] / sc["launches"]
+        achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/): separate
+        # --pmc runs for FETCH_SIZE and WRITE_SIZE, KB units, FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH §HBM)
+        # ... and only if that file was collected from THIS build of libhj.so (its sha256 is stored in the file)
+        traffic, src = None, None
+        try:
+            src = "profiles/r6_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
+            pmf = json.load(open(os.path.join(ROOT, src)))
+            key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom + "<")]
+            if key and pmf.get("lib_sha256") == lib_sha256():
+                traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (src + " (rocprofv3 --pmc passes of this command)") if traffic else None,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch,
+                "measured": "instrumented steps: kernel events on, the passes of R and S on ONE stream (a kernel alone on the chip); the timed "
+                            "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
+                            "committed kernel stats are taken with HJ_FORK_LOG2=0)"}
+        if not a.no_extras:
+            # The bound of THIS box, same run: a pass reads 8 B and writes 8 B per tuple, and no kernel with that mix can beat
+            # (R + W) / (R / read_only + W / write_only), the two one-way streams measured by hj_ubench kinds 2 / 3 on the same columns.
+            # Two further micro-benchmarks are kept as named REFERENCE POINTS, not ceilings (a naive two-column copy and the same copy
+            # with every 128-B line stored at a pseudo-random aligned position: the passes beat both, round 4's line said 1.03 / 1.07).
+            tk, tp = torch.empty_like(Rk), torch.empty_like(Rp)
+            roof.update(mix_ceiling(hj, Rk, Rp, tk, tp, n, 8.0 * tuples_per_launch, 8.0 * tuples_per_launch, achieved))
+            copy = hj.ubench("copy", Rk, Rp, tk, tp, n)
+            scat = hj.ubench("line_scatter", Rk, Rp, tk, tp, n)
+            del tk, tp
+            roof.update({"reference_points": {"stream_copy_GBs": round(copy, 1), "line_scatter_GBs": round(scat, 1),
+                                              "what": "hj_ubench kinds 0 / 1, same run: a plain 16 B/lane copy of a 2^%d-tuple column pair; the same "
+                                                      "reads with every 128-B line stored at a pseudo-random aligned line position.  Not bounds." % a.log2n}})
+    if use_dist and c_impl and dist_info and dist_info["rank0"]["path"] == "sliced" and (world > 1 or a.phantom > 1):
+        # N > 1: the step is bound by the links, not by HBM (DESIGN.md §7): every ordered pair of GPUs has its own xGMI link, and a
+        # rank's bytes to ONE peer cross ONE link direction.  achieved = those bytes over the device time the exchange was in
+        # flight on the communication stream (HIP events, first slice's exchange start to last slice's end) — on one GPU in the
+        # shape of a G-GPU job (--phantom) nothing crosses a link and achieved is null, the model stands in.
+        st = dist_info["rank0"]
+        G = a.phantom if world == 1 else world
+        per_peer = st["link_bytes"] / (G - 1)
+        LINK_GBS = 76.8
+        achieved = (per_peer / (st["exchange_ms"] * 1e-3) / 1e9) if (world > 1 and st["exchange_ms"] > 0) else None
+        roof = {"bound": "xgmi", "kernel": "exchange (one grouped send/recv per slice, %d slices per relation)" % st["slices"],
+                "achieved": round(achieved, 2) if achieved else None, "peak": LINK_GBS, "unit": "GB/s per link direction",
+                "frac": round(achieved / LINK_GBS, 4) if achieved else None, "traffic": per_peer,
+                "bytes_per_link_direction": per_peer, "payload_bytes_per_link_direction": st["payload_bytes"] / (G - 1),
+                "exchange_ms": round(st["exchange_ms"], 3),
+                "exposed_local_ms": round(st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"], 3),
+                "local_ms_total": round(sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"], 3),
+                "note": "rank 0's view; peak = one xGMI link direction (7 links x 153.6 GB/s bidirectional per GPU); traffic = bytes rank 0 "
+                        "sends to ONE peer per step, padding of the fixed-size regions included"}
+    _keep(B, locals(), "roof")
+
+
+def leg_probe_phase(B):
+    """per-kernel times of a step and the probe phase against its stated target"""
+    a, isteps, kt, n, use_dist = _take(B, "a", "isteps", "kt", "n", "use_dist")
+    kernels = {k: {"launches_per_step": v["launches"] / isteps, "ms_per_step": round(v["total_ms"] / isteps, 4)}
+               for k, v in kt.items() if v["launches"]}
+    jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
+    probe = None
+    if jc["launches"] and not use_dist:
+        avg = jc["total_ms"] / jc["launches"]
+        frac = 8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+        probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
+                 "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1), "frac_of_8TBs": round(frac, 4),
+                 "target_frac": probe_target_frac(a.log2n),
+                 "target_model": "0.70 of 8 TB/s at 2^30; below: the same with the measured 25 us of fixed cost per launch — first wave, tail, launch (profiles/r6_fixed_cost_2p27.txt)",
+                 "meets_target": bool(frac >= probe_target_frac(a.log2n))}
+    _keep(B, locals(), "kernels", "probe")
+
+
+def leg_reference_phase_split(B):
+    """the reference's own phase split (Partition / Joins / Total, hjcp.cu:938-940)"""
+    Rk, Rp, Sk, Sp, a, expect, hj, n, pkg, torch = _take(B, "Rk", "Rp", "Sk", "Sp", "a", "expect", "hj", "n", "pkg", "torch")
+    use_dist, = _take(B, "use_dist")
+    # the reference's phase split (hjcp.cu:938-940: Partition / Joins / Total throughput in MB/s of 2*(|R|+|S|)*4 bytes)
+    phase = None
+    if not use_dist and not a.no_extras:
+        reps = max(2, a.steps // 2)
+        tp_, tj_ = 0.0, 0.0
+        for _ in range(reps):
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hj.partition_both()
+            hj.sync()
+            t3 = time.perf_counter()
+            assert hj.join_count()[0] == expect
+            t2 = time.perf_counter()
+            tp_ += t3 - t1
+            tj_ += t2 - t3
+        nbytes = 2.0 * (2 * n) * 4
+        phase = {"partition_ms": round(tp_ / reps * 1e3, 3), "join_ms": round(tj_ / reps * 1e3, 3),
+                 "partition_MBps": round(nbytes / (tp_ / reps) / 1e6, 0), "joins_MBps": round(nbytes / (tj_ / reps) / 1e6, 0),
+                 "total_MBps": round(nbytes / ((tp_ + tj_) / reps) / 1e6, 0),
+                 "units": "the reference's printed lines (hjcp.cu:938-940): 2*(|R|+|S|)*sizeof(int) bytes / seconds / 10^6"}
+    _keep(B, locals(), "phase")
+
+
+def leg_materialize(B):
+    """N = 1: the materialising variant (partition both + ONE probe writing (key, payR, payS)), timed the same way"""
+    Rk, Rp, Sk, Sp, a, dev, dup, expect, hj, n = _take(B, "Rk", "Rp", "Sk", "Sp", "a", "dev", "dup", "expect", "hj", "n")
+    pkg, torch, use_dist = _take(B, "pkg", "torch", "use_dist")
+    # secondary: the materialising variant — partition both relations, then build+probe writing (key,payR,payS) in the
+    # same probe (the reference's lead timed run, hjcp.cu:881-940), N=1 only
+    mat = None
+    if not use_dist and not a.no_materialize:
+        cap = expect
+        ok, opr, ops = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
+
+        def mat_step():
+            hj.bind_device(pkg.REL_R, Rk, Rp)
+            hj.bind_device(pkg.REL_S, Sk, Sp)
+            hj.partition_both()
+            return hj.join_materialize_into(ok, opr, ops, cap)
+
+        assert mat_step() == expect   # warm-up (first touch of the output columns)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = max(1, a.steps // 2)
+        for _ in range(reps):
+            nout = mat_step()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / reps
+        assert nout == expect
+        if dup == 1:
+            # full-size property check (outside the timed region): with unique keys and payloads = 1 the output
+            # multiset is {(k,1,1) : k in R}; its order-independent digest must equal that of (R keys, 1, 1)
+            assert hj.digest_triples(ok, opr, ops, nout) == hj.digest_triples(Rk, Rp, Sp, n), "materialised output digest"
+        hj.enable_timings(2)   # one instrumented step: every launch of a materialising step, by name
+        hj.timings_reset()
+        assert mat_step() == expect
+        km = hj.timings()
+        hj.enable_timings(0)
+        mk = km.get("k_join_materialize", {"launches": 0, "total_ms": 0.0})
+        mat = {"value": round(2.0 * n / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3),
+               "output_tuples": int(nout), "probes_per_step": sum(v["launches"] for k, v in km.items() if k.startswith("k_join_count") or k.startswith("k_join_mat")),
+               "launches_of_one_step": {k: v["launches"] for k, v in km.items() if v["launches"]}}
+        if mk["launches"]:
+            avg = mk["total_ms"] / mk["launches"]
+            mat["k_join_materialize_ms"] = round(avg, 4)
+            mat["k_join_materialize_GBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9, 1)
+            mat["k_join_materialize_frac_of_8TBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if not a.no_extras:
+                mat.update(mix_ceiling(hj, Rk, Rp, ok, opr, n, 8.0 * 2 * n, 12.0 * nout, mat["k_join_materialize_GBs"]))
+        del ok, opr, ops
+    _keep(B, locals(), "mat")
+
+
+def leg_config2_as_stated(B):
+    """2^27 only: BASELINE configs[1] as written (ONE 9-bit pass) beside the default split"""
+    a, expect, hj, hj_cfg_bits, ms_per_step, n, step, torch, use_dist = _take(B, "a", "expect", "hj", "hj_cfg_bits", "ms_per_step", "n", "step", "torch", "use_dist")
+    # BASELINE configs[1] as stated — 2^27 x 2^27 with a SINGLE radix pass of 9 bits (2^18-tuple partitions, the LDS table rebuilt
+    # ~60 times per partition) — timed beside the default two-pass split of the same size, so that the choice of 9+6 bits is visible
+    # where the config is quoted
+    as_stated = None
+    if a.log2n == 27 and not use_dist and not a.no_extras and not a.bits:
+        hj.configure(bits1=9, force_bits=True)
+        assert step() == expect
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            assert step() == expect
+        torch.cuda.synchronize()
+        ms1 = (time.perf_counter() - t0) / 2 * 1e3
+        as_stated = {"radix_bits": [9, 0], "ms_per_step": round(ms1, 3), "value": round(2.0 * n / (ms1 * 1e-3) / 1e9, 3), "unit": "billion tuples/s",
+                     "note": "configs[1] as stated: single-pass radix (9 bits); the default for this size is two passes (%d+%d bits): %.3f ms"
+                             % (hj_cfg_bits[0], hj_cfg_bits[1], ms_per_step)}
+        hj.configure()
+    _keep(B, locals(), "as_stated")
+
+
+def leg_alt_transport(B):
+    """N > 1: the same workload driven by ONE process over RCCL and over the copy engines (rank 0, in a child process with a deadline)"""
+    a, c_impl, dist, dist_info, dj, hj, local, pkg, quiet, rank = _take(B, "a", "c_impl", "dist", "dist_info", "dj", "hj", "local", "pkg", "quiet", "rank")
+    torch, use_dist, world = _take(B, "torch", "use_dist", "world")
+    # ---- N > 1: both transports on the same workload, one process driving every GPU (rank 0), the others quiet ----
+    alt = None
+    final_cfg = hj.config()
+    if use_dist and c_impl and world > 1 and quiet is not None and not a.no_alt_transport:
+        if dj is not None:
+            dj.close()
+        hj.close()
+        del Rk, Rp, Sk, Sp
+        B.Rk = B.Rp = B.Sk = B.Sp = B.dj = None   # (the namespace must not keep the columns alive either)
+        torch.cuda.empty_cache()
+        dist.barrier(group=quiet)           # every rank has released its GPU
+        if rank == 0:
+            # in a CHILD process with a deadline: the headline is already measured, and a communicator that does not come up (or a
+            # crash) in this extra leg must cost a note in the line, not the line
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                   "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--alt-child", "--gpus", str(world), "--log2n", str(a.log2n), "--steps", str(a.steps),
+                   "--warmup", str(a.warmup), "--slices", str(a.slices)] + (["--exact-only"] if a.exact_only else []) + (["--single-group"] if a.single_group else [])
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=float(os.environ.get("HJ_BENCH_ALT_TIMEOUT_S", "600")))
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"alt_transport"' in l]
+                alt = json.loads(lines[-1])["alt_transport"] if (p.returncode == 0 and lines) else {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-600:])}
+            except subprocess.TimeoutExpired:
+                alt = {"error": "the one-process leg did not finish within its deadline"}
+            except Exception as e:   # noqa: BLE001
+                alt = {"error": repr(e)}
+        dist.barrier(group=quiet)
+        hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)   # (the CPU baseline below generates its sample on the GPU)
+    if dist_info is not None:
+        dist_info["alt_transport"] = alt
+    _keep(B, locals(), "final_cfg", "hj")
+
+
+def leg_cpu_baseline(B):
+    """rank 0: the CPU baselines (the port of the reference's scheme, the library's own host join, the reference's joinCpu)"""
+    a, dev, hj, pkg, rank, torch = _take(B, "a", "dev", "hj", "pkg", "rank", "torch")
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline and not (a.phantom > 1):
+        # rank 0 at every N (the other ranks wait at the final barrier): the same bounded sample of the per-GPU workload
+        cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
+        cpu["cpu_model"] = cpu_model()
+        cpu["joinCpu"] = join_cpu_baseline(hj, torch, dev, cpu["cores"])
+    _keep(B, locals(), "cpu")
+
+
+def leg_print_line(B):
+    """rank 0 prints the ONE JSON line; the process group goes down"""
+    a, as_stated, backend, c_impl, cpu, dist, dist_info, dist_mat, final_cfg, got = _take(B, "a", "as_stated", "backend", "c_impl", "cpu", "dist", "dist_info", "dist_mat", "final_cfg", "got")
+    hj_cfg_bits, isteps, kernels, layout, mat, ms_per_step, n, phase, probe, rank = _take(B, "hj_cfg_bits", "isteps", "kernels", "layout", "mat", "ms_per_step", "n", "phase", "probe", "rank")
+    roof, strong, use_dist, value, world = _take(B, "roof", "strong", "use_dist", "value", "world")
+    if rank == 0:
+        cfg = final_cfg
+        cfg["bits1"], cfg["bits2"] = hj_cfg_bits
+        line = {
+            "metric": ("billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)
+                       if world == 1 else
+                       "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform per GPU, %d GPUs" % (a.log2n, a.log2n, world))
+                      + (" [PLUMBING RUN over gloo on ONE GPU: not a measurement]" if backend == "gloo" else "")
+                      + (" [PHANTOM: ONE GPU running the local stages in the shape of a %d-GPU job, nothing crosses a link; value = this "
+                         "GPU's local work only, the modelled step is dist.model: not a measurement of the metric]" % a.phantom
+                         if (use_dist and world == 1 and a.phantom > 1) else "")
+                      + (" [multi-GPU code path forced at world size 1: not the headline]" if (use_dist and world == 1 and a.phantom <= 1) else ""),
+            # not a measurement: the gloo plumbing mode, and any N > 1 line produced by the torch.distributed FALLBACK driver when
+            # hj_dist was asked for (a communicator could not be made): a scaling number from it must not pass for hj_dist's
+            "is_measurement": backend != "gloo" and not (use_dist and a.dist_impl == "c" and not c_impl and backend != "gloo" and a.balance == "hash")
+                              and not (use_dist and world == 1 and a.phantom > 1),
+            "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "2^%d ⋈ 2^%d unique uniform int32 keys per GPU, payload=1, count-only "
+                                   "build+probe after %d-pass radix partition (%d+%d bits)%s" %
+                                   (a.log2n, a.log2n, 2 if cfg["bits2"] else 1, cfg["bits1"], cfg["bits2"],
+                                    "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
+                       "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
+                       "partition_layout_R_S": layout, "matches": int(got)},
+            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat if not use_dist else dist_mat,
+            "strong_scaling": strong, "config2_as_stated": as_stated,
+            "cpu_baseline": cpu, "dist": dist_info, "lib_sha256": lib_sha256(),
+            "timing": "value/ms_per_step: %d steps with no kernel events (library default); kernels/roofline/probe_phase: %d "
+                      "further steps with HIP events around the data-moving kernels" % (a.steps, isteps),
+        }
+        print(json.dumps(line))
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; default: WORLD_SIZE under a launcher, else 1")
@@ -726,377 +1186,21 @@ def main():
     if a.workload == "coprocess":
         return bench_coprocess(a, pkg, torch, dev, local)
 
-    if use_dist:
-        # a stream of our own for N>1: the all-to-alls run asynchronously next to local kernels, and HIP's
-        # legacy default stream would add implicit synchronisation with other blocking streams
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-    hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)
-    if a.bits or a.probe_chunk or a.lds or a.exact_only:
-        hj.configure(bits1=a.bits[0] if a.bits else 0, bits2=a.bits[1] if a.bits else 0, probe_chunk=a.probe_chunk,
-                     lds_capacity=a.lds[0] if a.lds else 0, lds_heads=a.lds[1] if a.lds else 0, exact_only=a.exact_only)
-    # inputs: rank r holds slice r of two independent pseudo-random permutations of the global key
-    # domain [0, min(total_n, 2^32)) (beyond 2^32 tuples keys repeat: int32 keys cannot be unique)
-    domain = min(total_n, 1 << 32)
-    Rk = torch.empty(n, dtype=torch.int32, device=dev)
-    Sk = torch.empty(n, dtype=torch.int32, device=dev)
-    Rp = torch.empty(n, dtype=torch.int32, device=dev)
-    Sp = torch.empty(n, dtype=torch.int32, device=dev)
-    hj.gen_unique(Rk, n, rank * n, domain, 1)
-    hj.gen_unique(Sk, n, rank * n, domain, 2)
-    hj.fill_payload(Rp, n, "ones")
-    hj.fill_payload(Sp, n, "ones")
-    hj.sync()
-    dup = max(1, total_n // domain)
-    expect = total_n * dup  # every key occurs dup times in R and in S
-
-    dj = None
-    c_impl = False
-    if use_dist:
-        from importlib import import_module
-        dmod = import_module(pkg.__name__ + ".dist")
-        c_impl = a.dist_impl == "c" and backend != "gloo" and a.balance == "hash"
-        dist_fallback = None
-        if c_impl:
-            # the exchange behind the C ABI: C++ host code over RCCL (ncclCommInitRank with an id broadcast over the control plane).
-            # If the communicator cannot be made (every rank agrees on that through an all-reduce), the torch.distributed driver of
-            # rounds 1-2 takes over and the line says so.
-            try:
-                dj = dmod.RankJoin(hj, rank, world)
-                dj.configure(slices=a.slices, exact_only=a.exact_only, phantom_world=a.phantom if world == 1 else 0, single_group=a.single_group)
-                ok = 1
-            except Exception as e:   # noqa: BLE001
-                ok, dist_fallback = 0, repr(e)
-            t_ok = torch.tensor([ok], dtype=torch.int32, device=cdev)
-            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-            if int(t_ok.item()) == 0:
-                c_impl, dj = False, None
-                dist_fallback = dist_fallback or "another rank could not create its hj_dist_rank"
-        if not c_impl:
-            dj = dmod.ShardedJoin(hj, pkg, dev, balance=a.balance)
-            dj.force_exchange = a.force_dist
-
-    def step(verify=False):
-        if not use_dist:
-            hj.bind_device(pkg.REL_R, Rk, Rp)
-            hj.bind_device(pkg.REL_S, Sk, Sp)
-            return hj.join()[0]
-        # verify: the digest of everything sent must equal the digest of everything received (dist.ShardedJoin.join)
-        return dj.join(Rk, Rp, Sk, Sp, verify=verify)[0]
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        got = step(verify=True)   # every warm-up step checks the exchange
-        assert got == expect, (got, expect)
-    hj.timings_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        got = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert got == expect, (got, expect)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / a.steps * 1e3
-    value = 2.0 * total_n * a.steps / dt / 1e9
-    # The headline loop above ran with the library's default: no HIP events around the kernels.  The per-kernel figures
-    # (roofline, probe phase, kernels) come from extra, instrumented steps of the same workload, outside the timed region.
-    hj.enable_timings(1)
-    hj.timings_reset()
-    isteps = max(1, min(a.steps, 5))
-    for _ in range(isteps):
-        assert step() == expect
-    barrier()
-    kt = hj.timings()
-    hj.enable_timings(0)
-    layout = [hj.partition_layout(pkg.REL_R), hj.partition_layout(pkg.REL_S)]
-    hj_cfg_bits = [hj.config()["bits1"], hj.config()["bits2"]]
-
-    dist_info = None
-    if use_dist:
-        recv = torch.tensor(list(dj.last_received), dtype=torch.int64, device=cdev)
-        allrecv = [torch.empty_like(recv) for _ in range(world)]
-        dist.all_gather(allrecv, recv)
-        dist_info = {"world": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-                     "driver": "hj_dist (C++ over RCCL, include/hj_dist.h)" if c_impl else "dist.py (torch.distributed)",
-                     "driver_fallback_reason": dist_fallback,
-                     "received_tuples_per_rank_R_S": [[int(x) for x in t.tolist()] for t in allrecv]}
-        dist_info["transport"] = "rccl (grouped ncclSend/ncclRecv per slice, hj_dist)" if c_impl else "torch.distributed all_to_all_single (%s)" % dist.get_backend()
-        if c_impl:
-            st = dj.stats()
-            G = a.phantom if (world == 1 and a.phantom > 1) else world
-            dist_info["rank0"] = st
-            if st["path"] == "sliced" and G > 1:
-                # Timeline model: every ordered pair of GPUs has its own xGMI link; a rank's bytes to ONE peer
-                # cross ONE link direction at LINK_GBS.  Local stages measured by HIP events in this run; everything except the
-                # first split, the last pass 1, and pass 2 + join is enqueued to run under the exchange.
-                LINK_GBS = 76.8
-                per_peer = st["link_bytes"] / (G - 1)
-                link_ms = per_peer / (LINK_GBS * 1e9) * 1e3
-                local_ms = sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"]
-                exposed = st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"]
-                dist_info["model"] = {"gpus": G, "phantom": bool(world == 1), "link_GBs_per_direction": LINK_GBS,
-                                      "bytes_per_link_direction": per_peer, "link_ms": round(link_ms, 3),
-                                      "local_ms_total": round(local_ms, 3), "exposed_local_ms": round(exposed, 3),
-                                      "exposed_over_link": round(exposed / link_ms, 4),
-                                      "modelled_step_ms": round(max(link_ms, local_ms - exposed) + exposed, 3),
-                                      "modelled_Gtuples_per_s_per_gpu": round(2.0 * n / ((max(link_ms, local_ms - exposed) + exposed) * 1e-3) / 1e9, 2),
-                                      "note": "split(i+1) || exchange(i) || pass-1(i-1); exposed = first split + last pass 1 + pass 2 and join of the probe side's last group of slices"}
-
-    # ---- N > 1 (or the multi-GPU path on one GPU): the materialising sharded join and the strong-scaling point ----
-    dist_mat, strong = None, None
-    # (the headline above is measured: a failure in one of the extra legs is recorded in the line, it does not take the line down —
-    # a rank that fails leaves its peers to the deadline of their next collective, after which they fail into the same handler)
-    if use_dist and c_impl and not a.no_materialize:
-        try:
-            dist_mat = dist_materialize_leg(a, pkg, torch, dist, hj, dj, (Rk, Rp, Sk, Sp), n, world, rank, expect, dup, cdev, barrier)
-        except Exception as e:   # noqa: BLE001
-            dist_mat = {"error": repr(e)}
-    if use_dist and c_impl and world > 1 and not a.no_strong and not (dist_mat or {}).get("error"):
-        try:
-            strong = strong_leg(a, pkg, torch, dist, hj, dj, n, world, rank, cdev, barrier)
-        except Exception as e:   # noqa: BLE001
-            strong = {"error": repr(e)}
-
-    # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
-    # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
-    passes = ("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter")
-    dom = max(passes, key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
-    sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
-    roof = None
-    if sc["launches"] and not use_dist:
-        launches_per_step = sc["launches"] / isteps
-        tuples_per_launch = float(n)  # every pass launch moves one whole relation (keys + payloads)
-        avg_ms = sc["total_ms"] / sc["launches"]
-        achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes of this same command (profiles/): separate
-        # --pmc runs for FETCH_SIZE and WRITE_SIZE, KB units, FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH §HBM)
-        # ... and only if that file was collected from THIS build of libhj.so (its sha256 is stored in the file)
-        traffic, src = None, None
-        try:
-            src = "profiles/r5_pmc_2p%d%s.json" % (a.log2n, "_exact" if dom.startswith("k_scatter") else "")
-            pmf = json.load(open(os.path.join(ROOT, src)))
-            key = [k for k in pmf["kernels"] if k.startswith("hj::" + dom + "<")]
-            if key and pmf.get("lib_sha256") == lib_sha256():
-                traffic = pmf["kernels"][key[0]]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": (src + " (rocprofv3 --pmc passes of this command)") if traffic else None,
-                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch,
-                "measured": "instrumented steps: kernel events on, the passes of R and S on ONE stream (a kernel alone on the chip); the timed "
-                            "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
-                            "committed kernel stats are taken with HJ_FORK_LOG2=0)"}
-        if not a.no_extras:
-            # The bound of THIS box, same run: a pass reads 8 B and writes 8 B per tuple, and no kernel with that mix can beat
-            # (R + W) / (R / read_only + W / write_only), the two one-way streams measured by hj_ubench kinds 2 / 3 on the same columns.
-            # Two further micro-benchmarks are kept as named REFERENCE POINTS, not ceilings (a naive two-column copy and the same copy
-            # with every 128-B line stored at a pseudo-random aligned position: the passes beat both, round 4's line said 1.03 / 1.07).
-            tk, tp = torch.empty_like(Rk), torch.empty_like(Rp)
-            roof.update(mix_ceiling(hj, Rk, Rp, tk, tp, n, 8.0 * tuples_per_launch, 8.0 * tuples_per_launch, achieved))
-            copy = hj.ubench("copy", Rk, Rp, tk, tp, n)
-            scat = hj.ubench("line_scatter", Rk, Rp, tk, tp, n)
-            del tk, tp
-            roof.update({"reference_points": {"stream_copy_GBs": round(copy, 1), "line_scatter_GBs": round(scat, 1),
-                                              "what": "hj_ubench kinds 0 / 1, same run: a plain 16 B/lane copy of a 2^%d-tuple column pair; the same "
-                                                      "reads with every 128-B line stored at a pseudo-random aligned line position.  Not bounds." % a.log2n}})
-    if use_dist and c_impl and dist_info and dist_info["rank0"]["path"] == "sliced" and (world > 1 or a.phantom > 1):
-        # N > 1: the step is bound by the links, not by HBM: every ordered pair of GPUs has its own xGMI link, and a
-        # rank's bytes to ONE peer cross ONE link direction.  achieved = those bytes over the device time the exchange was in
-        # flight on the communication stream (HIP events, first slice's exchange start to last slice's end) — on one GPU in the
-        # shape of a G-GPU job (--phantom) nothing crosses a link and achieved is null, the model stands in.
-        st = dist_info["rank0"]
-        G = a.phantom if world == 1 else world
-        per_peer = st["link_bytes"] / (G - 1)
-        LINK_GBS = 76.8
-        achieved = (per_peer / (st["exchange_ms"] * 1e-3) / 1e9) if (world > 1 and st["exchange_ms"] > 0) else None
-        roof = {"bound": "xgmi", "kernel": "exchange (one grouped send/recv per slice, %d slices per relation)" % st["slices"],
-                "achieved": round(achieved, 2) if achieved else None, "peak": LINK_GBS, "unit": "GB/s per link direction",
-                "frac": round(achieved / LINK_GBS, 4) if achieved else None, "traffic": per_peer,
-                "bytes_per_link_direction": per_peer, "payload_bytes_per_link_direction": st["payload_bytes"] / (G - 1),
-                "exchange_ms": round(st["exchange_ms"], 3),
-                "exposed_local_ms": round(st["first_split_ms"] + st["last_pass1_ms"] + st["pass2_join_ms"], 3),
-                "local_ms_total": round(sum(st["split_ms"]) + sum(st["pass1_ms"]) + st["pass2_join_ms"] + st["early_pass2_join_ms"], 3),
-                "note": "rank 0's view; peak = one xGMI link direction (7 links x 153.6 GB/s bidirectional per GPU); traffic = bytes rank 0 "
-                        "sends to ONE peer per step, padding of the fixed-size regions included"}
-    kernels = {k: {"launches_per_step": v["launches"] / isteps, "ms_per_step": round(v["total_ms"] / isteps, 4)}
-               for k, v in kt.items() if v["launches"]}
-    jc = kt.get("k_join_count", {"launches": 0, "total_ms": 0.0})
-    probe = None
-    if jc["launches"] and not use_dist:
-        avg = jc["total_ms"] / jc["launches"]
-        frac = 8.0 * 2 * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
-        probe = {"kernel": "k_join_count", "avg_launch_ms": round(avg, 4),
-                 "achieved_GBs": round(8.0 * 2 * n / (avg * 1e-3) / 1e9, 1), "frac_of_8TBs": round(frac, 4),
-                 "target_frac": probe_target_frac(a.log2n),
-                 "target_model": "0.70 of 8 TB/s at 2^30; below: the same with 60 us of fixed cost per launch (profiles/r5_launch_structure_ab.txt)",
-                 "meets_target": bool(frac >= probe_target_frac(a.log2n))}
-
-    # the reference's phase split (hjcp.cu:938-940: Partition / Joins / Total throughput in MB/s of 2*(|R|+|S|)*4 bytes)
-    phase = None
-    if not use_dist and not a.no_extras:
-        reps = max(2, a.steps // 2)
-        tp_, tj_ = 0.0, 0.0
-        for _ in range(reps):
-            hj.bind_device(pkg.REL_R, Rk, Rp)
-            hj.bind_device(pkg.REL_S, Sk, Sp)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            hj.partition_both()
-            hj.sync()
-            t3 = time.perf_counter()
-            assert hj.join_count()[0] == expect
-            t2 = time.perf_counter()
-            tp_ += t3 - t1
-            tj_ += t2 - t3
-        nbytes = 2.0 * (2 * n) * 4
-        phase = {"partition_ms": round(tp_ / reps * 1e3, 3), "join_ms": round(tj_ / reps * 1e3, 3),
-                 "partition_MBps": round(nbytes / (tp_ / reps) / 1e6, 0), "joins_MBps": round(nbytes / (tj_ / reps) / 1e6, 0),
-                 "total_MBps": round(nbytes / ((tp_ + tj_) / reps) / 1e6, 0),
-                 "units": "the reference's printed lines (hjcp.cu:938-940): 2*(|R|+|S|)*sizeof(int) bytes / seconds / 10^6"}
-
-    # secondary: the materialising variant — partition both relations, then build+probe writing (key,payR,payS) in the
-    # same probe (the reference's lead timed run, hjcp.cu:881-940), N=1 only
-    mat = None
-    if not use_dist and not a.no_materialize:
-        cap = expect
-        ok, opr, ops = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
-
-        def mat_step():
-            hj.bind_device(pkg.REL_R, Rk, Rp)
-            hj.bind_device(pkg.REL_S, Sk, Sp)
-            hj.partition_both()
-            return hj.join_materialize_into(ok, opr, ops, cap)
-
-        assert mat_step() == expect   # warm-up (first touch of the output columns)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = max(1, a.steps // 2)
-        for _ in range(reps):
-            nout = mat_step()
-        torch.cuda.synchronize()
-        dtm = (time.perf_counter() - t0) / reps
-        assert nout == expect
-        if dup == 1:
-            # full-size property check (outside the timed region): with unique keys and payloads = 1 the output
-            # multiset is {(k,1,1) : k in R}; its order-independent digest must equal that of (R keys, 1, 1)
-            assert hj.digest_triples(ok, opr, ops, nout) == hj.digest_triples(Rk, Rp, Sp, n), "materialised output digest"
-        hj.enable_timings(2)   # one instrumented step: every launch of a materialising step, by name
-        hj.timings_reset()
-        assert mat_step() == expect
-        km = hj.timings()
-        hj.enable_timings(0)
-        mk = km.get("k_join_materialize", {"launches": 0, "total_ms": 0.0})
-        mat = {"value": round(2.0 * n / dtm / 1e9, 3), "unit": "billion tuples/s", "ms_per_step": round(dtm * 1e3, 3),
-               "output_tuples": int(nout), "probes_per_step": sum(v["launches"] for k, v in km.items() if k.startswith("k_join_count") or k.startswith("k_join_mat")),
-               "launches_of_one_step": {k: v["launches"] for k, v in km.items() if v["launches"]}}
-        if mk["launches"]:
-            avg = mk["total_ms"] / mk["launches"]
-            mat["k_join_materialize_ms"] = round(avg, 4)
-            mat["k_join_materialize_GBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9, 1)
-            mat["k_join_materialize_frac_of_8TBs"] = round((8.0 * 2 * n + 12.0 * nout) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            if not a.no_extras:
-                mat.update(mix_ceiling(hj, Rk, Rp, ok, opr, n, 8.0 * 2 * n, 12.0 * nout, mat["k_join_materialize_GBs"]))
-        del ok, opr, ops
-
-    # BASELINE configs[1] as stated — 2^27 x 2^27 with a SINGLE radix pass of 9 bits (2^18-tuple partitions, the LDS table rebuilt
-    # ~60 times per partition) — timed beside the default two-pass split of the same size, so that the choice of 9+6 bits is visible
-    # where the config is quoted
-    as_stated = None
-    if a.log2n == 27 and not use_dist and not a.no_extras and not a.bits:
-        hj.configure(bits1=9, force_bits=True)
-        assert step() == expect
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            assert step() == expect
-        torch.cuda.synchronize()
-        ms1 = (time.perf_counter() - t0) / 2 * 1e3
-        as_stated = {"radix_bits": [9, 0], "ms_per_step": round(ms1, 3), "value": round(2.0 * n / (ms1 * 1e-3) / 1e9, 3), "unit": "billion tuples/s",
-                     "note": "configs[1] as stated: single-pass radix (9 bits); the default for this size is two passes (%d+%d bits): %.3f ms"
-                             % (hj_cfg_bits[0], hj_cfg_bits[1], ms_per_step)}
-        hj.configure()
-
-    # ---- N > 1: both transports on the same workload, one process driving every GPU (rank 0), the others quiet ----
-    alt = None
-    final_cfg = hj.config()
-    if use_dist and c_impl and world > 1 and quiet is not None and not a.no_alt_transport:
-        if dj is not None:
-            dj.close()
-        hj.close()
-        del Rk, Rp, Sk, Sp
-        torch.cuda.empty_cache()
-        dist.barrier(group=quiet)           # every rank has released its GPU
-        if rank == 0:
-            # in a CHILD process with a deadline: the headline is already measured, and a communicator that does not come up (or a
-            # crash) in this extra leg must cost a note in the line, not the line
-            import subprocess
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
-                                                                   "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-            cmd = [sys.executable, os.path.abspath(__file__), "--alt-child", "--gpus", str(world), "--log2n", str(a.log2n), "--steps", str(a.steps),
-                   "--warmup", str(a.warmup), "--slices", str(a.slices)] + (["--exact-only"] if a.exact_only else []) + (["--single-group"] if a.single_group else [])
-            try:
-                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=float(os.environ.get("HJ_BENCH_ALT_TIMEOUT_S", "600")))
-                lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"alt_transport"' in l]
-                alt = json.loads(lines[-1])["alt_transport"] if (p.returncode == 0 and lines) else {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-600:])}
-            except subprocess.TimeoutExpired:
-                alt = {"error": "the one-process leg did not finish within its deadline"}
-            except Exception as e:   # noqa: BLE001
-                alt = {"error": repr(e)}
-        dist.barrier(group=quiet)
-        hj = pkg.HashJoin(local, stream=torch.cuda.current_stream().cuda_stream)   # (the CPU baseline below generates its sample on the GPU)
-    if dist_info is not None:
-        dist_info["alt_transport"] = alt
-
-    cpu = None
-    if rank == 0 and not a.no_cpu_baseline and not (a.phantom > 1):
-        # rank 0 at every N (the other ranks wait at the final barrier): the same bounded sample of the per-GPU workload
-        cpu = cpu_baseline(pkg, hj, torch, dev, a.log2n)
-        cpu["cpu_model"] = cpu_model()
-        cpu["joinCpu"] = join_cpu_baseline(hj, torch, dev, cpu["cores"])
-
-    if rank == 0:
-        cfg = final_cfg
-        cfg["bits1"], cfg["bits2"] = hj_cfg_bits
-        line = {
-            "metric": ("billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform, %d GPU" % (a.log2n, a.log2n, world)
-                       if world == 1 else
-                       "billion tuples/sec (build+probe), 2^%d⋈2^%d int32 uniform per GPU, %d GPUs" % (a.log2n, a.log2n, world))
-                      + (" [PLUMBING RUN over gloo on ONE GPU: not a measurement]" if backend == "gloo" else "")
-                      + (" [PHANTOM: ONE GPU running the local stages in the shape of a %d-GPU job, nothing crosses a link; value = this "
-                         "GPU's local work only, the modelled step is dist.model: not a measurement of the metric]" % a.phantom
-                         if (use_dist and world == 1 and a.phantom > 1) else "")
-                      + (" [multi-GPU code path forced at world size 1: not the headline]" if (use_dist and world == 1 and a.phantom <= 1) else ""),
-            # not a measurement: the gloo plumbing mode, and any N > 1 line produced by the torch.distributed FALLBACK driver when
-            # hj_dist was asked for (a communicator could not be made): a scaling number from it must not pass for hj_dist's
-            "is_measurement": backend != "gloo" and not (use_dist and a.dist_impl == "c" and not c_impl and backend != "gloo" and a.balance == "hash")
-                              and not (use_dist and world == 1 and a.phantom > 1),
-            "value": round(value, 3), "unit": "billion tuples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "2^%d ⋈ 2^%d unique uniform int32 keys per GPU, payload=1, count-only "
-                                   "build+probe after %d-pass radix partition (%d+%d bits)%s" %
-                                   (a.log2n, a.log2n, 2 if cfg["bits2"] else 1, cfg["bits1"], cfg["bits2"],
-                                    "" if not use_dist else "; level-0 shard split + RCCL all-to-all over %d GPUs" % world),
-                       "tuples_per_relation_per_gpu": n, "radix_bits": [cfg["bits1"], cfg["bits2"]],
-                       "partition_layout_R_S": layout, "matches": int(got)},
-            "roofline": roof, "probe_phase": probe, "phase": phase, "kernels": kernels, "materialize": mat if not use_dist else dist_mat,
-            "strong_scaling": strong, "config2_as_stated": as_stated,
-            "cpu_baseline": cpu, "dist": dist_info, "lib_sha256": lib_sha256(),
-            "timing": "value/ms_per_step: %d steps with no kernel events (library default); kernels/roofline/probe_phase: %d "
-                      "further steps with HIP events around the data-moving kernels" % (a.steps, isteps),
-        }
-        print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
+    B = types.SimpleNamespace(**{k: v for k, v in locals().items() if k != 'ap'})
+    for leg in (leg_inputs_and_driver,
+                leg_timed_headline,
+                leg_instrumented_steps,
+                leg_dist_info,
+                leg_dist_materialize_and_strong,
+                leg_roofline,
+                leg_probe_phase,
+                leg_reference_phase_split,
+                leg_materialize,
+                leg_config2_as_stated,
+                leg_alt_transport,
+                leg_cpu_baseline,
+                leg_print_line):
+        leg(B)
 
 
 if __name__ == "__main__":

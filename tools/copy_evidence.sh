@@ -3,7 +3,7 @@
 # -> profiles/${ROUND}_*: what the documents quote.  Run from the repository root, in this order: profiles, final, then (after the PMC files
 # are in place and tools/gpu_bench_lines.sh has run) lines.
 set -e
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 S=gpurun_out/${ROUND}prof; D=profiles
 LIB=$(sha256sum icde2019-gpu-join_amd/libhj.so | cut -d" " -f1)
 same_binary() { # the results must come from the library that is in the tree now
@@ -12,7 +12,7 @@ same_binary() { # the results must come from the library that is in the tree now
 case "$1" in
 profiles)
   same_binary $S/libhj.sha256
-  for f in 2p30_exact zipf_exact zipf_24_27_pk_builds zipf_24_27_zipf_builds stream coprocess baselines forcedist forcedist_torch phantom2 phantom4 phantom8 phantom8_single_group; do cp $S/bench_$f.json $D/${ROUND}_bench_$f.json; done
+  for f in 2p30_exact zipf_exact zipf_24_27_pk_builds zipf_24_27_zipf_builds stream coprocess baselines forcedist forcedist_torch phantom2 phantom4 phantom8 phantom8_single_group phantom2_strong phantom4_strong phantom8_strong; do cp $S/bench_$f.json $D/${ROUND}_bench_$f.json; done
   for f in 2p30 2p27 zipf; do cp $S/bench_$f.json $D/${ROUND}_bench_${f}_evidence_call.json; done
   cp $S/stats30.kernel_stats.csv $D/${ROUND}_kernel_stats_2p30.csv; cp $S/stats27.kernel_stats.csv $D/${ROUND}_kernel_stats_2p27.csv; cp $S/statszipf.kernel_stats.csv $D/${ROUND}_kernel_stats_zipf.csv
   # the bench line each rocprofv3 process printed itself: CSV and line are ONE process (their per-kernel averages agree)

@@ -4,7 +4,7 @@
 # processes back to back: processes on one box differ by up to 10 % (profiles/r4_column_phase.txt), so the documents quote the MEDIAN
 # process and the range (tools/copy_evidence.sh lines picks it).
 cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 export ROUND
 OUT=gpurun_out/${ROUND}lines
 mkdir -p $OUT

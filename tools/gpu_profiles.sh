@@ -3,7 +3,7 @@
 # into profiles/).  --pmc runs are separate from --kernel-trace --stats runs and never combined with sys/runtime tracing.
 cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 OUT=$ROOT/gpurun_out/${ROUND}prof
 mkdir -p $OUT
 cd $ROOT
@@ -20,6 +20,10 @@ python bench.py --workload coprocess --log2n 27 --steps 9 --warmup 2 > $OUT/benc
 python bench.py --steps 5 --warmup 2 --force-dist --no-cpu-baseline > $OUT/bench_forcedist.json 2>/dev/null; echo "forcedist rc=$?"
 for g in 2 4 8; do python bench.py --steps 5 --warmup 2 --force-dist --phantom $g --no-cpu-baseline > $OUT/bench_phantom$g.json 2>/dev/null; done
 python bench.py --steps 5 --warmup 2 --force-dist --phantom 8 --single-group --no-cpu-baseline > $OUT/bench_phantom8_single_group.json 2>/dev/null
+# the STRONG shape (BASELINE's metric read as "2^30 x 2^30 ... 1/2/4/8 GPU": 2^30 tuples per relation in TOTAL): 2^(30 - log2 G) per GPU
+python bench.py --steps 5 --warmup 2 --force-dist --phantom 2 --log2n 29 --no-cpu-baseline > $OUT/bench_phantom2_strong.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --force-dist --phantom 4 --log2n 28 --no-cpu-baseline > $OUT/bench_phantom4_strong.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --force-dist --phantom 8 --log2n 27 --no-cpu-baseline > $OUT/bench_phantom8_strong.json 2>/dev/null; echo "phantom strong rc=$?"
 python bench.py --steps 5 --warmup 2 --force-dist --dist-impl torch --no-cpu-baseline > $OUT/bench_forcedist_torch.json 2>/dev/null
 python tools/step_vs_size.py 2>/dev/null > $OUT/step_vs_size.txt
 for l in 24 27 30; do python bench.py --workload baselines --log2n $l --steps 3 --warmup 1 2>/dev/null; done > $OUT/bench_baselines.json

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 G=/usr/local/graft/bin/gpurun
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 export ROUND
 tools/kernel_sizes.sh > profiles/${ROUND}_libhj_kernels.txt   # (the coverage call below reads it on the box)
 ok() { grep -q '"status": *"ok"' gpurun_out/.last_call.json || { echo "gpurun did not run the command: $(cat gpurun_out/.last_call.json | head -c 300)"; exit 3; }; }

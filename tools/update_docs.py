@@ -13,7 +13,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r5")
+ROUND = os.environ.get("ROUND", "r6")
 
 
 def load(name):
