@@ -139,6 +139,8 @@ SIGNATURES = {
     "hj_dist_rank_join": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, u64p, u64p]),
     "hj_dist_rank_join_materialize": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p, u64p, u64p, u64p]),
     "hj_dist_rank_get_stats": (C.c_int, [vp, C.POINTER(DistStats)]),
+    "hj_dist_debug_stall_rank": (C.c_int, [C.c_int]),          # debug symbols (tests): not declared in the headers
+    "hj_host_split_debug_progress": (C.c_int, [C.c_int]),
     "hashJoinClusteredProbe": (C.c_uint, [C.POINTER(Args), vp]),
     "hj_reference_last_result": (None, [C.POINTER(LastResult)]),
 }

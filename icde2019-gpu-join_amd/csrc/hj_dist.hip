@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -56,6 +57,7 @@ using namespace hjx;
 namespace {
 
 constexpr uint64_t PAD = 16;
+std::atomic<int> g_debug_stall_rank{0}; // tests only (hj_dist_debug_stall_rank): rank + 1 that stalls in its next exchange; 0 = none
 constexpr size_t MSG_CHUNK = (size_t)512 << 20; // RCCL 2.26 / ROCm 7 corrupted single messages of >= 2 GiB (tools/experiments/rccl_2gib_repro.py)
 
 // librccl is bound at run time, not at link time: a process that has PyTorch loaded already carries PyTorch's own copy of
@@ -342,6 +344,7 @@ struct hj_dist_rank {
     uint32_t cur_maxK = 0, cur_K[2] = {0, 0}; // the slices of the running sliced join (for the event census of a deadline)
     std::vector<uint8_t> enq;  // [2*maxK] split events, [2*maxK] exchange events recorded by the running join
     bool prefer_exact = false; // the last fast attempt overflowed somewhere: exact path until new columns are bound
+    bool args_rejected = false; // the last join returned HJ_EINVAL because some rank's arguments were bad (learned from the first all-gather): the link is fine
     const int32_t *last_cols[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t last_n[2] = {0, 0};
     // buffers (grow-only)
@@ -726,10 +729,10 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     auto exchange = [&](int x, uint32_t i) -> int {
         const SliceGeom &q = g[x];
         r->stage = "exchange"; r->stage_rel = x; r->stage_slice = (int)i;
-        if (x == second && i == 0) { // test hook ($HJ_DIST_TEST_STALL_RANK = rank + 1): this rank stops taking part for longer than the deadline
-            const char *e = getenv("HJ_DIST_TEST_STALL_RANK");
-            if (e && atoi(e) == r->rank + 1) std::this_thread::sleep_for(std::chrono::duration<double>(r->timeout_s * 2.5 + 0.2));
-        }
+        // test hook (hj_dist_debug_stall_rank; was read from the environment inside every exchange until round 5): this rank stops taking
+        // part for longer than the deadline
+        if (x == second && i == 0 && g_debug_stall_rank.load(std::memory_order_relaxed) == r->rank + 1)
+            std::this_thread::sleep_for(std::chrono::duration<double>(r->timeout_s * 2.5 + 0.2));
         DCHK(r, hipStreamWaitEvent(ms, r->ev_split[x * maxK + i], 0));
         if (!xchg_started) { DCHK(r, hipEventRecord(r->ev_t[4 * 2 * maxK + 6], ms)); xchg_started = true; } // the links are busy from here ...
         const uint64_t base = (uint64_t)i * G * q.region;
@@ -1058,6 +1061,7 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
     r->st.materializing = mat ? 1u : 0u; r->st.materialized = 0;
     const int rc = rank_join_inner(r, Rk, Rp, nR, Sk, Sp, nS, matches, agg, mat);
     if (rc == HJ_ECAPACITY && mat) { r->stage = "idle"; return rc; } // every rank saw the same all-gathered sizes: an answer, not a failure of the group
+    if (rc == HJ_EINVAL && r->args_rejected) { r->stage = "idle"; return rc; } // ... and so is a rejected argument: all ranks learned it from the first all-gather
     if (rc) {
         if (r->err.empty()) r->err = hj_error(r->c);
         r->link->abort("rank " + std::to_string(r->rank) + " failed: " + r->err);
@@ -1070,9 +1074,14 @@ int rank_join(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR
 int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint64_t nR, const int32_t *Sk, const int32_t *Sp, uint64_t nS,
                     uint64_t *matches, uint64_t *agg, MatOut *mat) {
     hj_ctx *c = r->c;
-    if ((nR && (!Rk || !Rp)) || (nS && (!Sk || !Sp))) return r->fail(HJ_EINVAL, "null column");
-    if (mat && mat->cap && (!mat->key || !mat->payR || !mat->payS)) return r->fail(HJ_EINVAL, "output columns == NULL");
-    if ((((uintptr_t)Rk | (uintptr_t)Rp | (uintptr_t)Sk | (uintptr_t)Sp) & 15)) return r->fail(HJ_EINVAL, "device columns must be 16-byte aligned");
+    // A caller's mistake on ONE rank: the verdict travels with the first all-gather, every rank returns HJ_EINVAL naming the
+    // rank and the reason, nothing has been exchanged and the group stays usable — the link is aborted for failures, not for arguments.
+    static const char *const kBadArgs[] = {"", "null column", "output columns == NULL", "device columns must be 16-byte aligned"};
+    uint64_t bad = 0;
+    if ((nR && (!Rk || !Rp)) || (nS && (!Sk || !Sp))) bad = 1;
+    else if (mat && mat->cap && (!mat->key || !mat->payR || !mat->payS)) bad = 2;
+    else if ((((uintptr_t)Rk | (uintptr_t)Rp | (uintptr_t)Sk | (uintptr_t)Sp) & 15)) bad = 3;
+    r->args_rejected = false;
     DCHK(r, hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
     const int32_t *cols[4] = {Rk, Rp, Sk, Sp};
@@ -1082,7 +1091,7 @@ int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint6
     // nominal sizes = the largest local slice of each relation over the ranks, and whether anybody wants the exact path:
     // one small all-gather, read by the host before anything is planned (sizes decide the geometry on every rank)
     uint64_t *small = (uint64_t *)r->small.p;
-    r->h_small[0] = nR; r->h_small[1] = nS; r->h_small[2] = (r->prefer_exact || r->cfg.exact_only) ? 1 : 0;
+    r->h_small[0] = nR; r->h_small[1] = nS; r->h_small[2] = ((r->prefer_exact || r->cfg.exact_only) ? 1 : 0) | (bad << 1);
     r->h_small[3] = (r->prefer_exact || r->cfg.balance_size) ? 1 : 0; // skew was seen on these columns (or the caller asks): size-aware shards
     DCHK(r, hipMemcpyAsync(small + 16, r->h_small, 32, hipMemcpyHostToDevice, c->stream));
     LRET(r, coll_begin(r));
@@ -1094,8 +1103,12 @@ int rank_join_inner(hj_dist_rank *r, const int32_t *Rk, const int32_t *Rp, uint6
     uint64_t nmax[2] = {0, 0};
     bool exact = false, balance = false;
     for (int q = 0; q < r->world; q++) {
+        if (const uint64_t why = r->h_small[32 + 4 * q + 2] >> 1) { // (the lowest such rank: every rank reports the same one)
+            r->args_rejected = true;
+            return r->fail(HJ_EINVAL, "rank %d of %d rejected its arguments: %s (nothing was exchanged; the group stays usable)", q, r->world, kBadArgs[why < 4 ? why : 0]);
+        }
         nmax[0] = std::max(nmax[0], r->h_small[32 + 4 * q]); nmax[1] = std::max(nmax[1], r->h_small[32 + 4 * q + 1]);
-        exact |= r->h_small[32 + 4 * q + 2] != 0;
+        exact |= (r->h_small[32 + 4 * q + 2] & 1) != 0;
         balance |= r->h_small[32 + 4 * q + 3] != 0;
     }
     uint64_t out[2] = {0, 0};
@@ -1312,6 +1325,10 @@ int hj_dist_join_materialize(hj_dist *d, uint64_t *matches, uint64_t *agg, uint6
     if (n_out) for (int r = 0; r < d->world; r++) n_out[r] = r < (int)d->ranks[0]->n_out_all.size() ? d->ranks[0]->n_out_all[r] : 0;
     return soft;
 }
+
+/* tests only: rank `rank` (>= 0) of every group of this process stops taking part in its next probe-side exchange for 2.5 deadlines — a
+ * stalled peer; -1 = nobody (include/hj_dist.h, "tests only"). */
+int hj_dist_debug_stall_rank(int rank) { g_debug_stall_rank.store(rank + 1); return HJ_OK; }
 
 int hj_dist_get_stats(hj_dist *d, int rank, hj_dist_stats *out) {
     if (!d || !out || rank < 0 || rank >= d->world) return HJ_EINVAL;

@@ -449,6 +449,8 @@ bool host_level0_split(const int32_t *K, const int32_t *Pv, uint64_t n, uint32_t
 
 using namespace hj;
 
+static std::atomic<int> g_split_test_progress{0};
+
 extern "C" {
 
 int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads, int32_t *out_keys,
@@ -464,6 +466,10 @@ int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t
     return HJ_OK;
 }
 
+/* tests only: the next hj_host_split_blocks calls copy out every range the split publishes while
+ * it runs and check afterwards that it was final (HJ_EIO otherwise; *gbs then returns the tuples published). */
+int hj_host_split_debug_progress(int on) { g_split_test_progress.store(on); return HJ_OK; }
+
 uint64_t hj_host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads) {
     if (parts == 0 || parts > 4096) return 0;
     if (threads == 0) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
@@ -478,7 +484,7 @@ int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, u
     if (cap < host_split_blocks_capacity(n, parts, threads)) return HJ_ECAPACITY;
     std::vector<HostBlock> blocks;
     std::vector<uint64_t> psize;
-    // HJ_HOST_SPLIT_TEST_PROGRESS=1 (tests): take the complete prefixes the split publishes while it runs the way an uploader would —
+    // hj_host_split_debug_progress(1) (tests; an environment variable read here until round 5): take the complete prefixes the split publishes while it runs the way an uploader would —
     // copy them out at once — and check afterwards that what was copied was final
     struct Snap { uint64_t start; std::vector<int32_t> k; };
     std::vector<Snap> snaps;
@@ -490,8 +496,7 @@ int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, u
             if (d > sent[t]) { snaps.push_back(Snap{sent[t], std::vector<int32_t>(out_keys + sent[t], out_keys + d)}); sent[t] = d; }
         }
     };
-    const char *tp = getenv("HJ_HOST_SPLIT_TEST_PROGRESS");
-    const bool snooping = tp && atoi(tp) == 1;
+    const bool snooping = g_split_test_progress.load(std::memory_order_relaxed) != 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (!host_level0_split_blocks(keys, pays, n, parts, threads, out_keys, out_pays, blocks, psize, nullptr, snooping ? &snoop : nullptr)) return HJ_ENOMEM;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -206,6 +206,10 @@ int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, u
  * defines them; *seconds = wall time without the allocation of the staging columns.  No GPU involved. */
 int hj_host_join(const int32_t *keysR, const int32_t *paysR, uint64_t nR, const int32_t *keysS, const int32_t *paysS, uint64_t nS,
                  uint32_t threads, uint64_t *matches, uint64_t *agg, double *seconds);
+/* tests only: the following hj_host_split_blocks calls copy out every range the split publishes while it runs and check afterwards that
+ * it was final when published (HJ_EIO otherwise; *gbs then returns the tuples published).  0 = off (the default).  Until round 5 an
+ * environment variable read inside the public entry point. */
+int hj_host_split_debug_progress(int on);
 /* NUMA placement of the last hj_join_coprocess call (partition-primitives.cu:129-253 keeps partitions and threads per
  * socket): NUMA nodes of the host, the node closest to the context's GPU (-1 unknown: pinned staging is allocated there by
  * hipHostMalloc), and how many of that node's CPUs the split's workers were bound to (0: not bound — one node, HJ_NUMA=0). */

@@ -131,11 +131,17 @@ int hj_dist_rank_join(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp,
                       const int32_t *d_Sp, uint64_t nS, uint64_t *matches, uint64_t *agg);
 /* Collective, materialising (see hj_dist_join_materialize): this rank's output goes to its own columns (cap tuples each);
  * *n_out = tuples this rank produced, n_out_all[world] = every rank's (may be NULL), *matches / *agg global (agg NULL: not computed).
- * HJ_ECAPACITY on EVERY rank when some rank's output did not fit.  [sync] */
+ * HJ_ECAPACITY on EVERY rank when some rank's output did not fit — the group stays usable (re-bind larger columns and call again); *agg
+ * then covers only the tuples that fitted.  HJ_EINVAL on EVERY rank when some rank's arguments were bad (NULL or unaligned columns: the
+ * verdict travels with the first all-gather, nothing is exchanged, the group stays usable).  Any other error aborts the group.  [sync] */
 int hj_dist_rank_join_materialize(hj_dist_rank *r, const int32_t *d_Rk, const int32_t *d_Rp, uint64_t nR, const int32_t *d_Sk,
                                   const int32_t *d_Sp, uint64_t nS, int32_t *d_out_key, int32_t *d_out_payR, int32_t *d_out_payS,
                                   uint64_t cap, uint64_t *n_out, uint64_t *n_out_all, uint64_t *matches, uint64_t *agg);
 int hj_dist_rank_get_stats(hj_dist_rank *r, hj_dist_stats *out);
+
+/* tests only: rank `rank` (>= 0) of every group of this process stops taking part in its next probe-side exchange for 2.5 deadlines —
+ * a stalled peer (the deadline tests); -1 = nobody (the default).  Until round 5 an environment variable read inside every exchange. */
+int hj_dist_debug_stall_rank(int rank);
 
 #ifdef __cplusplus
 }

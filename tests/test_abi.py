@@ -186,8 +186,9 @@ def test_host_one_pass_block_split_parity():
             else:
                 assert op is None and np.array_equal(np.sort(got_k), np.sort(keys))
     # what the split publishes while it runs (the ranges hj_join_coprocess uploads beside the split): checked inside the library under
-    # HJ_HOST_SPLIT_TEST_PROGRESS=1 — every published range was final when published and consists of whole, full blocks
-    os.environ["HJ_HOST_SPLIT_TEST_PROGRESS"] = "1"
+    # hj_host_split_debug_progress(1) (a debug symbol, not in the header) — every published range was final when published and consists
+    # of whole, full blocks
+    p._lib.lib().hj_host_split_debug_progress(1)
     try:
         published = 0
         for n, parts, threads in ((2_000_000, 16, 4), (1_500_000, 3, 7), (900_000, 200, 2)):
@@ -198,7 +199,7 @@ def test_host_one_pass_block_split_parity():
             published += covered
         assert published > 0
     finally:
-        del os.environ["HJ_HOST_SPLIT_TEST_PROGRESS"]
+        p._lib.lib().hj_host_split_debug_progress(0)
     # the staging capacity stays in proportion: at most an eighth more than the tuples once there is a block's worth per (worker,
     # partition), and a small input does not pay for the threads and partitions it was offered (one worker per 2^16 tuples)
     cap_of = p._lib.lib().hj_host_split_blocks_capacity

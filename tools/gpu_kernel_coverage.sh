@@ -27,7 +27,7 @@ for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
         launched[name] = launched.get(name, 0) + int(row.get("Calls", 0) or 0)
 # the instances of the binary: profiles/<round>_libhj_kernels.txt (tools/kernel_sizes.sh, written in the build container from the same sources)
 dem = {}
-for line in open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "profiles", os.environ.get("ROUND", "r5") + "_libhj_kernels.txt")):
+for line in open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "profiles", os.environ.get("ROUND", "r6") + "_libhj_kernels.txt")):
     p = line.split(None, 2)
     if len(p) == 3 and p[0].isdigit():
         dem[p[2].strip()] = p[2].strip()
