@@ -447,13 +447,21 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled 
     while (nspans > 1024) { span += TILE; nspans = (R.n + span - 1) / span; }
     std::vector<uint32_t> lt1(P1), own1(512, 0xFFFFu), lines1, vbase1(P1), vcap1(P1);
     deal(fd.data(), P1, lt1, own1, lines1);
+    // the bypass that WRITES its hits as whole lines (HOT 3, below 512 digits): the hits are digit number P1 and get lines by their share
+    std::vector<uint32_t> lt1h, own1h, lines1h;
+    if (sp.hot_ready && P1 < 512) {
+        std::vector<double> fdh(fd);
+        fdh.push_back(sp.hot_share);
+        lt1h.assign(P1 + 1, 0); own1h.assign(512, 0xFFFFu);
+        deal(fdh.data(), P1 + 1, lt1h, own1h, lines1h);
+    }
     uint64_t posA = 0;
     double maxfd = 0;
     for (uint32_t d = 0; d < P1; d++) {
         double hd = 0;
         for (uint32_t q = 0; q < P2; q++) hd += h[d * P2 + q];
         const double E = (double)span * fd[d];
-        const uint64_t gran = (uint64_t)lines1[d] * 32;
+        const uint64_t gran = (uint64_t)std::max(lines1[d], lines1h.empty() ? 0u : lines1h[d]) * 32; // (a slot counts as full one granule early: the larger of the two dealings)
         uint64_t cap = (uint64_t)(E * (1.0 + relerr(hd)) + 8.0 * std::sqrt(E) + 64.0);
         cap = ((cap + gran - 1) / gran) * gran + gran;
         vbase1[d] = (uint32_t)posA; vcap1[d] = (uint32_t)cap;
@@ -534,13 +542,16 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled 
     const uint32_t nwg = (uint32_t)(wg.size() / 4), heavy1 = maxfd > 0.25 ? 1u : 0u;
     std::vector<uint32_t> tab;
     auto put = [&](const std::vector<uint32_t> &v) { while (tab.size() & 3) tab.push_back(0); const size_t at = tab.size(); tab.insert(tab.end(), v.begin(), v.end()); return at; };
+    vbase1.push_back(0); vcap1.push_back(0); // (entry P1: the hot digit of HOT 3 has no slot)
     const size_t o_vb1 = put(vbase1), o_vc1 = put(vcap1), o_lt1 = put(lt1), o_ow1 = put(own1), o_h1 = put(std::vector<uint32_t>{heavy1});
+    const size_t o_lt1h = put(lt1h), o_ow1h = put(own1h);
     const size_t o_cb2 = put(cbase2), o_c2 = put(cap2), o_lt2 = put(lt2), o_ow2 = put(own2), o_h2 = put(heavy2), o_wg = put(wg), o_rp = put(rpart), o_r0 = put(pr0), o_nr = put(pnr);
     RET(ensure(c, sp.tab, tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(sp.tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // tab is pageable
     const uint32_t *T = (const uint32_t *)sp.tab.p;
     sp.vbase1 = T + o_vb1; sp.vcap1 = T + o_vc1; sp.lt1 = T + o_lt1; sp.own1 = T + o_ow1; sp.heavy1_d = T + o_h1;
+    sp.lt1h = lt1h.empty() ? nullptr : T + o_lt1h; sp.own1h = lt1h.empty() ? nullptr : T + o_ow1h;
     sp.cbase2 = T + o_cb2; sp.cap2 = T + o_c2; sp.lt2 = T + o_lt2; sp.own2 = T + o_ow2; sp.heavy2 = T + o_h2; sp.wg2 = T + o_wg; sp.rpart = T + o_rp; sp.pr0 = T + o_r0; sp.pnr = T + o_nr;
     sp.n = R.n; sp.b1 = b1; sp.b2 = b2; sp.span = (uint32_t)span; sp.nspans = (uint32_t)nspans; sp.nwg2 = nwg; sp.nranges = nwg * P2;
     sp.sizeA = posA; sp.sizeB = posB; sp.heavy1 = heavy1 != 0; sp.any_heavy2 = any_heavy; sp.any_light2 = any_light; sp.sample_size = ns;
@@ -594,14 +605,22 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
         HIPCHK(c, hipMemsetAsync(d_cnt, 0, (size_t)HOT_SLOTS * 4, st));
         { Timed t(c, "k_hot_build"); HIPCHK(c, launch_hot_build(st, O.in_k, O.in_p, O.n, d_cand, d_cnt, d_pay, reinterpret_cast<unsigned long long *>(sc + 13))); }
         va.hot.mode = (uint32_t)c->hot_request; va.hot.cand = d_cand; va.hot.cnt = d_cnt; va.hot.pay = d_pay;
+        if (c->hot_request == 2 && sp.lt1h && c->hot_lines && P1 < 512) { // the hits leave as whole lines through LDS (HOT 3)
+            RET(ensure(c, sp.hot_tail, (size_t)sp.nspans * (32 * 8 + 4)));
+            va.hot.mode = 3; va.hot.lt3 = sp.lt1h; va.hot.own3 = sp.own1h;
+            va.hot.tail_k = (int32_t *)sp.hot_tail.p; va.hot.tail_p = va.hot.tail_k + (size_t)sp.nspans * 32;
+            va.hot.tail_n = (uint32_t *)(va.hot.tail_p + (size_t)sp.nspans * 32);
+        }
         va.hot.acc = reinterpret_cast<unsigned long long *>(sc + 13);
         va.hot.out_key = c->hot_out[0];
         va.hot.out_tab = r == HJ_REL_S ? c->hot_out[1] : c->hot_out[2]; // the other relation's payload column
         va.hot.out_str = r == HJ_REL_S ? c->hot_out[2] : c->hot_out[1];
         va.hot.out_cap = c->hot_cap;
-        va.hot.cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+        va.hot.cursor = reinterpret_cast<unsigned long long *>(sc + SC_CURSOR);
+        va.hot.stamps = c->stamps_part2; // (experiment builds: per-workgroup phase times of the bypassing pass 1, 8 words each)
     }
     { Timed t(c, "k_part1_var"); HIPCHK(c, launch_part1_var(st, fa, va, sp.heavy1)); }
+    if (va.hot.mode == 3) { Timed t(c, "k_hot_tail"); HIPCHK(c, launch_hot_tail(st, va.hot, sp.nspans)); }
     FastArgs fb{};
     fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
     fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = sp.nspans;
@@ -884,9 +903,9 @@ int plan_join(hj_ctx *c, JoinArgs &a_out, bool &tag16, bool gen_ok, bool keep_cu
     a.radix_bits = rbits; a.cap = c->cap; a.nh = c->nh; a.chunk = c->chunk;
     a.bflag = (B.fast_tried && !B.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + c->build) : nullptr;
     a.pflag = (Pb.fast_tried && !Pb.flag_known_good) ? reinterpret_cast<const uint32_t *>(sc + 8 + (1 - c->build)) : nullptr;
-    a.out_cursor = reinterpret_cast<unsigned long long *>(sc + 10);
+    a.out_cursor = reinterpret_cast<unsigned long long *>(sc + SC_CURSOR);
     a.stamps = c->stamps_join;
-    uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + 10; // (sc[12]: a word nobody reads)
+    uint64_t *const zero_cursor = keep_cursor ? sc + 12 : sc + SC_CURSOR; // (sc[12]: a word nobody reads)
     const bool atomic_plan = c->plan_atomic;
     if (nparts <= 1024 && !Pb.sampled && !general) { // one workgroup's worth of partitions: plan + scan + expand in one single-workgroup launch
         Timed t(c, "k_join_plan");
@@ -936,9 +955,9 @@ int run_count(hj_ctx *c, JoinArgs &a_out, bool &tag16, const JoinArgs *late = nu
 }
 
 int fetch_scalars(hj_ctx *c) {
-    // one 120-byte copy: the results, the overflow flags of the two relations' histogram-free passes, the output cursor, what the
-    // heavy-hitter bypass counted
-    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, 15 * 8, hipMemcpyDeviceToHost, c->stream));
+    // one copy: the results, the overflow flags of the two relations' histogram-free passes, what the heavy-hitter bypass counted, the
+    // output cursor (a 128-byte line of its own, SC_CURSOR)
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, (SC_CURSOR + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->redo_mask = 0;
     for (int r = 0; r < 2; r++) {
@@ -1063,6 +1082,7 @@ static void read_knobs(hj_ctx *c) {
     if (const char *tl = getenv("HJ_TAGS_LEGACY")) c->tags_legacy = atoi(tl) != 0;
     if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
     if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
+    if (const char *hl = getenv("HJ_HOT_LINES")) c->hot_lines = atoi(hl);
     c->debug = getenv("HJ_DEBUG") != nullptr;
 }
 
@@ -1078,11 +1098,11 @@ int hj_create(hj_ctx **out, int device) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_EHIP; }
     c->stream = c->own_stream;
-    if (hipMalloc(&c->scalars.p, 128) != hipSuccess) { delete c; return HJ_ENOMEM; }
-    c->scalars.cap = 128;
-    (void)hipMemset(c->scalars.p, 0, 128);
-    if (hipHostMalloc((void **)&c->h_scalars, 128, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
-    memset(c->h_scalars, 0, 128);
+    if (hipMalloc(&c->scalars.p, SC_BYTES) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    c->scalars.cap = SC_BYTES;
+    (void)hipMemset(c->scalars.p, 0, SC_BYTES);
+    if (hipHostMalloc((void **)&c->h_scalars, SC_BYTES, hipHostMallocDefault) != hipSuccess) { delete c; return HJ_ENOMEM; }
+    memset(c->h_scalars, 0, SC_BYTES);
     if (const char *ev = getenv("HJ_KERNEL_EVENTS")) c->events = !strcmp(ev, "all") ? 2 : (!strcmp(ev, "none") ? 0 : 1);
     read_knobs(c);
     (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
@@ -1113,7 +1133,7 @@ int hj_destroy(hj_ctx *c) {
         release(R.beg); release(R.end); release(R.s1beg); release(R.s1end);
         release(R.comp_k); release(R.comp_p); release(R.comp_off);
         release(R.sp.tab); release(R.sp.rbeg); release(R.sp.rend);
-        release(R.sph.tab); release(R.sph.rbeg); release(R.sph.rend); release(R.sph.hot_tab);
+        release(R.sph.tab); release(R.sph.rbeg); release(R.sph.rend); release(R.sph.hot_tab); release(R.sph.hot_tail);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); if (c->seg_joined[i]) (void)hipEventDestroy(c->seg_joined[i]); }
@@ -1260,7 +1280,7 @@ int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_pay
         bool tag16;
         if (c->join_planned) { // the item list of these partitions is on the device (a count ran): only the cursor is reset
             a = c->last_args; tag16 = c->last_tag16;
-            HIPCHK(c, hipMemsetAsync((uint64_t *)c->scalars.p + 10, 0, 8, c->stream));
+            HIPCHK(c, hipMemsetAsync((uint64_t *)c->scalars.p + SC_CURSOR, 0, 8, c->stream));
         } else {
             RET(plan_join(c, a, tag16));
         }
@@ -1279,7 +1299,7 @@ int materialize_local(hj_ctx *c, int32_t *d_key, int32_t *d_payR, int32_t *d_pay
         for (int r = 0; r < 2; r++)
             if (m & (1u << r)) RET(partition_rel(c, r));
     }
-    if (n_out) *n_out = c->h_scalars[10];
+    if (n_out) *n_out = c->h_scalars[SC_CURSOR];
     return 0;
 }
 
@@ -1405,7 +1425,7 @@ int join_graph(hj_ctx *c, uint64_t *matches, uint64_t *agg, bool *done) {
         JoinArgs a;
         bool tag16 = false;
         if (!rc) rc = run_count(c, a, tag16);
-        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(c->h_scalars, c->scalars.p, 15 * 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(c->h_scalars, c->scalars.p, (SC_CURSOR + 1) * 8, hipMemcpyDeviceToHost, c->stream);
         const hipError_t e2 = hipStreamEndCapture(c->stream, &gr);
         if (rc || e != hipSuccess || e2 != hipSuccess || !gr) { // not capturable: the eager path answers this call (and reports its own errors)
             if (gr) (void)hipGraphDestroy(gr);
@@ -1483,7 +1503,7 @@ static int join_and_materialize_impl(hj_ctx *c, int32_t *d_key, int32_t *d_payR,
     for (int attempt = 0; attempt < 4; attempt++) {
         // the output cursor starts at 0 BEFORE the passes: pass 1 of a skewed probe side appends the tuples of its heavy hitters, the probe
         // appends the rest behind them (plan_join leaves the cursor alone)
-        HIPCHK(c, hipMemsetAsync(sc + 10, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(sc + SC_CURSOR, 0, 8, c->stream));
         RET(partition_both(c));
         RET(hj_join_materialize_enqueue(c, d_key, d_payR, d_payS, cap, true));
         RET(fetch_scalars(c)); // [sync]
@@ -1492,7 +1512,7 @@ static int join_and_materialize_impl(hj_ctx *c, int32_t *d_key, int32_t *d_payR,
         // slots overflowed (skew): nothing of this attempt counts; the flagged relation takes its next path (sampled capacities, exact
         // passes), and BOTH are partitioned again — the tuples pass 1 wrote belong to a cursor that restarts
     }
-    if (n_out) *n_out = c->h_scalars[10];
+    if (n_out) *n_out = c->h_scalars[SC_CURSOR];
     return 0;
 }
 

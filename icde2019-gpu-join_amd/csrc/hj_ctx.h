@@ -17,6 +17,11 @@ constexpr uint64_t PAD = 16; // int32 elements of slack after every column (16-b
 constexpr uint32_t TARGET_SPANS = 1024; // 4 spans per CU: measured best (profiles/r1_spans_sweep.txt)
 constexpr uint32_t DEFAULT_CAP = 4608, DEFAULT_HEADS = 4096, DEFAULT_CHUNK = 65536;
 constexpr uint32_t TARGET_PART = 4096; // average build tuples per final partition
+// the context's device scalars (uint64 words): the OUTPUT CURSOR of the materialising kernels sits on a 128-byte line of its own, four lines
+// from the words the kernels poll (the relations' overflow flags, read by every partition workgroup every few rounds): with the cursor
+// beside them (word 10, until round 6) every reservation of the writing bypass invalidated the line the flags are read from
+constexpr uint32_t SC_CURSOR = 64;
+constexpr size_t SC_BYTES = 1024;
 
 struct KStat { std::string name; uint32_t launches = 0; float total_ms = 0, last_ms = 0; };
 struct Stamp { int kid; hipEvent_t a, b; };
@@ -74,6 +79,8 @@ struct Rel {
         // the heavy-hitter bypass (only in Rel::sph): the plan's capacities leave out the tuples pass 1 joins itself
         bool hot_ready = false;   // the candidate table is on the device
         Buf hot_tab;              // cand[HOT_SLOTS] | cnt[HOT_SLOTS] | pay[HOT_SLOTS]
+        Buf hot_tail;             // HOT 3: per pass-1 workgroup the tuples of its open hot line (keys | payloads | counts)
+        const uint32_t *lt1h = nullptr, *own1h = nullptr; // HOT 3: the LDS lines of pass 1 dealt to P1 + 1 digits (the hits are digit P1)
         uint32_t hot_keys = 0;    // candidates in the table
         double hot_share = 0;     // sampled share of the relation's tuples the bypass takes (candidates unique in the other relation)
     } sp, sph;                    // sph: the plan used when pass 1 bypasses the heavy hitters (hj_join, hj_join_and_materialize)
@@ -95,7 +102,7 @@ struct hj_ctx {
     // workspace
     struct PassWs { Buf span_start, hist, chunk_sums, chunk_prefix; } ws[2]; // per relation (passes of one relation are serial)
     Buf items_cnt, items, wave_counts, wave_agg, jchunk_sums, jchunk_prefix;
-    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [10] output cursor of k_join_mat, [12] scratch, [13],[14] matches / aggregate of the heavy-hitter bypass
+    Buf scalars;                // device u64: [0] n_items, [1] matches, [2] agg, [3] misc, [4] misc, [5..7] baselines, [8],[9] overflow flags of R, S, [SC_CURSOR = 64] output cursor of k_join_mat (a line of its own), [12] scratch, [13],[14] matches / aggregate of the heavy-hitter bypass
     uint64_t *h_scalars = nullptr; // pinned host mirror (8 x u64) + [8],[9]: the relations' overflow flags
     bool join_planned = false;     // per-wave counts + item list of the current partitions are on the device
     hj::JoinArgs last_args{};
@@ -123,6 +130,7 @@ struct hj_ctx {
     bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
     bool debug = false;             // HJ_DEBUG: stderr diagnostics
     int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)
+    int hot_lines = 1;              // HJ_HOT_LINES=0: the writing bypass stores 4 bytes per hit (HOT 2) even where it could write whole lines (HOT 3): A/B
     double hot_min_share = 0.10;    // HJ_HOT_MIN_SHARE: smallest sampled share of the relation worth the lookups
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)

@@ -855,14 +855,14 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     // the per-group results and, with the result block, the flags of this rank's kernels; [sync]
     if (mat && mat->want_agg) { // sum payR * payS over what was written (the cursor is on the device: k_dot reads it there)
         DCHK(r, hipMemsetAsync(sc + 3, 0, 8, cs));
-        DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + 10, mat->cap, sc + 3));
+        DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + SC_CURSOR, mat->cap, sc + 3));
     }
     DCHK(r, hipMemcpyAsync(r->h_small + 16, small + 20, 32, hipMemcpyDeviceToHost, cs));
     r->stage = "pipeline drained"; r->stage_rel = -1; r->stage_slice = -1;
     LRET(r, wait_stream(r, cs, "the sliced pipeline (splits, exchanges, local passes, joins)")); // every exchange is behind this: the deadline, not a blocking sync
     if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
     uint64_t m = r->h_small[16] + r->h_small[18], a = r->h_small[17] + r->h_small[19];
-    if (mat) { m = c->h_scalars[10]; a = mat->want_agg ? c->h_scalars[3] : 0; mat->n_out = m; } // the output cursor = this rank's matches
+    if (mat) { m = c->h_scalars[SC_CURSOR]; a = mat->want_agg ? c->h_scalars[3] : 0; mat->n_out = m; } // the output cursor = this rank's matches
     // one all-reduce: matches, aggregate, the two flags (a rank whose local slots overflowed must take everybody along)
     r->h_small[0] = m; r->h_small[1] = a; r->h_small[2] = c->h_scalars[8] & 0xFFFFFFFFu; r->h_small[3] = c->h_scalars[9] & 0xFFFFFFFFu;
     DCHK(r, hipMemcpyAsync(small, r->h_small, 32, hipMemcpyHostToDevice, cs));
@@ -1019,7 +1019,7 @@ int join_exact(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2
         if (mat->want_agg) {
             uint64_t *sc = (uint64_t *)c->scalars.p;
             DCHK(r, hipMemsetAsync(sc + 3, 0, 8, cs));
-            DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + 10, mat->cap, sc + 3));
+            DCHK(r, launch_dot(cs, mat->payR, mat->payS, sc + SC_CURSOR, mat->cap, sc + 3));
             if (fetch_scalars(c)) { r->err = hj_error(c); return HJ_EHIP; }
             a = c->h_scalars[3];
         }

@@ -200,8 +200,8 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
             c->join_planned = false;
             uint64_t *slot = (uint64_t *)d_seg.p + 4 * b;
             if (hipMemsetAsync(slot + 2, 0, 8, c->stream) != hipSuccess ||
-                launch_dot(c->stream, (const int32_t *)c->out_p1[b].p, (const int32_t *)c->out_p2[b].p, sc + 10, ocap, slot + 2) != hipSuccess ||
-                hipMemcpyAsync(slot, sc + 10, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                launch_dot(c->stream, (const int32_t *)c->out_p1[b].p, (const int32_t *)c->out_p2[b].p, sc + SC_CURSOR, ocap, slot + 2) != hipSuccess ||
+                hipMemcpyAsync(slot, sc + SC_CURSOR, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
                 hipMemcpyAsync(slot + 1, sc + 8 + HJ_REL_S, 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
                 hipMemcpyAsync(h_seg + 4 * b, slot, 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipEventRecord(ev_done[b], c->stream) != hipSuccess) { rc = fail(c, HJ_EHIP, "segment result"); break; }
