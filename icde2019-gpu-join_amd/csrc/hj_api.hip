@@ -447,21 +447,13 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled 
     while (nspans > 1024) { span += TILE; nspans = (R.n + span - 1) / span; }
     std::vector<uint32_t> lt1(P1), own1(512, 0xFFFFu), lines1, vbase1(P1), vcap1(P1);
     deal(fd.data(), P1, lt1, own1, lines1);
-    // the bypass that WRITES its hits as whole lines (HOT 3, below 512 digits): the hits are digit number P1 and get lines by their share
-    std::vector<uint32_t> lt1h, own1h, lines1h;
-    if (sp.hot_ready && P1 < 512) {
-        std::vector<double> fdh(fd);
-        fdh.push_back(sp.hot_share);
-        lt1h.assign(P1 + 1, 0); own1h.assign(512, 0xFFFFu);
-        deal(fdh.data(), P1 + 1, lt1h, own1h, lines1h);
-    }
     uint64_t posA = 0;
     double maxfd = 0;
     for (uint32_t d = 0; d < P1; d++) {
         double hd = 0;
         for (uint32_t q = 0; q < P2; q++) hd += h[d * P2 + q];
         const double E = (double)span * fd[d];
-        const uint64_t gran = (uint64_t)std::max(lines1[d], lines1h.empty() ? 0u : lines1h[d]) * 32; // (a slot counts as full one granule early: the larger of the two dealings)
+        const uint64_t gran = (uint64_t)lines1[d] * 32;
         uint64_t cap = (uint64_t)(E * (1.0 + relerr(hd)) + 8.0 * std::sqrt(E) + 64.0);
         cap = ((cap + gran - 1) / gran) * gran + gran;
         vbase1[d] = (uint32_t)posA; vcap1[d] = (uint32_t)cap;
@@ -542,16 +534,13 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled 
     const uint32_t nwg = (uint32_t)(wg.size() / 4), heavy1 = maxfd > 0.25 ? 1u : 0u;
     std::vector<uint32_t> tab;
     auto put = [&](const std::vector<uint32_t> &v) { while (tab.size() & 3) tab.push_back(0); const size_t at = tab.size(); tab.insert(tab.end(), v.begin(), v.end()); return at; };
-    vbase1.push_back(0); vcap1.push_back(0); // (entry P1: the hot digit of HOT 3 has no slot)
     const size_t o_vb1 = put(vbase1), o_vc1 = put(vcap1), o_lt1 = put(lt1), o_ow1 = put(own1), o_h1 = put(std::vector<uint32_t>{heavy1});
-    const size_t o_lt1h = put(lt1h), o_ow1h = put(own1h);
     const size_t o_cb2 = put(cbase2), o_c2 = put(cap2), o_lt2 = put(lt2), o_ow2 = put(own2), o_h2 = put(heavy2), o_wg = put(wg), o_rp = put(rpart), o_r0 = put(pr0), o_nr = put(pnr);
     RET(ensure(c, sp.tab, tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(sp.tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // tab is pageable
     const uint32_t *T = (const uint32_t *)sp.tab.p;
     sp.vbase1 = T + o_vb1; sp.vcap1 = T + o_vc1; sp.lt1 = T + o_lt1; sp.own1 = T + o_ow1; sp.heavy1_d = T + o_h1;
-    sp.lt1h = lt1h.empty() ? nullptr : T + o_lt1h; sp.own1h = lt1h.empty() ? nullptr : T + o_ow1h;
     sp.cbase2 = T + o_cb2; sp.cap2 = T + o_c2; sp.lt2 = T + o_lt2; sp.own2 = T + o_ow2; sp.heavy2 = T + o_h2; sp.wg2 = T + o_wg; sp.rpart = T + o_rp; sp.pr0 = T + o_r0; sp.pnr = T + o_nr;
     sp.n = R.n; sp.b1 = b1; sp.b2 = b2; sp.span = (uint32_t)span; sp.nspans = (uint32_t)nspans; sp.nwg2 = nwg; sp.nranges = nwg * P2;
     sp.sizeA = posA; sp.sizeB = posB; sp.heavy1 = heavy1 != 0; sp.any_heavy2 = any_heavy; sp.any_light2 = any_light; sp.sample_size = ns;
@@ -605,12 +594,6 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
         HIPCHK(c, hipMemsetAsync(d_cnt, 0, (size_t)HOT_SLOTS * 4, st));
         { Timed t(c, "k_hot_build"); HIPCHK(c, launch_hot_build(st, O.in_k, O.in_p, O.n, d_cand, d_cnt, d_pay, reinterpret_cast<unsigned long long *>(sc + 13))); }
         va.hot.mode = (uint32_t)c->hot_request; va.hot.cand = d_cand; va.hot.cnt = d_cnt; va.hot.pay = d_pay;
-        if (c->hot_request == 2 && sp.lt1h && c->hot_lines && P1 < 512) { // the hits leave as whole lines through LDS (HOT 3)
-            RET(ensure(c, sp.hot_tail, (size_t)sp.nspans * (32 * 8 + 4)));
-            va.hot.mode = 3; va.hot.lt3 = sp.lt1h; va.hot.own3 = sp.own1h;
-            va.hot.tail_k = (int32_t *)sp.hot_tail.p; va.hot.tail_p = va.hot.tail_k + (size_t)sp.nspans * 32;
-            va.hot.tail_n = (uint32_t *)(va.hot.tail_p + (size_t)sp.nspans * 32);
-        }
         va.hot.acc = reinterpret_cast<unsigned long long *>(sc + 13);
         va.hot.out_key = c->hot_out[0];
         va.hot.out_tab = r == HJ_REL_S ? c->hot_out[1] : c->hot_out[2]; // the other relation's payload column
@@ -620,7 +603,6 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
         va.hot.stamps = c->stamps_part2; // (experiment builds: per-workgroup phase times of the bypassing pass 1, 8 words each)
     }
     { Timed t(c, "k_part1_var"); HIPCHK(c, launch_part1_var(st, fa, va, sp.heavy1)); }
-    if (va.hot.mode == 3) { Timed t(c, "k_hot_tail"); HIPCHK(c, launch_hot_tail(st, va.hot, sp.nspans)); }
     FastArgs fb{};
     fb.keys = (const int32_t *)R.a_k.p; fb.pays = (const int32_t *)R.a_p.p;
     fb.sbeg = (const uint64_t *)R.s1beg.p; fb.send = (const uint64_t *)R.s1end.p; fb.nparents = P1; fb.spp = sp.nspans;
@@ -1082,7 +1064,6 @@ static void read_knobs(hj_ctx *c) {
     if (const char *tl = getenv("HJ_TAGS_LEGACY")) c->tags_legacy = atoi(tl) != 0;
     if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
     if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
-    if (const char *hl = getenv("HJ_HOT_LINES")) c->hot_lines = atoi(hl);
     c->debug = getenv("HJ_DEBUG") != nullptr;
 }
 
@@ -1133,7 +1114,7 @@ int hj_destroy(hj_ctx *c) {
         release(R.beg); release(R.end); release(R.s1beg); release(R.s1end);
         release(R.comp_k); release(R.comp_p); release(R.comp_off);
         release(R.sp.tab); release(R.sp.rbeg); release(R.sp.rend);
-        release(R.sph.tab); release(R.sph.rbeg); release(R.sph.rend); release(R.sph.hot_tab); release(R.sph.hot_tail);
+        release(R.sph.tab); release(R.sph.rbeg); release(R.sph.rend); release(R.sph.hot_tab);
     }
     for (int i = 0; i < 2; i++) { release(c->ws[i].span_start); release(c->ws[i].hist); release(c->ws[i].chunk_sums); release(c->ws[i].chunk_prefix); }
     for (int i = 0; i < 2; i++) { release(c->seg_k[i]); release(c->seg_p[i]); release(c->cop_k[i]); release(c->cop_p[i]); if (c->seg_ready[i]) (void)hipEventDestroy(c->seg_ready[i]); if (c->seg_joined[i]) (void)hipEventDestroy(c->seg_joined[i]); }

@@ -79,8 +79,6 @@ struct Rel {
         // the heavy-hitter bypass (only in Rel::sph): the plan's capacities leave out the tuples pass 1 joins itself
         bool hot_ready = false;   // the candidate table is on the device
         Buf hot_tab;              // cand[HOT_SLOTS] | cnt[HOT_SLOTS] | pay[HOT_SLOTS]
-        Buf hot_tail;             // HOT 3: per pass-1 workgroup the tuples of its open hot line (keys | payloads | counts)
-        const uint32_t *lt1h = nullptr, *own1h = nullptr; // HOT 3: the LDS lines of pass 1 dealt to P1 + 1 digits (the hits are digit P1)
         uint32_t hot_keys = 0;    // candidates in the table
         double hot_share = 0;     // sampled share of the relation's tuples the bypass takes (candidates unique in the other relation)
     } sp, sph;                    // sph: the plan used when pass 1 bypasses the heavy hitters (hj_join, hj_join_and_materialize)
@@ -130,7 +128,6 @@ struct hj_ctx {
     bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
     bool debug = false;             // HJ_DEBUG: stderr diagnostics
     int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)
-    int hot_lines = 1;              // HJ_HOT_LINES=0: the writing bypass stores 4 bytes per hit (HOT 2) even where it could write whole lines (HOT 3): A/B
     double hot_min_share = 0.10;    // HJ_HOT_MIN_SHARE: smallest sampled share of the relation worth the lookups
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)

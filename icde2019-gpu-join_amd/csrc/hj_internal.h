@@ -130,18 +130,14 @@ uint32_t fast_slot_cap(uint64_t expected, uint32_t P);
 constexpr uint32_t HOT_SLOTS = 1024;
 constexpr int32_t HOT_NEVER = INT32_MIN; // never a candidate (the sentinel of the sampling table)
 struct HotArgs {
-    uint32_t mode = 0;           // 0 off, 1 count, 2 emit (4-byte stores per hit), 3 emit (whole lines through LDS)
+    uint32_t mode = 0;           // 0 off, 1 count, 2 emit
     const uint32_t *cand = nullptr, *cnt = nullptr; // [HOT_SLOTS] candidate keys (a filler never maps to its own slot) / tuples of the other relation per candidate
     const int32_t *pay = nullptr;                   // [HOT_SLOTS] payload of one such tuple
     unsigned long long *acc = nullptr;              // mode 1: {matches, aggregate}
     int32_t *out_key = nullptr, *out_tab = nullptr, *out_str = nullptr; // mode 2: output columns (key, the other relation's payload, this relation's payload)
     uint64_t out_cap = 0;
     unsigned long long *cursor = nullptr;
-    // mode 3 (mode 2's output written as whole lines; pass-1 fan-out < 512): the hits are digit number P with LDS lines of their own
-    const uint32_t *lt3 = nullptr, *own3 = nullptr;  // lines dealt to P + 1 digits: (lines << 16 | first line) [P + 1], owner digit per LDS line [512]
-    int32_t *tail_k = nullptr, *tail_p = nullptr;    // [spans * 32] what a workgroup's open hot line held at the end (key, this relation's payload)
-    uint32_t *tail_n = nullptr;                      // [spans] ... and how many
-    unsigned long long *stamps = nullptr;            // experiment builds (-DHJ_STAMPS): per workgroup {ticks in phase A, B, C, hot flush, rounds, -, -, -}
+    unsigned long long *stamps = nullptr;            // experiment builds (-DHJ_STAMPS): per workgroup {ticks in phase A, B, C, waiting at the end of C, rounds, -, -, -}
 };
 __host__ __device__ inline uint32_t hot_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 22; }
 static_assert(HOT_SLOTS == 1024, "hot_slot yields 10 bits");
@@ -156,7 +152,6 @@ struct VarArgs {
 };
 hipError_t launch_hot_sample(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t *tkey, uint32_t *tcnt, uint32_t slots);
 hipError_t launch_hot_collect(hipStream_t st, const uint32_t *tkey, const uint32_t *tcnt, uint32_t slots, uint32_t thr, uint2 *out, uint32_t *nout, uint32_t cap);
-hipError_t launch_hot_tail(hipStream_t st, const HotArgs &h, uint32_t nspans);
 hipError_t launch_hot_build(hipStream_t st, const int32_t *keys, const int32_t *pays, uint64_t n, const uint32_t *cand, uint32_t *cnt, int32_t *pay, unsigned long long *zero_acc);
 hipError_t launch_sample_joint(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t bits, uint32_t stride, uint32_t *hist, uint64_t *sampled,
                                const uint32_t *hot_cand = nullptr, const uint32_t *hot_cnt = nullptr);

@@ -282,13 +282,8 @@ __device__ __forceinline__ uint32_t slot_lines(const FastGeom &g, uint32_t d) { 
 // (matches and payload products, one atomic pair per workgroup at the end).  HOT 2: written to the join's output columns — the hits of
 // round r are ranked by ballots, the workgroup reserves their exact number on the output cursor with ONE returning atomic issued in
 // phase B, and they are written at the start of round r + 1 (the atomic has phases B and C to return; the tuples are still in kk/pp).
-// HOT 3 (VAR only: P < 512): the same output, written as WHOLE 128-byte lines.  The hits are digit number P: they take slots in LDS lines
-// dealt to that digit like any other (ranked with one ballot-aggregated atomic per wave instruction), and every round the digit's full
-// lines leave as 16-byte stores to the OUTPUT columns — key, this relation's payload, and the other relation's payload looked up per
-// tuple — at a position the digit's owner thread reserved on the output cursor in phase B (whole lines only: the cursor stays a multiple
-// of 32 while pass 1 runs; the atomic returns under the flush of the ordinary lines).  What is left in the digit's open line at the end
-// (< 32 tuples per workgroup) goes to a side buffer that k_hot_tail appends.  HOT 2 writes 4 bytes per active lane in 24 store instructions
-// per wave and round; this writes the same tuples in ~2 (config 4's pass 1: 10.3 -> see profiles/r6_hot_*).
+// (HOT 3, round 6, removed: the hits as digit number P through the LDS lines, whole-line stores to the output, one reservation per round by
+// the digit's owner — every hit pays phases B and C again: 8.8 ms against HOT 2's 8.35 on config 4, profiles/r6_hot_bypass.txt.)
 template <int U, int KFIX, int SRC, bool EXACT = false, bool HEAVY = false, bool VAR = false, int MODE = 0, int HOT = 0>
 __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restrict__ keys, const int32_t *__restrict__ pays,
                                         uint64_t lo64, uint64_t hi64, uint64_t nalloc, uint32_t nseg, uint32_t shift,
@@ -297,7 +292,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                                         uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf,
                                         const uint32_t *__restrict__ remap = nullptr, const HotArgs *hotp = nullptr) {
     static_assert(HOT == 0 || (SRC == 0 && !EXACT && MODE == 0), "the bypass belongs to pass 1 of the histogram-free passes");
-    static_assert(HOT != 3 || (VAR && !HEAVY), "the hot digit takes dealt lines");
     int2 *buf = L_.buf;
     uint32_t *hh = L_.hh, *line = L_.line;
     const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)MAX_PARTS / P);
@@ -464,15 +458,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                 }
             if (HOT == 1) hcnt += (uint32_t)__popc(hw);
         }
-        uint32_t oh[HOT == 3 ? U * 4 : 1]; // HOT 3: what the leader of each tuple slot's hits got back (issued first: see below)
-        if (HOT == 3) {
-#pragma unroll
-            for (int j = 0; j < U * 4; j++) {
-                const uint64_t m = __ballot((hw >> j) & 1u);
-                oh[j] = 0;
-                if (m && ln == (uint32_t)__builtin_ctzll(m)) oh[j] = atomicAdd(&h[P], (uint32_t)__popcll(m));
-            }
-        }
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
@@ -486,19 +471,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                                            : atomicAdd(&h[valid ? d : (uint32_t)MAX_PARTS + ln], 1u); // invalid: a trash counter
                 code[u * 4 + e] = valid ? ((d << 16) | ((old >> 16) + (old & 0xFFFFu))) : WF_NONE;
             }
-        if (HOT == 3) { // the hits are digit P: ONE atomic per wave instruction for all of them (they share the counter), ranked by the ballot.
-                        // The eight leader atomics were issued in front of the ordinary ranks; the leader's value comes back by v_readlane
-                        // (the leader's lane number is wave-uniform), not through LDS.
-#pragma unroll
-            for (int j = 0; j < U * 4; j++) {
-                const bool hit = (hw >> j) & 1u;
-                const uint64_t m = __ballot(hit);
-                if (m) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)oh[j], __builtin_ctzll(m));
-                    if (hit) code[j] = (P << 16) | ((o >> 16) + (o & 0xFFFFu) + (uint32_t)__popcll(m & (((uint64_t)1 << ln) - 1)));
-                }
-            }
-        }
         if (HOT == 2 && ln == 0) hwtot[wv] = htot;
         __syncthreads();
 #ifdef HJ_STAMPS
@@ -525,18 +497,9 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         uint32_t hw[U * 4];
 #pragma unroll
         for (int j = 0; j < U * 4; j++) hw[j] = h[code[j] != WF_NONE ? code[j] >> 16 : 0u]; // all LDS reads first
-        if (tid < P + (HOT == 3 ? 1u : 0u)) { // next round's counter starts at the fill the digit's open line will have
+        if (tid < P) { // next round's counter starts at the fill the digit's open line will have
             const uint32_t w = h[tid];
             hprev[tid] = (((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1)) << 16;
-            if (HOT == 3 && tid == P) { // the hot digit's full lines of this round: their place in the output, reserved now, awaited in phase C
-                const uint32_t fullh = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1), caph = (L_.lt[P] >> 16) * WC_LINE;
-                const uint32_t nlh = (fullh < caph ? fullh : caph) / WC_LINE;
-#if defined(HJ_EXP) && HJ_EXP == 3
-                hres = 0ull;
-#else
-                hres = nlh ? atomicAdd(hotp->cursor, (unsigned long long)nlh * WC_LINE) : 0ull;
-#endif
-            }
         }
         bool any_bypass = false;
 #pragma unroll
@@ -568,7 +531,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                         const uint32_t d = c >> 16, q = c & 0xFFFFu;
                         const uint32_t full = ((hw[j] >> 16) + (hw[j] & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
                         if (q < full && q >= (VAR ? (L_.lt[d] >> 16) * WC_LINE : capS)) {
-                            if (HOT == 3 && d == P) { *ovf = 4u; continue; } // more hits in one round than the hot digit has lines: the attempt is void (the plain sampled path redoes it)
                             const uint64_t o = (uint64_t)line[d] * WC_LINE + q;
                             if (EXACT || o < (uint64_t)(slot_line(g, d) + slot_lines(g, d)) * WC_LINE) { out_keys[o] = elem(kk[u], e); out_pays[o] = elem(pp[u], e); }
                             else *ovf = 2u;
@@ -620,44 +582,8 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             }
         }
 #ifdef HJ_STAMPS
-        unsigned long long ts3 = HOT ? hj_now() : 0ull;
+        const unsigned long long ts3 = HOT ? hj_now() : 0ull; // (ts3 .. ts4: this wave waits for the other waves' lines)
 #endif
-        if (HOT == 3) { // the hot digit's full lines: 8 lanes per line, every wave takes every 16th group of 8 lines
-            if (tid == P) line[P] = (uint32_t)(hres / WC_LINE);
-            __syncthreads();
-#ifdef HJ_STAMPS
-            ts3 = hj_now(); // (the wait for the reservation and the other waves' ordinary lines counts as phase C)
-#endif
-            const uint32_t wh = h[P], lth = L_.lt[P];
-            uint32_t nfh = ((wh >> 16) + (wh & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
-            const uint32_t caph = (lth >> 16) * WC_LINE;
-            nfh = (nfh < caph ? nfh : caph) / WC_LINE;
-            const uint32_t c4 = (ln & 7u) * 4;
-#if defined(HJ_EXP) && HJ_EXP == 4
-            nfh = 0;
-#endif
-            for (uint32_t t = wv * 8; t < nfh; t += (WC_THREADS / 64) * 8) {
-                const uint32_t idx = t + (ln >> 3);
-                if (idx < nfh) {
-                    const uint32_t ls = (lth & 0xFFFFu) + idx;
-                    const uint64_t gpos = ((uint64_t)line[P] + idx) * WC_LINE + c4;
-                    const int4 x = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4);
-                    const int4 y = *reinterpret_cast<const int4 *>(buf + ls * WC_LINE + c4 + 2);
-                    const int4 kq = make_int4(x.x, x.z, y.x, y.z), pq = make_int4(x.y, x.w, y.y, y.w);
-                    const int4 tq = make_int4((int)hk2[hot_slot((uint32_t)kq.x)].y, (int)hk2[hot_slot((uint32_t)kq.y)].y, (int)hk2[hot_slot((uint32_t)kq.z)].y,
-                                              (int)hk2[hot_slot((uint32_t)kq.w)].y);
-                    if (gpos + 4 <= hotp->out_cap) {
-                        *reinterpret_cast<int4 *>(hotp->out_key + gpos) = kq;
-                        *reinterpret_cast<int4 *>(hotp->out_str + gpos) = pq;
-                        *reinterpret_cast<int4 *>(hotp->out_tab + gpos) = tq;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (gpos + e < hotp->out_cap) { hotp->out_key[gpos + e] = elem(kq, e); hotp->out_str[gpos + e] = elem(pq, e); hotp->out_tab[gpos + e] = elem(tq, e); }
-                    }
-                }
-            }
-        }
         __syncthreads();
 #ifdef HJ_STAMPS
         if (HOT) { const unsigned long long ts4 = hj_now(); stA += ts1 - ts0; stB += ts2 - ts1; stC += ts3 - ts2; stH += ts4 - ts3; }
@@ -711,14 +637,6 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             if (ln < (uint32_t)WC_LINE) out_keys[(uint64_t)line[d] * WC_LINE + s] = v.x;
             else out_pays[(uint64_t)line[d] * WC_LINE + s] = v.y;
         }
-    }
-    if (HOT == 3 && wv == 0) { // what is left in the hot digit's open line: to the side buffer k_hot_tail appends from
-        const uint32_t w = hlast[P], cur = ((w >> 16) + (w & 0xFFFFu)) & (uint32_t)(WC_LINE - 1);
-        if (ln < cur) {
-            const int2 v = buf[(L_.lt[P] & 0xFFFFu) * WC_LINE + ln];
-            hotp->tail_k[(size_t)blockIdx.x * WC_LINE + ln] = v.x; hotp->tail_p[(size_t)blockIdx.x * WC_LINE + ln] = v.y;
-        }
-        if (ln == 0) hotp->tail_n[blockIdx.x] = cur;
     }
     if (!EXACT && tid < P) {
         const uint32_t slot = g.slotA + tid * g.slotB;
@@ -947,47 +865,15 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     FastGeom g{s, a.nspans, 0};
     g.vbase = v.vbase; g.vcap = v.vcap; g.voff = 0; g.vs = s;
     for (uint32_t d = tid; d < 2 * WC_HSTRIDE; d += WC_THREADS) L_.hh[d] = 0;
-    const uint32_t *lt_g = HOT == 3 ? v.hot.lt3 : v.lt, *own_g = HOT == 3 ? v.hot.own3 : v.own; // HOT 3: lines dealt to P + 1 digits (the hits are digit P)
-    if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = lt_g[tid]; }
-    if (HOT == 3 && tid == a.P) { L_.line[tid] = 0; L_.lt[tid] = lt_g[tid]; }
-    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = own_g[tid];
+    if (tid < a.P) { L_.line[tid] = slot_line(g, tid); L_.lt[tid] = v.lt[tid]; }
+    if (tid < (uint32_t)MAX_PARTS) L_.own[tid] = v.own[tid];
     if (tid == 0) L_.wlist[(WC_THREADS / 64) * 32] = 0;
     if (HOT) hot_load(L_.hk, v.hot.cand, v.hot.cnt, v.hot.pay);
     __syncthreads();
     // 512 digits: every digit has exactly one of the 512 lines, there is nothing to deal — the fixed-geometry rounds (no per-digit
     // line table in the inner loops) with the sampled slot capacities (a 512-way pass under skew: 9.8 -> see r4_sampled_16_17_bits.txt)
-    if (HOT == 3) { wc_fast<U, 0, 0, false, false, true, 0, 3>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot); return; } // (the host asks for it below 512 digits only)
-    constexpr int H12 = HOT == 3 ? 2 : HOT;
-    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0, H12>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
-    else wc_fast<U, 0, 0, false, HEAVY, true, 0, H12>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
-}
-
-// HOT 3's leftovers: per pass-1 workgroup up to 31 hot tuples that did not fill a line.  They are appended behind the lines pass 1 wrote
-// (one exact reservation per workgroup of this kernel; the cursor stops being a multiple of 32 here, after the last whole line).
-__global__ __launch_bounds__(256) void k_hot_tail(HotArgs h, uint32_t nspans) {
-    __shared__ uint32_t wtot[4];
-    __shared__ unsigned long long base;
-    const uint32_t span = blockIdx.x * 8 + (threadIdx.x >> 5), i = threadIdx.x & 31u, wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-    uint32_t cnt = span < nspans ? h.tail_n[span] : 0u;
-    if (cnt > (uint32_t)WC_LINE) cnt = WC_LINE; // (a pass-1 workgroup that gave up wrote nothing: whatever is there, stay inside the buffer)
-    const bool valid = i < cnt;
-    const uint64_t m = __ballot(valid);
-    if (ln == 0) wtot[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) { const uint32_t t = wtot[0] + wtot[1] + wtot[2] + wtot[3]; base = t ? atomicAdd(h.cursor, (unsigned long long)t) : 0ull; }
-    __syncthreads();
-    if (!valid) return;
-    uint64_t pos = base + (uint32_t)__popcll(m & (((uint64_t)1 << ln) - 1));
-    for (uint32_t w = 0; w < wv; w++) pos += wtot[w];
-    if (pos >= h.out_cap) return;
-    const uint32_t key = (uint32_t)h.tail_k[(size_t)span * WC_LINE + i], sl = hot_slot(key);
-    h.out_key[pos] = (int32_t)key;
-    h.out_str[pos] = h.tail_p[(size_t)span * WC_LINE + i];
-    h.out_tab[pos] = h.pay[sl]; // (a hit by construction: cand[sl] == key and cnt[sl] == 1 when pass 1 took it)
-}
-hipError_t launch_hot_tail(hipStream_t st, const HotArgs &h, uint32_t nspans) {
-    hipLaunchKernelGGL(k_hot_tail, dim3((nspans + 7) / 8), dim3(256), 0, st, h, nspans);
-    return hipGetLastError();
+    if (a.P == (uint32_t)MAX_PARTS) wc_fast<U, 1, 0, false, HEAVY, false, 0, HOT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
+    else wc_fast<U, 0, 0, false, HEAVY, true, 0, HOT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
 }
 
 // ---- the heavy-hitter bypass: finding the candidates (once per binding) and what the other relation holds for them (every step) ----
@@ -1477,15 +1363,13 @@ hipError_t launch_part1_fast(hipStream_t st, const FastArgs &fa) {
 }
 
 hipError_t launch_part1_var(hipStream_t st, const FastArgs &fa, const VarArgs &va, bool heavy) {
-    static bool set[5][64] = {};
+    static bool set[4][64] = {};
     hipError_t e;
 #define HJ_P1V(IDX, HV, HT) do { auto fn = k_part1_var<2, HV, HT>; if ((e = fast_attr(fn, set[IDX])) != hipSuccess) return e; \
         hipLaunchKernelGGL(fn, dim3(fa.nspans), dim3(WC_THREADS), fast_lds_bytes(), st, fa, va); } while (0)
     if (va.hot.mode && heavy) return hipErrorInvalidValue; // (the host does not bypass where the residue still has a dominant digit)
-    if (va.hot.mode == 3 && fa.P >= (uint32_t)MAX_PARTS) return hipErrorInvalidValue; // (512 digits leave no line for the hits: the host asks for mode 2 there)
     if (va.hot.mode == 1) HJ_P1V(2, false, 1);
     else if (va.hot.mode == 2) HJ_P1V(3, false, 2);
-    else if (va.hot.mode == 3) HJ_P1V(4, false, 3);
     else if (heavy) HJ_P1V(0, true, 0);
     else HJ_P1V(1, false, 0);
 #undef HJ_P1V

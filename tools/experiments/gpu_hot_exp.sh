@@ -1,11 +1,11 @@
 #!/bin/bash
-# attribution builds of the writing bypass (make exp EXP="1 2 3 4": hj_part.hip under -DHJ_EXP=n): kernel time of pass 1 with one piece removed
-# 1: HOT 2 without the cursor atomic   2: HOT 2 without hot_emit   3: HOT 3 without the cursor atomic   4: HOT 3 without the hot flush
+# attribution builds of the writing bypass (make exp EXP="1 2 5 6": hj_part.hip under -DHJ_EXP=n): kernel time of pass 1 with one piece changed
+# 1: without the cursor atomic   2: without hot_emit   5: the atomic on a word of the workgroup's own   6: the atomic on the cursor, result unused
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/hotexp
 P=icde2019-gpu-join_amd
 cp $P/libhj.so $P/libhj_shipped.so
-for n in ${VARIANTS:-0 1 2 3 4}; do
+for n in ${VARIANTS:-0 1 2 5 6}; do
   if [ $n = 0 ]; then cp $P/libhj_shipped.so $P/libhj.so; else cp $P/libhj_exp$n.so $P/libhj.so; fi
   touch $P/libhj.so $P/bench
   echo "== variant $n"

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/experiments/hot_phases.py [log2R] [log2S] — where a round of the bypassing pass 1 spends its time (config 4: 27 31): phase A (kept
 stores, table lookups, ranks), B (placement), C (flush of the ordinary lines; HOT 3: + the wait for the reservation), and the hot flush, as
-s_memrealtime ticks summed per workgroup by a -DHJ_STAMPS build (gpu_hot_phases.sh).  One JSON line per mode: count (HOT 1), write with
-4-byte stores (HOT 2: HJ_HOT_LINES=0) and write as whole lines (HOT 3)."""
+s_memrealtime ticks summed per workgroup by a -DHJ_STAMPS build (gpu_hot_phases.sh).  One JSON line per mode: count (HOT 1), write (HOT 2), and
+write with capacity 0 (every kernel runs, no output tuple is stored)."""
 import json
 import os
 import sys
@@ -46,7 +46,7 @@ def main():
         kt = hj.timings()
         k = kt.get("k_part1_var", {"launches": 1, "total_ms": 0})
         print(json.dumps({"mode": name, "workgroups": int(len(a)), "rounds_per_workgroup": int(np.median(r)) if len(a) else None,
-                          "us_per_round": {"A": us(0), "B": us(1), "C": us(2), "hot_flush": us(3), "sum": round(us(0) + us(1) + us(2) + us(3), 3)} if len(a) else None,
+                          "us_per_round": {"A": us(0), "B": us(1), "C": us(2), "wait_at_end_of_C": us(3), "sum": round(us(0) + us(1) + us(2) + us(3), 3)} if len(a) else None,
                           "k_part1_var_ms": round(k["total_ms"] / max(1, k["launches"]), 3), "hot": hj.hot_stats()}))
 
     def nostore():   # capacity 0: every kernel runs, no output tuple is stored (the call reports HJ_ECAPACITY with the true size)
@@ -57,13 +57,8 @@ def main():
         return expect
 
     for name, env, fn in (("count (HOT 1)", None, lambda: hj.join()[0]),
-                          ("write, whole lines, NO output stores (HOT 3, capacity 0)", "1", nostore),
-                          ("write, 4-byte stores, NO output stores (HOT 2, capacity 0)", "0", nostore),
-                          ("write, whole lines (HOT 3)", "1", lambda: hj.join_and_materialize_into(out[0], out[1], out[2], expect)),
-                          ("write, 4-byte stores (HOT 2)", "0", lambda: hj.join_and_materialize_into(out[0], out[1], out[2], expect))):
-        if env is not None:
-            os.environ["HJ_HOT_LINES"] = env
-            hj.reload_knobs()
+                          ("write, NO output stores (HOT 2, capacity 0)", None, nostore),
+                          ("write (HOT 2)", None, lambda: hj.join_and_materialize_into(out[0], out[1], out[2], expect))):
         got = fn()
         assert got == expect or os.environ.get("HOT_PHASES_NOCHECK"), (got, expect)
         st.zero_()
