@@ -72,21 +72,23 @@ def results_rows():
     out = ["| workload (BASELINE config) | Gtuples/s: median of three processes [min–max] (evidence call) | ms/step | dominant pass kernel; probe | materialising variant | CPU baseline |",
            "|---|---|---|---|---|---|"]
     p, c = b30["probe_phase"], b30["cpu_baseline"]
-    out.append("| **3: 2^30 ⋈ 2^30 unique uniform int32, count-only (headline)** | **%.1f** %s(%.1f; driver r4 141.8, r3 140.9, r2 124.3) | %.2f (%.2f) | %s; `k_join` %.2f ms = %.2f of 8 TB/s (target %.2f) | %s | "
-               "%.3f (radix port, %d threads, %s); `joinCpu` port %.3f at 2^22 |"
+    out.append("| **3: 2^30 ⋈ 2^30 unique uniform int32, count-only (headline)** | **%.1f** %s(%.1f; driver r5 137.2, r4 141.8, r3 140.9, r2 124.3) | %.2f (%.2f) | %s; `k_join` %.2f ms = %.2f of 8 TB/s (target %.2f) | %s | "
+               "%.3f (port of the reference's scheme, %d threads, %s); %.2f (the library's own host code, `hj_host_join`, same input and threads); `joinCpu` port %.3f at 2^22 |"
                % (b30["value"], tp(b30), e30["value"], b30["ms_per_step"], e30["ms_per_step"], roof(b30), p["avg_launch_ms"], p["frac_of_8TBs"], p["target_frac"], mat(b30),
-                  c["value"], c["cores"], "full size" if "full size" in c["sample"] else "bounded sample", c["joinCpu"]["value"]))
+                  c["value"], c["cores"], "full size" if "full size" in c["sample"] else "bounded sample", (c.get("best_effort") or {}).get("value", float("nan")), c["joinCpu"]["value"]))
     out.append("| 3, exact (histogram) passes only | %.1f | %.2f | `k_scatter_wc` + `k_hist` | | |" % (bx["value"], bx["ms_per_step"]))
     p, c = b27["probe_phase"], b27["cpu_baseline"]
-    out.append("| **2: 2^27 ⋈ 2^27, default 9+6 bits** | **%.1f** %s(%.1f; r4 127.7) | %.2f (%.2f) | %s; `k_join` %.3f ms = %.2f (target %.3f from the fixed-cost model: %s) | %s | %.3f |"
+    out.append("| **2: 2^27 ⋈ 2^27, default 9+6 bits** | **%.1f** %s(%.1f; r5 124.7, r4 127.7) | %.2f (%.2f) | %s; `k_join` %.3f ms = %.2f (target %.3f from the measured fixed cost: %s) | %s | %.3f; own host code %.2f |"
                % (b27["value"], tp(b27), e27["value"], b27["ms_per_step"], e27["ms_per_step"], roof(b27), p["avg_launch_ms"], p["frac_of_8TBs"], p["target_frac"],
-                  "met" if p["meets_target"] else "NOT met", mat(b27), c["value"]))
+                  "met" if p["meets_target"] else "NOT met", mat(b27), c["value"], (c.get("best_effort") or {}).get("value", float("nan"))))
     s = b27.get("config2_as_stated") or {}
     if s:
         out.append("| 2 AS STATED in configs[1]: ONE 9-bit pass | %.1f | %.2f | 2^18-tuple partitions rebuild the LDS table ~60 × each: why the default is two passes | | |" % (s["value"], s["ms_per_step"]))
     p, c = bz["probe_phase"], bz["cpu_baseline"]
-    out.append("| **4: PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0, count-only** | **%.1f** %s(%.1f; r4 126.0) | %.2f (%.2f) | S: `k_part1_var` %.2f + `k_part2_var` %.2f ms (sampled capacities, no histogram); %s; `k_join` %.2f ms = %.2f | %s | %.3f (bounded PK–FK Zipf sample, %d threads) |"
-               % (bz["value"], tp(bz), ez["value"], bz["ms_per_step"], ez["ms_per_step"], kms(bz, "k_part1_var"), kms(bz, "k_part2_var"), roof(bz), p["avg_launch_ms"], p["frac_of_8TBs"], mat(bz),
+    hb = (bz["config"].get("heavy_hitter_bypass") or {})
+    out.append("| **4: PK–FK 2^27 ⋈ 2^31, Zipf θ=1.0, count-only** | **%.1f** %s(%.1f; r5 126.6, r4 126.0) | %.2f (%.2f) | heavy-hitter bypass: %d keys = %.1f %% of S joined by pass 1 itself (§3.8); S: `k_hot_build` %.2f + `k_part1_var` %.2f + `k_part2_var` %.2f ms (sampled capacities, no histogram); %s; `k_join` %.2f ms = %.2f | %s (hj_join_and_materialize: pass 1 writes the hot keys' tuples) | %.3f (bounded PK–FK Zipf sample, %d threads) |"
+               % (bz["value"], tp(bz), ez["value"], bz["ms_per_step"], ez["ms_per_step"], hb.get("keys", 0), 100.0 * hb.get("matches", 0) / float(1 << 31),
+                  kms(bz, "k_hot_build") if "k_hot_build" in bz["kernels"] else 0.0, kms(bz, "k_part1_var"), kms(bz, "k_part2_var"), roof(bz), p["avg_launch_ms"], p["frac_of_8TBs"], mat(bz),
                   c["value"], c["cores"]))
     out.append("| 4, exact passes only | %.1f | %.2f | `k_scatter_wc` + `k_hist` | | |" % (bzx["value"], bzx["ms_per_step"]))
     f = bz["first_call_split_ms"]
@@ -103,23 +105,28 @@ def results_rows():
                % (b["perfect array"]["Gtuples_per_s"], b["global chained table"]["Gtuples_per_s"], b["partitioned (radix + LDS tables)"]["Gtuples_per_s"]))
     mm = m8["dist"]["model"]
     mt = (m8.get("materialize") or {}).get("model") or {}
-    out.append("| 5: 2^33 ⋈ 2^33 over 8 GPUs | measured by the driver (`bench.py --gpus 8`: headline over RCCL + materialising join + strong-scaling point + both transports); "
-               "modelled from one-GPU stage times (NOT a measurement): %.1f per GPU count-only%s | %.1f modelled | link-bound: %.1f ms of links, %.1f ms of local work of which %.1f exposed | | |"
+    out.append("| 5: 2^33 ⋈ 2^33 over 8 GPUs | **not yet measured** (no multi-GPU node has run it; `tools/multigpu_session.sh` is the one command for the first session: RCCL tests, "
+               "`bench.py --gpus 2/4/8` = headline + materialising join + strong-scaling point + both transports); modelled from one-GPU stage times (NOT a measurement): %.1f per GPU "
+               "count-only%s | %.1f modelled | link-bound: %.1f ms of links, %.1f ms of local work of which %.1f exposed | | |"
                % (mm["modelled_Gtuples_per_s_per_gpu"], (", %.1f materialising" % mt["modelled_Gtuples_per_s_per_gpu"]) if mt else "", mm["modelled_step_ms"], mm["link_ms"], mm["local_ms_total"], mm["exposed_local_ms"]))
     return out
 
 
 def model_rows(_wide=True):
-    out = ["| G | bytes per link direction | link ms | local ms total | exposed local ms (first split + last pass 1 + last group's pass 2 and join) | modelled step: count-only | modelled step: materialising | per-GPU Gtuples/s (count / materialising) |",
-           "|---|---|---|---|---|---|---|---|"]
-    for g, lab in (("2", "2"), ("4", "4"), ("8", "8"), ("8_single_group", "8, probe side joined in one group (`--single-group`)")):
-        d = load("phantom" + g)[0]
+    out = ["| G | bytes per link direction | link ms | local ms total | exposed local ms (first split + last pass 1 + last group's pass 2 and join) | modelled step: count-only | modelled step: materialising | per-GPU Gtuples/s (count / materialising) | aggregate Gtuples/s, count-only (one GPU alone: the headline row) |",
+           "|---|---|---|---|---|---|---|---|---|"]
+    for g, lab in (("2", "2 (weak: 2^30 per relation per GPU)"), ("4", "4"), ("8", "8"), ("8_single_group", "8, probe side joined in one group (`--single-group`)"),
+                   ("2_strong", "2, STRONG shape: 2^30 per relation in total = 2^29 per GPU"), ("4_strong", "4, strong: 2^28 per GPU"), ("8_strong", "8, strong: 2^27 per GPU")):
+        try:
+            d = load("phantom" + g)[0]
+        except FileNotFoundError:
+            continue
         m = d["dist"]["model"]
         mt = (d.get("materialize") or {}).get("model") or {}
-        out.append("| %s | %.2f GB | %.1f | %.1f | %.1f | %.1f ms | %s | %.1f / %s |"
+        out.append("| %s | %.2f GB | %.1f | %.1f | %.1f | %.1f ms | %s | %.1f / %s | %.0f |"
                    % (lab, m["bytes_per_link_direction"] / 1e9, m["link_ms"], m["local_ms_total"], m["exposed_local_ms"], m["modelled_step_ms"],
                       ("%.1f ms (local %.1f, exposed %.1f)" % (mt["modelled_step_ms"], mt["local_ms_total"], mt["exposed_local_ms"])) if mt else "—",
-                      m["modelled_Gtuples_per_s_per_gpu"], ("%.1f" % mt["modelled_Gtuples_per_s_per_gpu"]) if mt else "—"))
+                      m["modelled_Gtuples_per_s_per_gpu"], ("%.1f" % mt["modelled_Gtuples_per_s_per_gpu"]) if mt else "—", m["gpus"] * m["modelled_Gtuples_per_s_per_gpu"]))
     return out
 
 
@@ -132,7 +139,7 @@ def step_rows():
     return ["Per step at 2^30⋈2^30 (`profiles/%s_bench_2p30.json`; the evidence call's process in brackets): 2 × `k_part1_fast` + 2 × `k_part2_fast` + `k_join_count` =" % ROUND,
             "%.2f + %.2f + %.2f = %.1f ms (%.2f + %.2f + %.2f = %.1f ms) of kernels measured one at a time; the timed step runs S's two passes on a second"
             % (k["k_part1_fast"]["ms_per_step"], k["k_part2_fast"]["ms_per_step"], k["k_join_count"]["ms_per_step"], tot, ke["k_part1_fast"]["ms_per_step"], ke["k_part2_fast"]["ms_per_step"], ke["k_join_count"]["ms_per_step"], tote),
-            "stream beside R's (§3.5) and takes **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (the driver's runs: r4 15.14 ms = 141.8, r3 15.24 = 140.9, r2 17.27; round 1: 20.0–20.4)."
+            "stream beside R's (§3.5) and takes **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (the driver's runs: r5 15.65 ms = 137.2, r4 15.14 = 141.8, r3 15.24 = 140.9, r2 17.27; round 1: 20.0–20.4)."
             % (b30["ms_per_step"], b30["value"], e30["ms_per_step"], e30["value"]),
             "Materialising step: **%.2f ms = %.1f Gtuples/s (%.2f ms = %.1f)** (round 2, two probes: 22.3–23.3 ms = 92–96)."
             % (m["ms_per_step"], m["value"], me["ms_per_step"], me["value"])]
