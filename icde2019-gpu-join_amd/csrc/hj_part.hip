@@ -292,6 +292,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                                         uint64_t *__restrict__ oend, uint32_t *__restrict__ ovf,
                                         const uint32_t *__restrict__ remap = nullptr, const HotArgs *hotp = nullptr) {
     static_assert(HOT == 0 || (SRC == 0 && !EXACT && MODE == 0), "the bypass belongs to pass 1 of the histogram-free passes");
+    constexpr bool BALANCED = VAR && !EXACT; // the flush of phase C from ONE list per workgroup (the sampled passes)
     int2 *buf = L_.buf;
     uint32_t *hh = L_.hh, *line = L_.line;
     const uint32_t kshift = KFIX ? (uint32_t)__builtin_ctz((unsigned)KFIX) : 31u - (uint32_t)__builtin_clz((uint32_t)MAX_PARTS / P);
@@ -364,7 +365,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
     const uint2 *hk2 = reinterpret_cast<const uint2 *>(L_.hk);
     uint32_t *hwtot = L_.hot, *hwpre = L_.hot + 16;                                   // HOT 2: hits per wave / their exclusive prefix
     unsigned long long *hbase = reinterpret_cast<unsigned long long *>(L_.hot + 32); // HOT 2: the round's reservation
-    uint32_t hcnt = 0, hw = 0; // HOT 1: this thread's hits / hit bits of the round's 8 tuples
+    uint32_t hcnt = 0, hw = 0; // HOT 1: this WAVE's hits (wave-uniform) / hit bits of the round's 8 tuples
     uint64_t hagg = 0;
     unsigned long long hres = 0;
     // HOT 2: the hits of the round whose tuples are in (kk, pp) go out — every wave runs the same ballots
@@ -420,6 +421,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         // another workgroup gave up (a slot overflowed somewhere): stop moving data that will be thrown away.  One
         // thread polls the flag, the workgroup learns it through LDS behind the round's barriers (uniform exit).
         if (!EXACT && tid == 0 && (round & 3u) == 0) L_.wlist[(WC_THREADS / 64) * 32] = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (BALANCED && tid == 0) L_.wlist[(WC_THREADS / 64) * 32 + 1] = 0; // the flush list of phase C is empty (read last behind the last barrier of the round before)
         if (tid < P) { // the lines flushed last round move this digit's output position
             const uint32_t w = hprev[tid];
             const uint32_t full = ((w >> 16) + (w & 0xFFFFu)) & ~(uint32_t)(WC_LINE - 1);
@@ -456,7 +458,10 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
                     if (HOT == 1) hagg += hit ? (uint64_t)((int64_t)(int32_t)en.y * (int64_t)elem(pp[u], e)) : (uint64_t)0;
                     if (HOT == 2) htot += (uint32_t)__popcll(__ballot(hit));
                 }
-            if (HOT == 1) hcnt += (uint32_t)__popc(hw);
+            if (HOT == 1) { // the wave's hits, counted in scalar registers (the kernel has no vector register to spare)
+#pragma unroll
+                for (int j = 0; j < U * 4; j++) hcnt += (uint32_t)__popcll(__ballot((hw >> j) & 1u));
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -555,11 +560,24 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
             fullq_n = (fullq_n < capq ? fullq_n : capq) >> 5; // full lines of that digit
             const bool fullq = (ln < 32u) && ((VAR ? lsl - (ltq & 0xFFFFu) : (lsl & (K - 1))) < fullq_n);
             const uint64_t m = __ballot(fullq);
-            const uint32_t nfull = (uint32_t)__popcll(m);
-            if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = lsl;
-            __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
+            uint32_t nfull = (uint32_t)__popcll(m), t0 = 0, tstep = 8;
+            if (BALANCED) { // lines dealt by need (VAR): the full lines of a round sit with the waves that own the heavy digits' lines — one
+                            // list for the workgroup, every wave takes every 16th group of 8 lines (one more barrier; config 4's pass 1:
+                            // 1.1 us of 6.5 per round were waves waiting for the slowest one's lines, profiles/r6_hot_bypass.txt)
+                uint32_t *gn = L_.wlist + (WC_THREADS / 64) * 32 + 1;
+                uint32_t gbase = 0;
+                if (ln == 0 && nfull) gbase = atomicAdd(gn, nfull);
+                gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+                if (fullq) L_.wlist[gbase + (uint32_t)__popcll(m & (((uint64_t)1 << ln) - 1))] = lsl;
+                __syncthreads();
+                nfull = *gn; t0 = wv * 8; tstep = (WC_THREADS / 64) * 8;
+                wlist = L_.wlist;
+            } else {
+                if (fullq) wlist[__popcll(m & (((uint64_t)1 << ln) - 1))] = lsl;
+                __builtin_amdgcn_wave_barrier(); // DS operations of one wave execute in order
+            }
             const uint32_t c4 = (ln & 7u) * 4;
-            for (uint32_t t = 0; t < nfull; t += 8) {
+            for (uint32_t t = t0; t < nfull; t += tstep) {
                 const uint32_t idx = t + (ln >> 3);
                 if (idx < nfull) {
                     const uint32_t ls = wlist[idx];
@@ -599,7 +617,7 @@ __device__ __forceinline__ void wc_fast(const WfLds &L_, const int32_t *__restri
         hot_emit();
     }
     if (HOT == 1) { // one atomic pair per workgroup
-        const uint64_t wc = wave_sum64((uint64_t)hcnt), wa = wave_sum64(hagg);
+        const uint64_t wc = (uint64_t)hcnt, wa = wave_sum64(hagg); // (hcnt is the WAVE's count already)
         unsigned long long *red = reinterpret_cast<unsigned long long *>(L_.hot);
         if (ln == 0) { red[wv] = wc; red[16 + wv] = wa; }
         __syncthreads();
