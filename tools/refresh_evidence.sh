@@ -16,4 +16,4 @@ $G --timeout 1800 -- 'bash tools/gpu_bench_lines.sh' | tail -4; ok
 bash tools/copy_evidence.sh lines
 $G --timeout 3600 -- 'bash tools/gpu_kernel_coverage.sh' | tail -3; ok
 cp gpurun_out/coverage/kernel_coverage.txt profiles/${ROUND}_kernel_coverage.txt
-python3 tools/update_docs.py
+[ "$SKIP_DOCS" = 1 ] || python3 tools/update_docs.py
