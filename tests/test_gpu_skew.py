@@ -140,7 +140,10 @@ def test_skewed_exact_passes_deal_lines_by_need(P, cfg):
                                        (dict(bits1=9, bits2=7), 1 << 20, 1 << 24), (dict(bits1=9, bits2=8), 1 << 20, 3 << 22),
                                        (dict(bits1=8, bits2=8), 1 << 21, 1 << 24),
                                        # a 512-way SECOND pass under skew (one line per child, the hot child's overflow leaves tuple by tuple)
-                                       (dict(bits1=6, bits2=9), 1 << 20, 3 << 22)])
+                                       (dict(bits1=6, bits2=9), 1 << 20, 3 << 22),
+                                       # few heads: 9 radix bits + log2(16 heads) < 16, so the tables hold FULL keys (since round 6 every default
+                                       # shape takes 16-bit tags): the full-key kernels over list items
+                                       (dict(bits1=5, bits2=4, lds_heads=16, lds_capacity=600), 1 << 16, 1 << 20)])
 def test_sampled_path_for_a_skewed_probe_side(P, cfg, nR, nS):
     """A skewed relation on the probe side: the first join finds its slots overflowing, samples the key distribution once and
     from then on partitions it with the histogram-free passes at per-digit capacities (layout 'sampled': a partition is a list

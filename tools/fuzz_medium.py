@@ -59,6 +59,9 @@ for seed in range(FIRST, FIRST + n_cases):
                 hj.partition(P.REL_R); hj.partition(P.REL_S)
                 k, pr, ps = hj.join_materialize(cap=em)
                 okc = okc and len(k) == em and o.triples_checksum(k, pr, ps) == echk
+                # round 6: partition both + one probe in ONE call (a skewed probe side's hot keys are written by pass 1), then a count on what it left
+                k, pr, ps = hj.join_and_materialize(cap=em)
+                okc = okc and len(k) == em and o.triples_checksum(k, pr, ps) == echk and hj.join_count() == (em, eagg)
             hj.configure(exact_only=exact, build_side=bside, graph=True, **fb)
             for _ in range(3):
                 okc = okc and hj.join() == (em, eagg)
