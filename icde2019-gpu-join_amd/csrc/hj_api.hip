@@ -567,6 +567,7 @@ int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag
         if (rc < 0) return rc;
         if (rc > 0 || !R.sph.valid) { R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = true; want_hot = false; } // the plain plan below
     }
+    if (!want_hot && b1 + b2 > 17) return 0; // (18 radix bits only with the bypass: *done stays false, the exact passes take the relation)
     Rel::Sampled &sp = want_hot ? R.sph : R.sp;
     if (!sp.valid || sp.n != R.n || sp.b1 != b1 || sp.b2 != b2 || c->replan) {
         sp.valid = false;
@@ -696,13 +697,14 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     // 18.9 ms where the exact passes take 24.6, at 17 bits 23.6 against 26.9; at 18 bits both passes are 512-way, a heavy digit has
     // ONE LDS line and most of its tuples bypass it: no faster than the exact passes, the materialising join slower (profiles/
     // r4_sampled_16_17_bits.txt)
-    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= 17 && c->fast_path && !c->cfg.exact_only &&
+    // the heavy-hitter bypass: asked for by the running entry point (hj_join: count; hj_join_and_materialize: write), for the PROBE side
+    // of the join, whose other side is there to be looked at
+    const bool want_hot = c->hot_request && c->hot_enable && r == 1 - c->build && !R.hot_useless && c->rel[1 - r].bound && c->rel[1 - r].n &&
+                          !c->rel[c->build].sampled && !c->rel[c->build].prefer_exact;
+    // (round 6: with the bypass the sampled path also takes 18 radix bits — what made a 512-way pass under skew no faster than the exact passes
+    // was the hot digits' tuples leaving tuple by tuple, and those are the tuples the bypass takes out; without it the cap stays at 17)
+    if (R.prefer_exact && !R.sampled_failed && !R.force_exact && b2 && b1 + b2 <= (want_hot ? 18u : 17u) && c->fast_path && !c->cfg.exact_only &&
         R.n >= ((uint64_t)1 << 20)) {
-        // the heavy-hitter bypass: asked for by the running entry point (hj_join: count; hj_join_and_materialize: write), for the PROBE side
-        // of the join, whose other side is there to be looked at
-        const Rel &O = c->rel[1 - r];
-        const bool want_hot = c->hot_request && c->hot_enable && r == 1 - c->build && !R.hot_useless && O.bound && O.n && !c->rel[c->build].sampled &&
-                              !c->rel[c->build].prefer_exact;
         bool done = false;
         RET(partition_sampled(c, r, b1, b2, flag, &done, want_hot));
         if (done) return 0;

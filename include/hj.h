@@ -192,8 +192,9 @@ int hj_host_split(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t
 /* The split hj_join_coprocess itself runs (round 5): ONE pass over the input, no histogram.  A partition comes out as a list of
  * blocks of the output columns — each worker takes fixed-size blocks from its own arena as its partitions fill up, the reference's
  * bucket-chain layout (join-primitives.cu:138-192) on the host — which is all the uploads need.  out_keys / out_pays hold cap >=
- * hj_host_split_blocks_capacity(n, parts, threads) tuples (64-byte aligned for the streaming stores); out_pays is written only when
- * pays is given.  Block i holds block_count[i] tuples of partition block_part[i] at out_*[block_start[i]..]; blocks come sorted by
+ * hj_host_split_blocks_capacity(n, parts, threads) tuples; out_pays is written only when pays is given.  Alignment: with out_keys and
+ * out_pays 64-byte aligned whole lines leave with non-temporal AVX2 stores; any other alignment is accepted and takes plain stores (same
+ * result, the destination lines are then read for ownership first: slower, never wrong).  Block i holds block_count[i] tuples of partition block_part[i] at out_*[block_start[i]..]; blocks come sorted by
  * (partition, start).  *n_blocks = blocks produced; HJ_ECAPACITY if cap or max_blocks is too small.  No GPU involved. */
 uint64_t hj_host_split_blocks_capacity(uint64_t n, uint32_t parts, uint32_t threads);
 int hj_host_split_blocks(const int32_t *keys, const int32_t *pays, uint64_t n, uint32_t parts, uint32_t threads,
