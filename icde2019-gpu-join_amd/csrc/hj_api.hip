@@ -550,6 +550,40 @@ int plan_sampled_impl(hj_ctx *c, Rel &R, uint32_t b1, uint32_t b2, Rel::Sampled 
 
 int ensure_part(hj_ctx *c, Buf &b, size_t bytes);
 
+// ---- a look before the first optimistic attempt (round 6; VERDICT r5 item 4's first-call cost) ----
+// The histogram-free passes are optimistic: on a heavily skewed relation the first call on a binding used to pay a whole failed attempt (both
+// passes over the relation: 8-9 ms at 2^31 tuples), partition buffers sized for it (then re-allocated larger for the sampled path: device
+// allocations are the bulk of a first call) and only then the sample.  For a large relation nothing is known about, 2^16 of its keys are
+// counted by pass-1 and by pass-2 digit first (k_skew_probe + 4 KiB read back: ~50 us): a digit at more than twice its share (+6 sigma) means
+// slots WILL overflow, and the relation goes to the sampled path at once.  Milder skew is not seen by so small a sample and is found by the attempt,
+// as before.  Once per binding; never inside a captured step (the eager first call of a binding comes first).
+int skew_probe(hj_ctx *c, Rel &R) {
+    if (R.probed) return 0;
+    R.probed = true;
+    if (!c->skew_probe_log2 || R.n < ((uint64_t)1 << c->skew_probe_log2) || R.prefer_exact || !c->bits2 || !c->fast_path || c->cfg.exact_only ||
+        c->bits1 + c->bits2 > 18 || c->bits1 > 9 || c->bits2 > 9) return 0;
+    const double t0 = now_ms(), a0 = c->prof.alloc_ms;
+    const uint32_t nsamp = 1u << 16, P1 = 1u << c->bits1, P2 = 1u << c->bits2;
+    if (R.n < (uint64_t)nsamp * 16) return 0;
+    RET(ensure(c, c->probe_hist, 1024 * 4));
+    uint32_t h[1024];
+    HIPCHK(c, hipMemsetAsync(c->probe_hist.p, 0, 1024 * 4, c->stream));
+    { Timed t(c, "k_skew_probe"); HIPCHK(c, launch_skew_probe(c->stream, R.in_k, R.n, nsamp, c->bits1, c->bits2, (uint32_t *)c->probe_hist.p)); }
+    HIPCHK(c, hipMemcpyAsync(h, c->probe_hist.p, (size_t)(P1 + P2) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto over = [&](const uint32_t *v, uint32_t cnt) {
+        const double mean = (double)nsamp / cnt;
+        uint32_t mx = 0;
+        for (uint32_t i = 0; i < cnt; i++) mx = std::max(mx, v[i]);
+        return (double)mx > 2.0 * mean + 6.0 * std::sqrt(mean);
+    };
+    const bool skew1 = over(h, P1), skew2 = over(h + P1, P2);
+    if (skew1 || skew2) R.prefer_exact = true; // what a failed attempt would have taught
+    if (c->debug) fprintf(stderr, "[hj] skew probe of %llu tuples: pass-1 digits %s, pass-2 digits %s\n", (unsigned long long)R.n, skew1 ? "skewed" : "flat", skew2 ? "skewed" : "flat");
+    c->prof.plan_ms += (now_ms() - t0) - (c->prof.alloc_ms - a0);
+    return 0;
+}
+
 // the two launches; *done = false when the relation cannot take this path (the caller goes on to the exact passes)
 int partition_sampled(hj_ctx *c, int r, uint32_t b1, uint32_t b2, uint32_t *flag, bool *done, bool want_hot) {
     Rel &R = c->rel[r];
@@ -648,6 +682,7 @@ int partition_rel(hj_ctx *c, int r, FastPair *defer, bool assume_clean) {
     if (c->force_sampled & (1 << r)) R.prefer_exact = true; // experiment knob: this relation takes the sampled path whatever its distribution
     else if (c->force_sampled & (4 << r)) { R.prefer_exact = false; R.sampled_failed = false; } // bits 2, 3: forget what was learned (back to the plain passes)
     choose_bits(c);
+    RET(skew_probe(c, R));
     bool histogram_free = false; // the relation will take the plain or the sampled histogram-free passes (neither reads R.root)
     {
         const uint32_t P1g = 1u << c->bits1, P2g = 1u << c->bits2;
@@ -1066,6 +1101,7 @@ static void read_knobs(hj_ctx *c) {
     if (const char *tl = getenv("HJ_TAGS_LEGACY")) c->tags_legacy = atoi(tl) != 0;
     if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
     if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
+    if (const char *sk = getenv("HJ_SKEW_PROBE")) c->skew_probe_log2 = (uint32_t)std::max(0, std::min(63, atoi(sk))); // 0: no look before the first attempt
     c->debug = getenv("HJ_DEBUG") != nullptr;
 }
 
@@ -1137,7 +1173,7 @@ int hj_destroy(hj_ctx *c) {
     release(c->shard_root); release(c->shard_off);
     if (c->h_shard_off) (void)hipHostFree(c->h_shard_off);
     release(c->items_cnt); release(c->items); release(c->wave_counts); release(c->wave_agg);
-    release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars);
+    release(c->jchunk_sums); release(c->jchunk_prefix); release(c->scalars); release(c->probe_hist);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1207,6 +1243,7 @@ int hj_load_host(hj_ctx *c, int rel, const int32_t *keys, const int32_t *pays, u
     R.n = n;
     R.bound = true;
     R.prefer_exact = false; // new data: the histogram-free passes get their chance again
+    R.probed = false;
     R.sampled_failed = false; R.sp.valid = false; R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = false;
     { Rel &O = c->rel[1 - rel]; O.sph.valid = false; O.sph.hot_ready = false; O.hot_useless = false; } // its bypass plan looked at THIS relation's keys
     invalidate(c, rel);
@@ -1220,7 +1257,7 @@ int hj_bind_device(hj_ctx *c, int rel, const int32_t *d_keys, const int32_t *d_p
     Rel &R = c->rel[rel];
     // re-binding the same columns keeps what the last run learned about them (skewed keys: exact passes at once)
     if (R.in_k != d_keys || R.in_p != d_pays || R.n != n) {
-        R.prefer_exact = false; R.sampled_failed = false; R.sp.valid = false; R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = false;
+        R.prefer_exact = false; R.probed = false; R.sampled_failed = false; R.sp.valid = false; R.sph.valid = false; R.sph.hot_ready = false; R.hot_useless = false;
         Rel &O = c->rel[1 - rel]; // its bypass plan looked at THIS relation's keys
         O.sph.valid = false; O.sph.hot_ready = false; O.hot_useless = false;
     }

@@ -51,6 +51,7 @@ struct Rel {
     uint32_t pb1 = 0, pb2 = 0; // radix bits this relation was partitioned with
     bool partitioned = false;
     bool fast_tried = false;   // the histogram-free passes were queued: which layout holds is known on the device only
+    bool probed = false;       // the look before the first attempt on this binding (skew_probe) has been taken
     bool prefer_exact = false; // the last histogram-free attempt on this binding overflowed: go straight to the exact passes
     bool flag_known_good = false; // fast_tried and the flag has been read as 0 since: the slotted ranges are valid
     // what the host knows about the relation's overflow flag ON THE DEVICE: kernels that may raise it were queued and nobody has read
@@ -128,6 +129,8 @@ struct hj_ctx {
     bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
     bool debug = false;             // HJ_DEBUG: stderr diagnostics
     int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)
+    uint32_t skew_probe_log2 = 26;  // HJ_SKEW_PROBE: relations of at least 2^this tuples get a look at 2^16 keys before their first optimistic attempt (0 = never)
+    Buf probe_hist;
     double hot_min_share = 0.10;    // HJ_HOT_MIN_SHARE: smallest sampled share of the relation worth the lookups
     hipStream_t copy = nullptr;     // H2D of the next probe segment
     Buf shard_root, shard_off;      // hj_shard_split: persistent (no allocation in the steady state)

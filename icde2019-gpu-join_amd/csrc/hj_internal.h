@@ -150,6 +150,7 @@ struct VarArgs {
     const uint4 *wg;              // pass 2: per workgroup {parent d, first pass-1 span, spans, output position of its sub-slots}
     HotArgs hot;                  // pass 1: the heavy-hitter bypass
 };
+hipError_t launch_skew_probe(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t b1, uint32_t b2, uint32_t *hist);
 hipError_t launch_hot_sample(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t *tkey, uint32_t *tcnt, uint32_t slots);
 hipError_t launch_hot_collect(hipStream_t st, const uint32_t *tkey, const uint32_t *tcnt, uint32_t slots, uint32_t thr, uint2 *out, uint32_t *nout, uint32_t cap);
 hipError_t launch_hot_build(hipStream_t st, const int32_t *keys, const int32_t *pays, uint64_t n, const uint32_t *cand, uint32_t *cnt, int32_t *pay, unsigned long long *zero_acc);

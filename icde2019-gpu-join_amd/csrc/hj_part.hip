@@ -894,6 +894,30 @@ __global__ __launch_bounds__(WC_THREADS) void k_part1_var(FastArgs a, VarArgs v)
     else wc_fast<U, 0, 0, false, HEAVY, true, 0, HOT>(L_, a.keys, a.pays, lo, hi, a.n, 0, a.shift, a.P, g, a.out_keys, a.out_pays, a.obeg, a.oend, a.ovf, nullptr, &v.hot);
 }
 
+// ---- a look at a large relation BEFORE its first optimistic attempt (round 6) ----
+// nsamp keys, one per stratum of n / nsamp tuples at a hashed offset inside it (a fixed stride would alias with sorted or strided keys), counted by
+// pass-1 digit (hist[0 .. P1)) and by pass-2 digit (hist[P1 .. P1 + P2)): the host reads the P1 + P2 counters and sends a relation with a digit far
+// above its share straight to the sampled path — no failed attempt, no partition buffers allocated for it.  P1 + P2 <= 1024; hist zero at launch.
+__global__ __launch_bounds__(1024) void k_skew_probe(const int32_t *__restrict__ keys, uint64_t n, uint32_t nsamp, uint32_t b1, uint32_t b2, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[1024];
+    const uint32_t tid = threadIdx.x, i = blockIdx.x * 1024 + tid, P1 = 1u << b1, P2 = 1u << b2;
+    h[tid] = 0;
+    __syncthreads();
+    if (i < nsamp) {
+        const uint64_t stride = n / nsamp;
+        const uint64_t pos = (uint64_t)i * stride + (uint64_t)fmix32(i * 0x9E3779B1u + 0x7F4A7C15u) % stride;
+        const uint32_t key = (uint32_t)keys[pos];
+        atomicAdd(&h[(key >> b2) & (P1 - 1)], 1u);
+        atomicAdd(&h[P1 + (key & (P2 - 1))], 1u);
+    }
+    __syncthreads();
+    if (tid < P1 + P2 && h[tid]) atomicAdd(&hist[tid], h[tid]);
+}
+hipError_t launch_skew_probe(hipStream_t st, const int32_t *keys, uint64_t n, uint32_t nsamp, uint32_t b1, uint32_t b2, uint32_t *hist) {
+    hipLaunchKernelGGL(k_skew_probe, dim3((nsamp + 1023) / 1024), dim3(1024), 0, st, keys, n, nsamp, b1, b2, hist);
+    return hipGetLastError();
+}
+
 // ---- the heavy-hitter bypass: finding the candidates (once per binding) and what the other relation holds for them (every step) ----
 // k_hot_sample: nsamp keys of the relation (runs of 16, evenly spread) counted in an open-addressing table in HBM (slots >= 2 * nsamp)
 __global__ __launch_bounds__(256) void k_hot_sample(const int32_t *__restrict__ keys, uint64_t n, uint32_t nsamp, uint32_t *__restrict__ tkey,

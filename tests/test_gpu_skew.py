@@ -450,3 +450,51 @@ def test_heavy_hitter_bypass_under_a_captured_step(P):
         for i in range(5):
             assert hj.join() == (em, eagg), i
         assert hj.hot_stats()["mode"] == 1
+
+
+# ---- the look before the first optimistic attempt (round 6) ----
+
+@pytest.mark.parametrize("kind", ["zipf", "uniform", "sorted", "low_bits_constant"])
+def test_look_before_the_first_attempt(P, monkeypatch, kind):
+    """A relation nothing is known about gets 2^16 of its keys counted by pass-1 and pass-2 digit before its first histogram-free attempt
+    (relations of >= 2^26 tuples by default; HJ_SKEW_PROBE lowers the bar here).  Heavy skew — a Zipf(1.0) probe side, keys whose low bits never
+    change — goes to the sampled path at once: no failed attempt in the first call's breakdown; uniform and sorted keys stay on the plain passes
+    (the sample positions are hashed: a fixed stride over sorted keys would put every sample into one digit).  Results against the oracle
+    either way, and the old sequence (attempt, flag, redo) with the look switched off."""
+    import torch
+    nR, nS = 1 << 18, 3 << 20
+    rng = np.random.default_rng(11)
+    if kind == "zipf":
+        R, S = _zipf_fk(P, nR, nS, 1.0, 778)
+    elif kind == "uniform":
+        R = rng.permutation(nR).astype(np.int32); S = rng.integers(0, nR, nS).astype(np.int32)
+    elif kind == "sorted":
+        R = np.arange(nR, dtype=np.int32); S = np.arange(nS, dtype=np.int32)
+    else:
+        nR = 1 << 20   # (large enough to be looked at itself: its pass-2 digit is as degenerate as S's)
+        R = (rng.permutation(nR) * 128).astype(np.int32); S = (rng.integers(0, nR, nS) * 128).astype(np.int32)
+    Pr = rng.integers(-2**31, 2**31 - 1, nR).astype(np.int32)
+    Ps = rng.integers(-2**31, 2**31 - 1, nS).astype(np.int32)
+    em, eagg, echk = o.join_count(R, Pr, S, Ps, checksum=True)
+    dR, dPr, dS, dPs = (torch.from_numpy(x).cuda() for x in (R, Pr, S, Ps))
+    skewed = kind in ("zipf", "low_bits_constant")
+    for probe in ("20", "0"):
+        monkeypatch.setenv("HJ_SKEW_PROBE", probe)
+        with P.HashJoin(0) as hj:
+            hj.configure(bits1=8, bits2=7)
+            hj.bind_device(P.REL_R, dR, dPr)
+            hj.bind_device(P.REL_S, dS, dPs)
+            assert hj.join() == (em, eagg)
+            bd = hj.last_call_breakdown()
+            lay = hj.partition_layout(P.REL_S)
+            if probe == "20":
+                assert bd["failed_optimistic_attempt_ms"] == 0, bd
+                assert (lay != "slotted") == skewed, lay
+                if kind == "zipf":
+                    assert lay == "sampled" and hj.hot_stats()["mode"] == 1
+            elif skewed:
+                assert bd["failed_optimistic_attempt_ms"] > 0 and lay != "slotted", (bd, lay)
+            for _ in range(2):
+                assert hj.join() == (em, eagg)
+            k, pr, ps = hj.join_and_materialize(cap=em)
+            assert len(k) == em and o.triples_checksum(k, pr, ps) == echk
