@@ -1086,7 +1086,7 @@ void hj_invalidate_all(hj_ctx *c) {
 // ================================================================================================
 extern "C" {
 
-const char *hj_version(void) { return "hj-mi355x 0.5 (gfx950)"; }
+const char *hj_version(void) { return "hj-mi355x 0.6 (gfx950)"; }
 
 // every experiment / test knob the single-GPU path reads (DESIGN.md §9 lists them): once per context
 static void read_knobs(hj_ctx *c) {

@@ -61,6 +61,7 @@ int stream_probe(hj_ctx *c, const int32_t *h_keys, const int32_t *h_pays, uint64
     bool out_used[2] = {false, false};
     c->rel[HJ_REL_S].prefer_exact = false; // every call streams new data: the histogram-free passes get their chance again
     c->rel[HJ_REL_S].sampled_failed = false; c->rel[HJ_REL_S].sp.valid = false;
+    c->rel[HJ_REL_S].probed = true; // no look before the attempt for streamed segments: it reads back, and the segment loop never blocks the host
     const bool saved_force = c->force_build_r;
     c->force_build_r = true; // R builds, whatever the segment size; radix bits follow |R|
     // R is partitioned once (hjcp.cu:1874-1892), against an S stand-in of one segment so the bits are fixed
