@@ -829,13 +829,14 @@ def leg_roofline(B):
     use_dist, world = _take(B, "use_dist", "world")
     # roofline of the dominant kernel: a radix pass over one relation (4 launches per step at N=1: 2 passes x 2
     # relations), 16 algorithmic bytes per tuple per launch (8 B read + 8 B written)
-    passes = ("k_part1_fast", "k_part2_fast", "k_scatter_wc", "k_scatter")
+    # (up to 2^29 tuples in all the two relations' passes are ONE launch per pass: k_part1_fast2 / k_part2_fast2 move both relations)
+    passes = ("k_part1_fast", "k_part2_fast", "k_part1_fast2", "k_part2_fast2", "k_scatter_wc", "k_scatter")
     dom = max(passes, key=lambda k: kt.get(k, {}).get("total_ms", 0.0))
     sc = kt.get(dom, {"launches": 0, "total_ms": 0.0})
     roof = None
     if sc["launches"] and not use_dist:
         launches_per_step = sc["launches"] / isteps
-        tuples_per_launch = float(n)  # every pass launch moves one whole relation (keys + payloads)
+        tuples_per_launch = float(n) * (2 if dom.endswith("fast2") else 1)  # a pass launch moves one whole relation (keys + payloads); a merged one, both
         avg_ms = sc["total_ms"] / sc["launches"]
         achieved = 16.0 * tuples_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/): separate
@@ -855,9 +856,11 @@ def leg_roofline(B):
                 "traffic_source": (src + " (rocprofv3 --pmc passes of this command)") if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": 16.0 * tuples_per_launch,
-                "measured": "instrumented steps: kernel events on, the passes of R and S on ONE stream (a kernel alone on the chip); the timed "
-                            "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
-                            "committed kernel stats are taken with HJ_FORK_LOG2=0)"}
+                "measured": ("instrumented steps: kernel events on; up to 2^29 tuples in all, one launch per pass moves BOTH relations (the same "
+                             "launches as in the timed steps)") if dom.endswith("fast2") else
+                            ("instrumented steps: kernel events on, the passes of R and S on ONE stream (a kernel alone on the chip); the timed "
+                             "steps run S's passes on a second stream beside R's (rocprofv3 of those shows overlapped kernel durations; the "
+                             "committed kernel stats are taken with HJ_FORK_LOG2=0)")}
         if not a.no_extras:
             # The bound of THIS box, same run: a pass reads 8 B and writes 8 B per tuple, and no kernel with that mix can beat
             # (R + W) / (R / read_only + W / write_only), the two one-way streams measured by hj_ubench kinds 2 / 3 on the same columns.

@@ -178,7 +178,17 @@ void choose_bits(hj_ctx *c) {
         // a build partition averages 2048-4096 tuples — the join kernel's sweet spot (bit sweep at 2^26-2^28,
         // profiles/r2_bits_sweep.txt: a 7-bit floor for the second pass, round 1's rule, now costs 5-11 %)
         c->bits1 = 9;
-        c->bits2 = total - 9;
+        // Round 6 (profiles/r6_bits_split.txt): for two relations of SIMILAR size — the larger at most 1.5 x the smaller — up to 16 radix
+        // bits, a first pass of 7 bits: their passes run side by side on two streams, and 128 + 128 pass-2 workgroups (one per parent) are
+        // resident on the 256 CUs at once and finish together, where 512 + 512 take four turns with a prologue and a partial-line
+        // epilogue each.  2^22-2^28 tuples a side: -1 ... -27 % per step (2^27: -1.3 %, 2^26: -7 %, 2^24: -10 %, 96 M: -19 %); never
+        // more than 0.7 % behind 9 bits in the sweep.  With sizes apart the larger relation's pass 2 would be alone on the chip with 128
+        // workgroups (2^27 x 2^31: +22 %): 9 bits stay; so do the streaming probe (segments of any size against one R) and the ranks
+        // of the multi-GPU join (slices, not relations, run side by side there).
+        const uint64_t nl = std::max(nR, nS), nsm = std::min(nR, nS);
+        const uint32_t bs = c->bits1_similar;
+        if (bs && bs < 9 && !c->force_build_r && !c->keep_nine && total > bs && total - bs <= 9 && nsm && nl <= nsm + nsm / 2) c->bits1 = bs;
+        c->bits2 = total - c->bits1;
     }
     if (!g.lds_heads) { // hash-table heads ~ 2x the average build partition, power of two in [256, 4096]
         uint64_t avg = nb >> (c->bits1 + c->bits2);
@@ -1101,6 +1111,7 @@ static void read_knobs(hj_ctx *c) {
     if (const char *tl = getenv("HJ_TAGS_LEGACY")) c->tags_legacy = atoi(tl) != 0;
     if (const char *ho = getenv("HJ_HOT")) c->hot_enable = atoi(ho);
     if (const char *hm = getenv("HJ_HOT_MIN_SHARE")) c->hot_min_share = atof(hm);
+    if (const char *bs = getenv("HJ_BITS1_SIMILAR")) c->bits1_similar = (uint32_t)std::max(0, std::min(9, atoi(bs))); // 0 or 9: the first pass always takes 9 bits (rounds 2-5)
     if (const char *sk = getenv("HJ_SKEW_PROBE")) c->skew_probe_log2 = (uint32_t)std::max(0, std::min(63, atoi(sk))); // 0: no look before the first attempt
     c->debug = getenv("HJ_DEBUG") != nullptr;
 }
@@ -1357,9 +1368,10 @@ int partition_both(hj_ctx *c) {
     const bool fork = c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->fork_log2) && c->events == 0;
     // Small and medium inputs: ONE launch per pass for both relations (k_part1_fast2 / k_part2_fast2), one stream, no event fork and
     // join, no k_set_root in front of a relation whose flag is known to be 0, the join's item counter zeroed by pass 2: a steady-state
-    // step is pass 1, pass 2, plan, build+probe, sum, result copy.  Not with kernel events on (the instrumented steps time one
-    // relation's kernel alone on the chip), not for relations of very different sizes (their passes are arranged by priority below).
-    if (c->merge_log2 && c->events == 0 && c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->merge_log2) && c->rel[0].n && c->rel[1].n &&
+    // step is pass 1, pass 2, plan, build+probe, sum, result copy.  With kernel events on as well (round 6: the instrumented steps time the
+    // kernels a step really launches — with a 7-bit first pass one relation's pass 2 alone is 128 workgroups on 256 CUs, which no step
+    // ever runs).  Not for relations of very different sizes (their passes are arranged by priority below).
+    if (c->merge_log2 && c->rel[0].n + c->rel[1].n <= ((uint64_t)1 << c->merge_log2) && c->rel[0].n && c->rel[1].n &&
         std::max(c->rel[0].n, c->rel[1].n) < 4 * std::min(c->rel[0].n, c->rel[1].n)) {
         FastPair pr[2];
         for (int r = 0; r < 2; r++) {

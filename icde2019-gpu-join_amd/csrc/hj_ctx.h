@@ -129,6 +129,8 @@ struct hj_ctx {
     bool replan = false;            // HJ_REPLAN (experiments): re-plan the sampled geometry at every call
     bool debug = false;             // HJ_DEBUG: stderr diagnostics
     int hot_enable = 1;             // HJ_HOT=0: never bypass (A/B)
+    uint32_t bits1_similar = 7;     // HJ_BITS1_SIMILAR: bits of the first pass when the two relations are of similar size (choose_bits); 0 / 9 = always 9
+    bool keep_nine = false;         // a rank of the multi-GPU join: its slices, not its relations, run side by side — the first pass keeps 9 bits
     uint32_t skew_probe_log2 = 26;  // HJ_SKEW_PROBE: relations of at least 2^this tuples get a look at 2^16 keys before their first optimistic attempt (0 = never)
     Buf probe_hist;
     double hot_min_share = 0.10;    // HJ_HOT_MIN_SHARE: smallest sampled share of the relation worth the lookups

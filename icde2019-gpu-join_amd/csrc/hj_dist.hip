@@ -601,7 +601,7 @@ int join_fast(hj_dist_rank *r, const int32_t *const cols[4], const uint64_t n[2]
     *applicable = false;
     // radix bits from the nominal sizes (every rank computes the same)
     for (int x = 0; x < 2; x++) { c->rel[x].n = nmax[x]; c->rel[x].bound = true; }
-    choose_bits(c);
+    { const bool kn = c->keep_nine; c->keep_nine = true; choose_bits(c); c->keep_nine = kn; } // (slices run side by side here, not relations: 9 bits first)
     const uint32_t b1 = c->bits1, b2 = c->bits2;
     if (!b2 || !c->fast_path || c->cfg.exact_only) return 0; // single-pass sizes: exact path
     const uint32_t P1 = 1u << b1, P2 = 1u << b2;

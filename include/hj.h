@@ -44,7 +44,8 @@ enum {
  * a build partition fits the LDS hash table; replaces the compile-time log_parts1/log_parts2 of
  * src/common.h:51-52). */
 typedef struct hj_config {
-    uint32_t bits1;        /* radix bits of pass 1 (key bits [bits2, bits2+bits1)); 0 = auto */
+    uint32_t bits1;        /* radix bits of pass 1 (key bits [bits2, bits2+bits1)); 0 = auto (total from the smaller relation's size; 7 bits first
+                              for two relations of similar size up to 16 bits in all, 9 otherwise) */
     uint32_t bits2;        /* radix bits of pass 2 (key bits [0, bits2)); 0 with bits1!=0 = single pass */
     uint32_t force_bits;   /* 1: take bits1/bits2 literally (bits1=bits2=0 → no partitioning) */
     uint32_t build_side;   /* 0 auto (smaller relation, ties → R), 1 = R, 2 = S — a hint: bits follow the smaller relation, and a skewed or larger build relation lets the smaller PARTITION build (jp.cu:929-1003) */
