@@ -78,7 +78,7 @@ def results_rows():
                   c["value"], c["cores"], "full size" if "full size" in c["sample"] else "bounded sample", (c.get("best_effort") or {}).get("value", float("nan")), c["joinCpu"]["value"]))
     out.append("| 3, exact (histogram) passes only | %.1f | %.2f | `k_scatter_wc` + `k_hist` | | |" % (bx["value"], bx["ms_per_step"]))
     p, c = b27["probe_phase"], b27["cpu_baseline"]
-    out.append("| **2: 2^27 ⋈ 2^27, default 9+6 bits** | **%.1f** %s(%.1f; r5 124.7, r4 127.7) | %.2f (%.2f) | %s; `k_join` %.3f ms = %.2f (target %.3f from the measured fixed cost: %s) | %s | %.3f; own host code %.2f |"
+    out.append("| **2: 2^27 ⋈ 2^27, default 15 bits = 7+8 (r5: 9+6)** | **%.1f** %s(%.1f; r5 124.7, r4 127.7) | %.2f (%.2f) | %s; `k_join` %.3f ms = %.2f (target %.3f from the measured fixed cost: %s) | %s | %.3f; own host code %.2f |"
                % (b27["value"], tp(b27), e27["value"], b27["ms_per_step"], e27["ms_per_step"], roof(b27), p["avg_launch_ms"], p["frac_of_8TBs"], p["target_frac"],
                   "met" if p["meets_target"] else "NOT met", mat(b27), c["value"], (c.get("best_effort") or {}).get("value", float("nan"))))
     s = b27.get("config2_as_stated") or {}
